@@ -1,0 +1,175 @@
+"""ctypes binding of libddx_hip.so (the C ABI declared in include/ddx_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the HIP library is missing or a call fails this module
+raises.  PyTorch is used only for device memory, streams and (later) torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libddx_hip.so")
+
+DDX_F32, DDX_BF16 = 0, 1
+RESAMPLE_KEEP, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
+PRO_NONE, PRO_SILU, PRO_SCALE, PRO_SCALE_SILU = 0, 1, 2, 3
+EPI_STORE, EPI_MPSUM = 0, 1
+
+
+class DDXError(RuntimeError):
+    pass
+
+
+class WPrepDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("gain_ptr", C.c_void_p), ("gain", C.c_float),
+                ("w_dtype", C.c_int32), ("wp_dtype", C.c_int32), ("Cout", C.c_int32), ("Cg", C.c_int32),
+                ("ksize", C.c_int32), ("groups", C.c_int32), ("CK", C.c_int32), ("normalize", C.c_int32),
+                ("qk_head_dim", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("chan_scale", C.c_void_p), ("wp", C.c_void_p),
+                ("residual", C.c_void_p), ("out", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("C0", C.c_int32), ("C1", C.c_int32), ("Cout", C.c_int32), ("groups", C.c_int32), ("ksize", C.c_int32),
+                ("CK", C.c_int32), ("resample", C.c_int32), ("prologue", C.c_int32), ("epilogue", C.c_int32),
+                ("scale0", C.c_float), ("scale1", C.c_float), ("res_t", C.c_float), ("clip", C.c_float),
+                ("dtype", C.c_int32), ("force_direct", C.c_int32)]
+
+
+class LinearJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("gain_ptr", C.c_void_p), ("out", C.c_void_p), ("gain", C.c_float),
+                ("add_const", C.c_float), ("O", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
+                ("normalize", C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
+PROTOTYPES = {
+    "ddx_version": (C.c_char_p, []),
+    "ddx_last_error": (C.c_char_p, []),
+    "ddx_wprep_bytes": (C.c_size_t, [C.c_int32] * 6),
+    "ddx_mpconv_wprep": (C.c_int, [C.POINTER(WPrepDesc), C.c_void_p]),
+    "ddx_normalize_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "ddx_mpconv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ddx_mpconv2d_pick_ck": (C.c_int32, [C.c_int32] * 3),
+    "ddx_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                               C.c_int32, C.c_void_p]),
+    "ddx_linear_small_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_void_p]),
+    "ddx_mpfourier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_mpsum_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_void_p]),
+    "ddx_unet_input_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_unet_output_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_plan_begin": (C.c_void_p, []),
+    "ddx_plan_end": (C.c_int, [C.c_void_p]),
+    "ddx_plan_num_ops": (C.c_int, [C.c_void_p]),
+    "ddx_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_plan_graph_build": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_plan_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_plan_destroy": (None, [C.c_void_p]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libddx_hip.so (once).  Raises DDXError when the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise DDXError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+                           "dualdiffusion_amd has no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ddx_last_error().decode()
+        raise DDXError(f"libddx_hip call failed ({what}): rc={rc} {msg}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return DDX_F32
+    if dt == torch.bfloat16:
+        return DDX_BF16
+    raise DDXError(f"unsupported dtype {dt}: the HIP path computes in float32 or bfloat16")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DDXError("tensor is not on a ROCm device: dualdiffusion_amd has no CPU path")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Plan:
+    """Recorded launch sequence (ddx_plan_*): record with `with plan.record():`, then run() / graph_launch()."""
+
+    def __init__(self) -> None:
+        self._h = None
+        self._graph = False
+        self.keepalive: list = []  # descriptors / tensors referenced by the recorded closures
+
+    def record(self):
+        plan = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                h = lib().ddx_plan_begin()
+                if not h:
+                    raise DDXError("ddx_plan_begin failed: " + lib().ddx_last_error().decode())
+                plan._h = h
+                return plan
+
+            def __exit__(self_inner, et, ev, tb):
+                check(lib().ddx_plan_end(plan._h), "plan_end")
+                return False
+
+        return _Ctx()
+
+    @property
+    def num_ops(self) -> int:
+        return lib().ddx_plan_num_ops(self._h) if self._h else 0
+
+    def run(self, stream: Optional[int] = None) -> None:
+        check(lib().ddx_plan_run(self._h, stream if stream is not None else current_stream()), "plan_run")
+
+    def graph_build(self, stream: Optional[int] = None) -> None:
+        check(lib().ddx_plan_graph_build(self._h, stream if stream is not None else current_stream()), "plan_graph_build")
+        self._graph = True
+
+    def graph_launch(self, stream: Optional[int] = None) -> None:
+        check(lib().ddx_plan_graph_launch(self._h, stream if stream is not None else current_stream()), "plan_graph_launch")
+
+    @property
+    def has_graph(self) -> bool:
+        return self._graph
+
+    def __del__(self):
+        try:
+            if self._h and _lib is not None:
+                _lib.ddx_plan_destroy(self._h)
+        except Exception:
+            pass

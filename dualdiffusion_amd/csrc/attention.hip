@@ -1,0 +1,263 @@
+// Self-attention over the H*W tokens of an NHWC feature map, flash-style on the gfx950 matrix cores.
+//
+// Replaces reference src/modules/unets/unet_edm2_b4.py:137-148: q,k,v RMS-normalised over the head dimension per
+// token (normalize(dim=2)), then softmax(q k^T / sqrt(d)) v.  The q/k/v normalisation and the 1/sqrt(d) scale are
+// fused into the LDS staging; the score matrix never leaves registers.
+//
+// One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+//   S^T tile (32 keys x 32 queries) = K_tile . Q^T   : MFMA A operand = K rows (keys), B operand = Q (queries)
+//   -> every lane holds 16 keys of ONE query column: the softmax statistics are per-lane plus one cross-half shuffle.
+//   O^T tile (32 dims x 32 queries) += V^T . P^T     : A operand = V^T rows (dims), B operand = P straight from the
+//   S^T accumulator registers (the key order inside an MFMA k-slot is arbitrary as long as A and B agree, so no
+//   cross-lane permutation of P is needed; V^T is staged transposed so the matching keys are contiguous).
+#include "common.hpp"
+
+namespace ddx {
+
+template <typename T> struct AttnMma;
+template <> struct AttnMma<bf16> {
+  static constexpr int KM = 16, VPAD = 4;
+  using Frag = bf16x8;
+};
+template <> struct AttnMma<float> {
+  static constexpr int KM = 2, VPAD = 1;
+  using Frag = float;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
+                                                       int B, int Tn, int heads, float eps) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  constexpr int VPR = D / EV;           // 16-byte vectors per token row
+  constexpr int RPP = 256 / VPR;        // rows staged per pass
+  constexpr int QS = D + EV;            // Q / K row stride (elements)
+  constexpr int KC = 128;               // keys per chunk
+  constexpr int VS = KC + AttnMma<T>::VPAD;
+  constexpr int KM = AttnMma<T>::KM;
+  constexpr int NDT = D / 32;           // 32-row tiles of O^T
+  constexpr int NKT = KC / 32;
+  using Frag = typename AttnMma<T>::Frag;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sQ = reinterpret_cast<T*>(smem);
+  T* sK = sQ + 128 * QS;
+  T* sVt = sK + KC * QS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int q0 = blockIdx.x * 128;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int C = heads * D;
+  const float inv_sqrt_d = rsqrtf((float)D);
+
+  const int sv = tid % VPR;        // vector inside the row handled by this thread while staging
+  const int sr = tid / VPR;
+
+  // ---- stage Q (normalised, pre-scaled by 1/sqrt(D))
+  for (int r = sr; r < 128; r += RPP) {
+    const int q = q0 + r;
+    Vec16<T> x;
+    float f[EV];
+    float ss = 0.f;
+    if (q < Tn) {
+      x.v = *reinterpret_cast<const decltype(x.v)*>(qk + ((size_t)b * Tn + q) * (2 * C) + head * 2 * D + sv * EV);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) { f[e] = x.get(e); ss += f[e] * f[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EV; ++e) f[e] = 0.f;
+    }
+#pragma unroll
+    for (int o = VPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float sc = inv_sqrt_d / (eps + sqrtf(ss) * inv_sqrt_d);
+    Vec16<T> y;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) y.set(e, f[e] * sc);
+    *reinterpret_cast<decltype(y.v)*>(sQ + r * QS + sv * EV) = y.v;
+  }
+  __syncthreads();
+
+  // Q fragments of this wave's 32 queries stay in registers
+  Frag qf[D / KM];
+#pragma unroll
+  for (int ks = 0; ks < D / KM; ++ks) {
+    const T* rp = sQ + (wave * 32 + l31) * QS + ks * KM;
+    if constexpr (sizeof(T) == 2) qf[ks] = *reinterpret_cast<const bf16x8*>(rp + khalf * 8);
+    else qf[ks] = rp[khalf];
+  }
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  for (int c0 = 0; c0 < Tn; c0 += KC) {
+    __syncthreads();  // previous chunk fully consumed
+    // ---- stage K (normalised) and V^T (normalised, transposed)
+    for (int r = sr; r < KC; r += RPP) {
+      const int key = c0 + r;
+      float fk[EV], fv[EV];
+      float ssk = 0.f, ssv = 0.f;
+      if (key < Tn) {
+        Vec16<T> xk, xv;
+        xk.v = *reinterpret_cast<const decltype(xk.v)*>(qk + ((size_t)b * Tn + key) * (2 * C) + head * 2 * D + D + sv * EV);
+        xv.v = *reinterpret_cast<const decltype(xv.v)*>(v + ((size_t)b * Tn + key) * C + head * D + sv * EV);
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+          fk[e] = xk.get(e); ssk += fk[e] * fk[e];
+          fv[e] = xv.get(e); ssv += fv[e] * fv[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EV; ++e) { fk[e] = 0.f; fv[e] = 0.f; }
+      }
+#pragma unroll
+      for (int o = VPR / 2; o > 0; o >>= 1) { ssk += __shfl_xor(ssk, o, 64); ssv += __shfl_xor(ssv, o, 64); }
+      const float sck = 1.0f / (eps + sqrtf(ssk) * inv_sqrt_d);
+      const float scv = 1.0f / (eps + sqrtf(ssv) * inv_sqrt_d);
+      Vec16<T> yk;
+#pragma unroll
+      for (int e = 0; e < EV; ++e) yk.set(e, fk[e] * sck);
+      *reinterpret_cast<decltype(yk.v)*>(sK + r * QS + sv * EV) = yk.v;
+#pragma unroll
+      for (int e = 0; e < EV; ++e) sVt[(sv * EV + e) * VS + r] = from_f32<T>(fv[e] * scv);
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T for the NKT key tiles of the chunk
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (c0 + kt * 32 < Tn) {
+#pragma unroll
+        for (int ks = 0; ks < D / KM; ++ks) {
+          const T* rp = sK + (kt * 32 + l31) * QS + ks * KM;
+          if constexpr (sizeof(T) == 2)
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rp + khalf * 8), qf[ks], s[kt], 0, 0, 0);
+          else
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[khalf], qf[ks], s[kt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- online softmax (per lane = per query column; halves hold disjoint keys)
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = c0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (key >= Tn) s[kt][r] = -1e30f;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(s[kt][r] - m_new);
+        s[kt][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (c0 + kt * 32 >= Tn) continue;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 pf;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) pf[kk] = (bf16)s[kt][8 * j + kk];
+          const int kb = kt * 32 + 16 * j + 4 * khalf;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            const T* vp = sVt + (dt * 32 + l31) * VS + kb;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vp + 8);
+            bf16x8 vf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+          const int kl = kt * 32 + (st & 3) + 8 * (st >> 2) + 4 * khalf;
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sVt[(dt * 32 + l31) * VS + kl], s[kt][st], oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- finalise: O / l, lane owns query q, 4 consecutive dims per register group
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  const int q = q0 + wave * 32 + l31;
+  if (q < Tn) {
+    T* orow = out + ((size_t)b * Tn + q) * C + head * D;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        Vec4<T> ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov.set(e, oacc[dt][4 * g4 + e] * inv_l);
+        *reinterpret_cast<decltype(ov.v)*>(orow + dt * 32 + 8 * g4 + 4 * khalf) = ov.v;
+      }
+  }
+}
+
+template <typename T, int D>
+static int launch_attn(const void* qk, const void* v, void* out, int B, int Tn, int heads, float eps, hipStream_t s) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  constexpr int KC = 128;
+  const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + (size_t)D * (KC + AttnMma<T>::VPAD)) * sizeof(T);
+  if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim too large for this dtype");
+  auto kern = attn_fwd_kernel<T, D>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(attn)");
+    attr_done = true;
+  }
+  dim3 grid((Tn + 127) / 128, heads, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, B, Tn, heads, eps);
+  return check_launch("attn_fwd");
+}
+
+}  // namespace ddx
+
+using namespace ddx;
+
+extern "C" int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
+                            float eps, int32_t dtype, ddx_stream stream) {
+  if (!qk || !v || !out || B <= 0 || T <= 0 || heads <= 0) return set_error(DDX_ERR_ARG, "attn: bad args");
+  if (head_dim != 32 && head_dim != 64 && head_dim != 128) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim must be 32, 64 or 128");
+  return dispatch([=](hipStream_t s) -> int {
+    if (dtype == DDX_BF16) {
+      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, B, T, heads, eps, s);
+      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, B, T, heads, eps, s);
+      return launch_attn<bf16, 128>(qk, v, out, B, T, heads, eps, s);
+    }
+    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, B, T, heads, eps, s);
+    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, B, T, heads, eps, s);
+    return launch_attn<float, 128>(qk, v, out, B, T, heads, eps, s);
+  }, stream);
+}

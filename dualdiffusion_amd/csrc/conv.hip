@@ -1,0 +1,141 @@
+// C-ABI entry points for the magnitude-preserving conv path: weight preparation (fused weight-norm + gain + cast +
+// re-layout, reference src/modules/mp_tools.py:359-364), forced weight normalisation (:375-378) and the conv forward
+// dispatcher (MFMA implicit GEMM or the scalar kernel).
+#include <cmath>
+
+#include "conv_params.hpp"
+
+namespace ddx {
+
+// one workgroup per (destination) output channel
+template <typename TW_, typename TP>
+__global__ __launch_bounds__(256) void wprep_kernel(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr,
+                                                    float gain, int Cout, int Cg, int taps, int G, int CK, int normalize,
+                                                    int qk_d, float eps) {
+  __shared__ float scratch[4];
+  const int od = blockIdx.x;
+  const int Ng = Cout / G, NgP = (Ng + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
+  const int g = od / Ng, n = od - g * Ng;
+  int os = od;
+  if (qk_d > 0) {  // destination (head, s, d) <- source (head, d, s)
+    const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
+    const int s = rem / qk_d, dd = rem - s * qk_d;
+    os = head * 2 * qk_d + dd * 2 + s;
+  }
+  const int fan = Cg * taps;
+  const TW_* wr = w + (size_t)os * fan;
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
+    ss = block_sum_256(ss, scratch);
+    inv = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  }
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float sc = gn / sqrtf((float)fan);
+  for (int i = threadIdx.x; i < fan; i += 256) {
+    const int c = i / taps, tap = i - c * taps;
+    float x = to_f32<TW_>(wr[i]);
+    if (normalize) x = x / inv;
+    wp[wp_index(g, n, tap, c, nchunk, taps, NgP, CK)] = from_f32<TP>(x * sc);
+  }
+}
+
+template <typename TW_>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(TW_* w, int64_t fan, float eps) {
+  __shared__ float scratch[4];
+  TW_* wr = w + (size_t)blockIdx.x * fan;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
+  ss = block_sum_256(ss, scratch);
+  const float nrm = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  for (int64_t i = threadIdx.x; i < fan; i += 256) wr[i] = from_f32<TW_>(to_f32<TW_>(wr[i]) / nrm);
+}
+
+}  // namespace ddx
+
+using namespace ddx;
+
+extern "C" size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32_t groups, int32_t CK, int32_t dtype) {
+  if (groups <= 0 || CK <= 0) return 0;
+  const int Ng = Cout / groups, NgP = round_up(Ng, 32), nchunk = ceil_div(Cg, CK);
+  return (size_t)groups * nchunk * ksize * ksize * NgP * CK * dtype_size(dtype);
+}
+
+extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype) {
+  (void)dtype;
+  if (ksize == 1 && Cg >= 64) return 64;
+  return 32;
+}
+
+extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
+  if (!dp || !dp->w || !dp->wp) return set_error(DDX_ERR_ARG, "wprep: null");
+  const ddx_wprep_desc d = *dp;
+  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 32 && d.CK != 64))
+    return set_error(DDX_ERR_ARG, "wprep: bad shape");
+  if (d.qk_head_dim > 0 && (d.groups != 1 || d.Cout % (2 * d.qk_head_dim))) return set_error(DDX_ERR_ARG, "wprep: bad qk_head_dim");
+  return dispatch([d](hipStream_t s) -> int {
+    const int taps = d.ksize * d.ksize;
+    const int Ng = d.Cout / d.groups;
+    const size_t bytes = ddx_wprep_bytes(d.Cout, d.Cg, d.ksize, d.groups, d.CK, d.wp_dtype);
+    if (round_up(Ng, 32) != Ng || d.Cg % d.CK) {
+      if (hipMemsetAsync(d.wp, 0, bytes, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "wprep: memset");
+    }
+#define DDX_WPREP(TWT, TPT)                                                                                         \
+  hipLaunchKernelGGL((wprep_kernel<TWT, TPT>), dim3(d.Cout), dim3(256), 0, s, (const TWT*)d.w, (TPT*)d.wp, d.gain_ptr, \
+                     d.gain, d.Cout, d.Cg, taps, d.groups, d.CK, d.normalize, d.qk_head_dim, 1e-4f)
+    if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_F32) DDX_WPREP(float, float);
+    else if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_BF16) DDX_WPREP(float, bf16);
+    else if (d.w_dtype == DDX_BF16 && d.wp_dtype == DDX_BF16) DDX_WPREP(bf16, bf16);
+    else if (d.w_dtype == DDX_BF16 && d.wp_dtype == DDX_F32) DDX_WPREP(bf16, float);
+    else return set_error(DDX_ERR_ARG, "wprep: dtype");
+#undef DDX_WPREP
+    return check_launch("wprep");
+  }, stream);
+}
+
+extern "C" int ddx_normalize_weights(void* w, int32_t w_dtype, int64_t rows, int64_t fan_in, ddx_stream stream) {
+  if (!w || rows <= 0 || fan_in <= 0) return set_error(DDX_ERR_ARG, "normalize_weights: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    if (w_dtype == DDX_F32)
+      hipLaunchKernelGGL(normalize_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, (float*)w, fan_in, 1e-4f);
+    else
+      hipLaunchKernelGGL(normalize_rows_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, s, (bf16*)w, fan_in, 1e-4f);
+    return check_launch("normalize_weights");
+  }, stream);
+}
+
+extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
+  if (!dp) return set_error(DDX_ERR_ARG, "conv: null descriptor");
+  const ddx_conv_desc d = *dp;
+  if (!d.src0 || !d.wp || !d.out) return set_error(DDX_ERR_ARG, "conv: null buffer");
+  if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.C0 <= 0 || d.Cout <= 0 || d.groups <= 0) return set_error(DDX_ERR_ARG, "conv: bad size");
+  if ((d.C1 > 0) != (d.src1 != nullptr)) return set_error(DDX_ERR_ARG, "conv: src1/C1 mismatch");
+  const int Cin = d.C0 + d.C1;
+  if (Cin % d.groups || d.Cout % d.groups) return set_error(DDX_ERR_ARG, "conv: channels not divisible by groups");
+  if (d.ksize != 1 && d.ksize != 3) return set_error(DDX_ERR_UNSUPPORTED, "conv: ksize must be 1 or 3");
+  if ((d.prologue & DDX_PRO_SCALE) && !d.chan_scale) return set_error(DDX_ERR_ARG, "conv: chan_scale missing");
+  if (d.epilogue == DDX_EPI_MPSUM && !d.residual) return set_error(DDX_ERR_ARG, "conv: residual missing");
+  if (d.resample == DDX_RESAMPLE_UP && ((d.H | d.W) & 1)) return set_error(DDX_ERR_ARG, "conv: upsampled size must be even");
+  if (d.dtype != DDX_F32 && d.dtype != DDX_BF16) return set_error(DDX_ERR_ARG, "conv: dtype");
+
+  ConvParams p{};
+  p.src0 = d.src0; p.src1 = d.src1; p.cscale = d.chan_scale; p.wp = d.wp; p.res = d.residual; p.out = d.out;
+  p.B = d.B; p.H = d.H; p.W = d.W;
+  p.sH = d.resample == DDX_RESAMPLE_UP ? d.H / 2 : (d.resample == DDX_RESAMPLE_DOWN ? d.H * 2 : d.H);
+  p.sW = d.resample == DDX_RESAMPLE_UP ? d.W / 2 : (d.resample == DDX_RESAMPLE_DOWN ? d.W * 2 : d.W);
+  p.C0 = d.C0; p.C1 = d.C1; p.Cin = Cin; p.Cout = d.Cout; p.G = d.groups;
+  p.Cg = Cin / d.groups; p.Ng = d.Cout / d.groups; p.NgP = round_up(p.Ng, 32);
+  p.CK = d.CK; p.nchunk = ceil_div(p.Cg, d.CK);
+  p.resample = d.resample; p.prologue = d.prologue; p.epilogue = d.epilogue;
+  p.scale0 = d.scale0; p.scale1 = d.scale1;
+  const float t = d.res_t, nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
+  p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;
+  p.clip = d.clip;
+  const int ks = d.ksize, dt = d.dtype;
+  const bool mfma = !d.force_direct && conv_mfma_supported(p, ks, dt);
+  return dispatch([p, ks, dt, mfma](hipStream_t s) -> int {
+    return mfma ? launch_conv_mfma(p, ks, dt, s) : launch_conv_direct(p, ks, dt, s);
+  }, stream);
+}

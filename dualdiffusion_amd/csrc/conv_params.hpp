@@ -1,0 +1,38 @@
+// Device-side parameter block shared by the MFMA and the scalar conv kernels.
+#pragma once
+#include "common.hpp"
+
+namespace ddx {
+
+struct ConvParams {
+  const void* src0;
+  const void* src1;
+  const float* cscale;
+  const void* wp;
+  const void* res;
+  void* out;
+  int B, H, W;        // output size
+  int sH, sW;         // source size (H/2 for UP, 2H for DOWN)
+  int C0, C1, Cin;    // source channel counts, Cin = C0 + C1
+  int Cout, G, Cg, Ng, NgP;
+  int nchunk, CK;
+  int resample, prologue, epilogue;
+  float scale0, scale1;
+  float res_a, res_b;  // out = res * res_a + acc * res_b
+  float clip;
+  // spatial tiling (MFMA kernel)
+  int TH, TW, tiles_h, tiles_w, arows_alloc;
+  float inv_TWP;
+};
+
+// index into the prepared weight tensor wp[g][chunk][tap][NgP][CK]
+__host__ __device__ inline size_t wp_index(int g, int n, int tap, int c, int nchunk, int taps, int NgP, int CK) {
+  return ((((size_t)g * nchunk + c / CK) * taps + tap) * NgP + n) * CK + (c % CK);
+}
+
+int launch_conv_mfma(const ConvParams& p, int ksize, int dtype, hipStream_t s);   // conv_mfma.hip
+bool conv_mfma_supported(const ConvParams& p, int ksize, int dtype);
+void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype);
+int launch_conv_direct(const ConvParams& p, int ksize, int dtype, hipStream_t s);  // conv_direct.hip
+
+}  // namespace ddx

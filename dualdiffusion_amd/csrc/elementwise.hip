@@ -1,0 +1,301 @@
+// HBM-bound glue kernels of the UNet forward: pixel-norm, input/output preconditioning, layout conversion, the
+// noise-embedding front end and the small-M linear layers.  All are bandwidth- or latency-bound: coalesced 16-byte
+// accesses, wave shuffles for the reductions, no LDS staging needed.
+#include "common.hpp"
+
+namespace ddx {
+
+// ---------------------------------------------------------------------------------------------- pixel norm
+// reference: normalize(x, dim=1) (src/modules/mp_tools.py:42-49) as used at unet_edm2_b4.py:117.
+// NHWC rows are contiguous: one wave per row, 16-byte lanes, two passes over registers (row cached when C small).
+template <typename T>
+__global__ __launch_bounds__(256) void pixelnorm_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int C, float eps) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float inv_sqrt_c = rsqrtf((float)C);
+  for (int64_t r = wave_id; r < rows; r += nwaves) {
+    const T* xr = x + r * C;
+    T* yr = y + r * C;
+    float ss = 0.f;
+    if (C % EV == 0) {
+      constexpr int MAXV = 4;  // up to 4 vectors per lane cached in registers (C <= 64*4*EV)
+      Vec16<T> cache[MAXV];
+      const int nvec = C / EV;
+      const bool cached = nvec <= 64 * MAXV;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + k * 64;
+        if (cached && vi < nvec) {
+          cache[k].v = *reinterpret_cast<const decltype(cache[k].v)*>(xr + (size_t)vi * EV);
+#pragma unroll
+          for (int e = 0; e < EV; ++e) { const float f = cache[k].get(e); ss += f * f; }
+        }
+      }
+      if (!cached)
+        for (int vi = lane; vi < nvec; vi += 64) {
+          Vec16<T> t; t.v = *reinterpret_cast<const decltype(t.v)*>(xr + (size_t)vi * EV);
+#pragma unroll
+          for (int e = 0; e < EV; ++e) { const float f = t.get(e); ss += f * f; }
+        }
+      ss = wave_sum(ss);
+      const float nrm = eps + sqrtf(ss) * inv_sqrt_c;
+      if (cached) {
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+          const int vi = lane + k * 64;
+          if (vi < nvec) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < EV; ++e) o.set(e, cache[k].get(e) / nrm);
+            *reinterpret_cast<decltype(o.v)*>(yr + (size_t)vi * EV) = o.v;
+          }
+        }
+      } else {
+        for (int vi = lane; vi < nvec; vi += 64) {
+          Vec16<T> t, o; t.v = *reinterpret_cast<const decltype(t.v)*>(xr + (size_t)vi * EV);
+#pragma unroll
+          for (int e = 0; e < EV; ++e) o.set(e, t.get(e) / nrm);
+          *reinterpret_cast<decltype(o.v)*>(yr + (size_t)vi * EV) = o.v;
+        }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) { const float f = to_f32<T>(xr[c]); ss += f * f; }
+      ss = wave_sum(ss);
+      const float nrm = eps + sqrtf(ss) * inv_sqrt_c;
+      for (int c = lane; c < C; c += 64) yr[c] = from_f32<T>(to_f32<T>(xr[c]) / nrm);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- UNet input prep
+// reference unet_edm2_b4.py:257-269,277: x = c_in * x_in ; cat(x, ones, ln_freqs).  Output NHWC with Cpad channels.
+template <typename T>
+__global__ __launch_bounds__(256) void input_prep_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
+                                                         const float* __restrict__ lnf, T* __restrict__ out, int B, int C,
+                                                         int H, int W, int Cpad, float sigma_data) {
+  const size_t npix = (size_t)B * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int b = (int)(i / ((size_t)W * H));
+    const float sg = sigma[b];
+    const float c_in = 1.0f / sqrtf(sigma_data * sigma_data + sg * sg);
+    T* o = out + i * Cpad;
+    for (int c = 0; c < C; ++c) o[c] = from_f32<T>(c_in * x[(((size_t)b * C + c) * H + h) * W + w]);
+    o[C] = from_f32<T>(1.0f);
+    o[C + 1] = from_f32<T>(lnf[h]);
+    for (int c = C + 2; c < Cpad; ++c) o[c] = from_f32<T>(0.f);
+  }
+}
+
+// reference unet_edm2_b4.py:290-296: D_x = c_skip * x_in + c_out * x.float(); optional x_ref inpainting mix.
+template <typename T>
+__global__ __launch_bounds__(256) void output_combine_kernel(const T* __restrict__ y, const float* __restrict__ x_in,
+                                                             const float* __restrict__ sigma, const float* __restrict__ x_ref,
+                                                             float* __restrict__ out, int B, int C, int H, int W, float sd) {
+  const size_t n = (size_t)B * C * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int c = (int)((i / ((size_t)W * H)) % C);
+    const int b = (int)(i / ((size_t)W * H * C));
+    const float sg = sigma[b];
+    const float c_skip = sd * sd / (sg * sg + sd * sd);
+    const float c_out = sg * sd / sqrtf(sg * sg + sd * sd);
+    float d = c_skip * x_in[i] + c_out * to_f32<T>(y[(((size_t)b * H + h) * W + w) * C + c]);
+    if (x_ref) {
+      const float t = x_ref[(((size_t)b * (C + 1) + C) * H + h) * W + w];
+      const float a = x_ref[(((size_t)b * (C + 1) + c) * H + h) * W + w];
+      d = (a + (d - a) * t) / sqrtf((1.f - t) * (1.f - t) + t * t);
+    }
+    out[i] = d;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int H, int W) {
+  const size_t n = (size_t)B * C * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const int b = (int)(pix / ((size_t)W * H));
+    y[i] = from_f32<T>(x[(((size_t)b * C + c) * H + h) * W + w]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W) {
+  const size_t n = (size_t)B * C * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int c = (int)((i / ((size_t)W * H)) % C);
+    const int b = (int)(i / ((size_t)W * H * C));
+    y[i] = to_f32<T>(x[(((size_t)b * H + h) * W + w) * C + c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- embeddings
+// reference MPFourier.forward (mp_tools.py:324-330), fp32.
+__global__ void mpfourier_kernel(const float* __restrict__ x, const float* __restrict__ freqs, const float* __restrict__ phases,
+                                 float* __restrict__ out, int M, int C, int logq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const int b = i / C, c = i - b * C;
+  float v = x[b];
+  if (logq) v = logf(v) / 4.0f;
+  out[i] = cosf(v * freqs[c] + phases[c]) * 1.41421356237309515f;
+}
+
+// reference mp_sum (mp_tools.py:274-279) [+ mp_silu (:268)] on [M][C] fp32 rows.
+__global__ void mpsum_rows_kernel(const float* __restrict__ a, int a_rows, const float* __restrict__ b, const float* __restrict__ t_rows,
+                                  float t, float* __restrict__ out, int M, int C, int silu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const int r = i / C, c = i - r * C;
+  const float tt = t_rows ? t_rows[r] : t;
+  const float av = a[(a_rows == 1 ? 0 : r) * C + c], bv = b[i];
+  float v = (av + (bv - av) * tt) / sqrtf((1.f - tt) * (1.f - tt) + tt * tt);
+  if (silu) v = mp_silu_f(v);
+  out[i] = v;
+}
+
+// Small-M linear layers on raw master weights: one wave per output row o of a job, looping over the M activations
+// rows (M <= 16 per pass).  Weight rows are streamed once with 16-byte lanes; the squared norm for the fused
+// weight-norm comes from the same pass.  reference mp_tools.py:359-367.
+template <typename TW_>
+__global__ __launch_bounds__(256) void linear_small_kernel(const ddx_linear_job* __restrict__ jobs, const float* __restrict__ x,
+                                                           int x_stride, int M, float eps) {
+  const ddx_linear_job jb = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= jb.O) return;
+  const TW_* wr = reinterpret_cast<const TW_*>(jb.w) + (size_t)o * jb.K;
+  const int og = jb.O / jb.groups;
+  const float* xg = x + (size_t)(o / og) * jb.K;  // grouped: channel block of this output row
+  constexpr int MB = 8;
+  for (int m0 = 0; m0 < M; m0 += MB) {
+    float acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+    float ss = 0.f;
+    for (int k = lane; k < jb.K; k += 64) {
+      const float wv = to_f32<TW_>(wr[k]);
+      ss += wv * wv;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+        if (m0 + m < M) acc[m] += wv * xg[(size_t)(m0 + m) * x_stride + k];
+    }
+    ss = wave_sum(ss);
+    float sc = jb.gain;
+    if (jb.gain_ptr) sc *= *jb.gain_ptr;
+    sc *= rsqrtf((float)jb.K);
+    if (jb.normalize) sc /= (eps + sqrtf(ss) * rsqrtf((float)jb.K));
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float r = wave_sum(acc[m]);
+      if (lane == 0 && m0 + m < M) jb.out[(size_t)(m0 + m) * jb.O + o] = r * sc + jb.add_const;
+    }
+  }
+}
+
+static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
+
+}  // namespace ddx
+
+using namespace ddx;
+
+extern "C" int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream) {
+  if (!x || !y || rows <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "pixelnorm: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 16384);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(pixelnorm_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, rows, C, eps);
+    else
+      hipLaunchKernelGGL(pixelnorm_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, rows, C, eps);
+    return check_launch("pixelnorm");
+  }, stream);
+}
+
+extern "C" int ddx_unet_input_prep(const float* x_nchw, const float* sigma, const float* ln_freq_h, void* out_nhwc, int32_t B,
+                                   int32_t C, int32_t H, int32_t W, int32_t Cpad, float sigma_data, int32_t dtype,
+                                   ddx_stream stream) {
+  if (!x_nchw || !sigma || !ln_freq_h || !out_nhwc || Cpad < C + 2) return set_error(DDX_ERR_ARG, "input_prep: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * H * W);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(input_prep_kernel<bf16>, dim3(blocks), dim3(256), 0, s, x_nchw, sigma, ln_freq_h, (bf16*)out_nhwc, B, C, H, W, Cpad, sigma_data);
+    else
+      hipLaunchKernelGGL(input_prep_kernel<float>, dim3(blocks), dim3(256), 0, s, x_nchw, sigma, ln_freq_h, (float*)out_nhwc, B, C, H, W, Cpad, sigma_data);
+    return check_launch("input_prep");
+  }, stream);
+}
+
+extern "C" int ddx_unet_output_combine(const void* y_nhwc, const float* x_in_nchw, const float* sigma, const float* x_ref_nchw,
+                                       float* out_nchw, int32_t B, int32_t C, int32_t H, int32_t W, float sigma_data,
+                                       int32_t dtype, ddx_stream stream) {
+  if (!y_nhwc || !x_in_nchw || !sigma || !out_nchw) return set_error(DDX_ERR_ARG, "output_combine: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * C * H * W);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(output_combine_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)y_nhwc, x_in_nchw, sigma, x_ref_nchw, out_nchw, B, C, H, W, sigma_data);
+    else
+      hipLaunchKernelGGL(output_combine_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)y_nhwc, x_in_nchw, sigma, x_ref_nchw, out_nchw, B, C, H, W, sigma_data);
+    return check_launch("output_combine");
+  }, stream);
+}
+
+extern "C" int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream) {
+  if (!x || !y) return set_error(DDX_ERR_ARG, "nchw_to_nhwc: null");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * C * H * W);
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(blocks), dim3(256), 0, s, x, (bf16*)y, B, C, H, W);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, s, x, (float*)y, B, C, H, W);
+    return check_launch("nchw_to_nhwc");
+  }, stream);
+}
+
+extern "C" int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream) {
+  if (!x || !y) return set_error(DDX_ERR_ARG, "nhwc_to_nchw: null");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * C * H * W);
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, y, B, C, H, W);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, y, B, C, H, W);
+    return check_launch("nhwc_to_nchw");
+  }, stream);
+}
+
+extern "C" int ddx_mpfourier(const float* x, const float* freqs, const float* phases, float* out, int32_t M, int32_t C,
+                             int32_t log_sigma_quarter, ddx_stream stream) {
+  if (!x || !freqs || !phases || !out || M <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "mpfourier: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(mpfourier_kernel, dim3((M * C + 255) / 256), dim3(256), 0, s, x, freqs, phases, out, M, C, log_sigma_quarter);
+    return check_launch("mpfourier");
+  }, stream);
+}
+
+extern "C" int ddx_mpsum_rows(const float* a, int32_t a_rows, const float* b, const float* t_rows, float t, float* out, int32_t M,
+                              int32_t C, int32_t silu, ddx_stream stream) {
+  if (!a || !b || !out || M <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "mpsum_rows: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(mpsum_rows_kernel, dim3((M * C + 255) / 256), dim3(256), 0, s, a, a_rows, b, t_rows, t, out, M, C, silu);
+    return check_launch("mpsum_rows");
+  }, stream);
+}
+
+extern "C" int ddx_linear_small_batched(const ddx_linear_job* jobs_dev, int32_t njobs, int32_t max_O, const float* x, int32_t x_stride,
+                                        int32_t M, int32_t w_dtype, ddx_stream stream) {
+  if (!jobs_dev || njobs <= 0 || max_O <= 0 || !x || M <= 0) return set_error(DDX_ERR_ARG, "linear_small: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    dim3 grid((max_O + 3) / 4, njobs);
+    if (w_dtype == DDX_BF16)
+      hipLaunchKernelGGL(linear_small_kernel<bf16>, grid, dim3(256), 0, s, jobs_dev, x, x_stride, M, 1e-4f);
+    else
+      hipLaunchKernelGGL(linear_small_kernel<float>, grid, dim3(256), 0, s, jobs_dev, x, x_stride, M, 1e-4f);
+    return check_launch("linear_small");
+  }, stream);
+}

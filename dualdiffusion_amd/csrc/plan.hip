@@ -1,0 +1,117 @@
+// Launch plans and error plumbing of libddx_hip.
+//
+// A plan is a recorded list of kernel launches (closures over plain descriptors).  It is replayed with ONE FFI call,
+// either eagerly or as a hipGraph captured from that replay -- the MI355X stand-in for the reference's
+// torch.compile(fullgraph=True) of UNet.forward (reference src/modules/module.py:145-149): shapes are static, so the
+// whole forward is one graph launch with no per-kernel host work.
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+struct ddx_plan {
+  std::vector<ddx::LaunchFn> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool recording = false;
+};
+
+namespace ddx {
+
+static thread_local ddx_plan* g_recording = nullptr;
+static thread_local std::string g_last_error;
+
+int set_error(int code, const char* msg) {
+  g_last_error = msg ? msg : "";
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return DDX_ERR_LAUNCH;
+  }
+  return DDX_OK;
+}
+
+int dispatch(LaunchFn&& fn, ddx_stream stream) {
+  if (g_recording) {
+    g_recording->ops.emplace_back(std::move(fn));
+    return DDX_OK;
+  }
+  return fn(reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // namespace ddx
+
+extern "C" const char* ddx_version(void) { return "libddx_hip 0.1 (gfx950)"; }
+extern "C" const char* ddx_last_error(void) { return ddx::g_last_error.c_str(); }
+
+extern "C" ddx_plan* ddx_plan_begin(void) {
+  if (ddx::g_recording) { ddx::set_error(DDX_ERR_ARG, "plan_begin: already recording"); return nullptr; }
+  ddx_plan* p = new ddx_plan();
+  p->recording = true;
+  ddx::g_recording = p;
+  return p;
+}
+
+extern "C" int ddx_plan_end(ddx_plan* p) {
+  if (!p || ddx::g_recording != p) return ddx::set_error(DDX_ERR_ARG, "plan_end: not the recording plan");
+  p->recording = false;
+  ddx::g_recording = nullptr;
+  return DDX_OK;
+}
+
+extern "C" int ddx_plan_num_ops(const ddx_plan* p) { return p ? (int)p->ops.size() : -1; }
+
+extern "C" int ddx_plan_run(ddx_plan* p, ddx_stream stream) {
+  if (!p || p->recording) return ddx::set_error(DDX_ERR_ARG, "plan_run: bad plan");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (auto& op : p->ops) {
+    const int rc = op(s);
+    if (rc != DDX_OK) return rc;
+  }
+  return DDX_OK;
+}
+
+extern "C" int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream) {
+  if (!p || p->recording) return ddx::set_error(DDX_ERR_ARG, "plan_graph_build: bad plan");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipStreamBeginCapture");
+  int rc = DDX_OK;
+  for (auto& op : p->ops) {
+    rc = op(s);
+    if (rc != DDX_OK) break;
+  }
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc != DDX_OK) { if (g) hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess || !g) return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipStreamEndCapture");
+  hipGraphExec_t ex = nullptr;
+  if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(g);
+    return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipGraphInstantiate");
+  }
+  p->graph = g;
+  p->exec = ex;
+  return DDX_OK;
+}
+
+extern "C" int ddx_plan_graph_launch(ddx_plan* p, ddx_stream stream) {
+  if (!p || !p->exec) return ddx::set_error(DDX_ERR_ARG, "plan_graph_launch: graph not built");
+  if (hipGraphLaunch(p->exec, reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+    return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_launch: hipGraphLaunch");
+  return DDX_OK;
+}
+
+extern "C" void ddx_plan_destroy(ddx_plan* p) {
+  if (!p) return;
+  if (ddx::g_recording == p) ddx::g_recording = nullptr;
+  if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->graph) hipGraphDestroy(p->graph);
+  delete p;
+}

@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C ABI (libddx_hip.so).
+
+These are the host-side counterparts of the reference's op library (src/modules/mp_tools.py) for the hot
+path: every function enqueues hand-written HIP kernels on the current torch stream; none has a PyTorch
+fallback.  Activations are NHWC (`[B, H, W, C]` contiguous) float32 or bfloat16 device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import check, current_stream, dtype_code, lib, ptr
+
+
+class PreparedWeight:
+    """Output of weight preparation (mp_tools.py:359-364) in the implicit-GEMM layout."""
+
+    __slots__ = ("wp", "Cout", "Cg", "ksize", "groups", "CK", "dtype", "desc")
+
+    def __init__(self, wp, Cout, Cg, ksize, groups, CK, dtype, desc):
+        self.wp, self.Cout, self.Cg, self.ksize, self.groups, self.CK, self.dtype, self.desc = wp, Cout, Cg, ksize, groups, CK, dtype, desc
+
+
+def pick_ck(Cg: int, ksize: int, dtype: torch.dtype) -> int:
+    return int(lib().ddx_mpconv2d_pick_ck(Cg, ksize, dtype_code(dtype)))
+
+
+def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float = 1.0, gain_ptr: Optional[torch.Tensor] = None,
+          normalize: bool = False, qk_head_dim: int = 0, CK: Optional[int] = None, cg_pad: Optional[int] = None,
+          out: Optional[torch.Tensor] = None) -> PreparedWeight:
+    """Prepare MPConv weights `[Cout, Cg, k, k]` for ddx_mpconv2d_fwd.  `cg_pad`: channel count of the activation
+    tensor per group when it is zero-padded beyond the weight's Cg (conv_in: 6 -> 8)."""
+    assert weight.is_contiguous()
+    Cout, Cg = weight.shape[0], weight.shape[1]
+    ksize = weight.shape[2] if weight.ndim == 4 else 1
+    if CK is None:
+        CK = pick_ck(cg_pad or Cg, ksize, dtype)
+    nbytes = lib().ddx_wprep_bytes(Cout, Cg, ksize, groups, CK, dtype_code(dtype))
+    if cg_pad is not None:
+        assert (cg_pad + CK - 1) // CK == (Cg + CK - 1) // CK, "padded channels must stay inside the last K chunk"
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    assert out.numel() >= nbytes
+    d = L.WPrepDesc(w=ptr(weight), wp=ptr(out), gain_ptr=ptr(gain_ptr), gain=float(gain), w_dtype=dtype_code(weight.dtype),
+                    wp_dtype=dtype_code(dtype), Cout=Cout, Cg=Cg, ksize=ksize, groups=groups, CK=CK,
+                    normalize=int(normalize), qk_head_dim=qk_head_dim)
+    check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep")
+    return PreparedWeight(out, Cout, Cg, ksize, groups, CK, dtype, d)
+
+
+def normalize_weights_(weight: torch.Tensor) -> None:
+    """In-place forced weight normalisation (mp_tools.py:375-378)."""
+    rows = weight.shape[0]
+    check(lib().ddx_normalize_weights(ptr(weight), dtype_code(weight.dtype), rows, weight.numel() // rows, current_stream()),
+          "normalize_weights")
+
+
+def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = None, src1: Optional[torch.Tensor] = None,
+           scale0: float = 1.0, scale1: float = 1.0, resample: int = L.RESAMPLE_KEEP, prologue: int = L.PRO_NONE,
+           chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
+           clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False) -> torch.Tensor:
+    """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h)."""
+    B, sH, sW, C0 = src0.shape
+    if out_hw is None:
+        out_hw = {L.RESAMPLE_KEEP: (sH, sW), L.RESAMPLE_UP: (sH * 2, sW * 2), L.RESAMPLE_DOWN: (sH // 2, sW // 2)}[resample]
+    H, W = out_hw
+    C1 = src1.shape[3] if src1 is not None else 0
+    if out is None:
+        out = torch.empty(B, H, W, pw.Cout, dtype=src0.dtype, device=src0.device)
+    d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
+                   B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
+                   prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
+                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=int(force_direct))
+    check(lib().ddx_mpconv2d_fwd(C.byref(d), current_stream()), "mpconv2d_fwd")
+    return out
+
+
+def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4) -> torch.Tensor:
+    """RMS normalisation over the last (channel) axis of contiguous rows."""
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().ddx_pixelnorm_fwd(ptr(x), ptr(out), rows, Cn, eps, dtype_code(x.dtype), current_stream()), "pixelnorm_fwd")
+    return out
+
+
+def attention(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None, eps: float = 1e-4) -> torch.Tensor:
+    """qk `[B, H, W, 2C]` (head, {q,k}, d), v `[B, H, W, C]` (head, d) -> `[B, H, W, C]`."""
+    B, H, W, Cn = v.shape
+    if out is None:
+        out = torch.empty_like(v)
+    check(lib().ddx_attn_fwd(ptr(qk), ptr(v), ptr(out), B, H * W, heads, Cn // heads, eps, dtype_code(v.dtype), current_stream()),
+          "attn_fwd")
+    return out
+
+
+def make_linear_jobs(jobs: list, device) -> torch.Tensor:
+    """Pack [(weight[O,K], gain_ptr|None, out[M,O] fp32, gain, add_const, groups, normalize)] into a device job table."""
+    arr = (L.LinearJob * len(jobs))()
+    for i, (w, gptr, out, gain, addc, groups, normalize) in enumerate(jobs):
+        O = w.shape[0]
+        K = w.numel() // O
+        arr[i] = L.LinearJob(w=ptr(w), gain_ptr=ptr(gptr), out=ptr(out), gain=float(gain), add_const=float(addc), O=O, K=K,
+                             groups=groups, normalize=int(normalize))
+    raw = bytes(arr)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def linear_small(job_table: torch.Tensor, njobs: int, max_O: int, x: torch.Tensor, M: int, w_dtype: torch.dtype,
+                 x_stride: Optional[int] = None) -> None:
+    check(lib().ddx_linear_small_batched(ptr(job_table), njobs, max_O, ptr(x), x_stride if x_stride is not None else x.shape[-1], M,
+                                         dtype_code(w_dtype), current_stream()), "linear_small_batched")
+
+
+def mpfourier(x: torch.Tensor, freqs: torch.Tensor, phases: torch.Tensor, out: torch.Tensor, log_sigma_quarter: bool) -> None:
+    check(lib().ddx_mpfourier(ptr(x), ptr(freqs), ptr(phases), ptr(out), x.numel(), freqs.numel(), int(log_sigma_quarter),
+                              current_stream()), "mpfourier")
+
+
+def mpsum_rows(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, t: float = 0.5, t_rows: Optional[torch.Tensor] = None,
+               silu: bool = False) -> None:
+    M, Cn = b.shape
+    check(lib().ddx_mpsum_rows(ptr(a), a.shape[0] if a.ndim == 2 else 1, ptr(b), ptr(t_rows), float(t), ptr(out), M, Cn, int(silu),
+                               current_stream()), "mpsum_rows")
+
+
+def unet_input_prep(x_nchw: torch.Tensor, sigma: torch.Tensor, ln_freq_h: torch.Tensor, out_nhwc: torch.Tensor, sigma_data: float) -> None:
+    B, Cn, H, W = x_nchw.shape
+    check(lib().ddx_unet_input_prep(ptr(x_nchw), ptr(sigma), ptr(ln_freq_h), ptr(out_nhwc), B, Cn, H, W, out_nhwc.shape[3],
+                                    sigma_data, dtype_code(out_nhwc.dtype), current_stream()), "unet_input_prep")
+
+
+def unet_output_combine(y_nhwc: torch.Tensor, x_in: torch.Tensor, sigma: torch.Tensor, x_ref: Optional[torch.Tensor],
+                        out: torch.Tensor, sigma_data: float) -> None:
+    B, Cn, H, W = x_in.shape
+    check(lib().ddx_unet_output_combine(ptr(y_nhwc), ptr(x_in), ptr(sigma), ptr(x_ref), ptr(out), B, Cn, H, W, sigma_data,
+                                        dtype_code(y_nhwc.dtype), current_stream()), "unet_output_combine")
+
+
+def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, Cn, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, H, W, Cn, dtype=dtype, device=x.device)
+    check(lib().ddx_nchw_to_nhwc(ptr(x), ptr(out), B, Cn, H, W, dtype_code(dtype), current_stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, H, W, Cn = x.shape
+    if out is None:
+        out = torch.empty(B, Cn, H, W, dtype=torch.float32, device=x.device)
+    check(lib().ddx_nhwc_to_nchw(ptr(x), ptr(out), B, Cn, H, W, dtype_code(x.dtype), current_stream()), "nhwc_to_nchw")
+    return out

@@ -1,0 +1,178 @@
+/*
+ * ddx_hip.h -- C ABI of libddx_hip.so: the MI355X (gfx950) kernels behind the EDM2-UNet denoising /
+ * mel-latent hot path of dualdiffusion.
+ *
+ * Conventions (precedent for a native boundary in the reference:
+ * src/training/module_trainers/dae_trainer_m1.py:237-267):
+ *   - every entry point returns 0 (DDX_OK) or a negative ddx_status; nothing allocates, nothing
+ *     synchronises, all buffers are caller-owned device memory, all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*);
+ *   - activations are NHWC ("channels_last", the reference's physical layout,
+ *     src/pipelines/dual_diffusion_pipeline.py:235) in DDX_F32 or DDX_BF16; accumulation is fp32;
+ *   - descriptors are plain C structs of pointers and sizes; no torch types anywhere.
+ *
+ * Each entry point names the reference code (under /root/reference/src) it replaces.
+ */
+#ifndef DDX_HIP_H
+#define DDX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ddx_stream; /* hipStream_t */
+
+enum ddx_dtype { DDX_F32 = 0, DDX_BF16 = 1 };
+enum ddx_status {
+  DDX_OK = 0,
+  DDX_ERR_ARG = -1,         /* malformed descriptor */
+  DDX_ERR_UNSUPPORTED = -2, /* shape / dtype combination not built */
+  DDX_ERR_LAUNCH = -3,      /* HIP launch failure (hipGetLastError) */
+  DDX_ERR_NO_DEVICE = -4
+};
+
+/* Library identity: version string and the gfx arch the kernels were compiled for. */
+const char* ddx_version(void);
+const char* ddx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight preparation  (modules/mp_tools.py:359-364 MPConv.forward weight path, :375-378 normalize_weights)
+ *   w' = [normalize(w)] * gain / sqrt(fan_in), cast, re-laid out for the implicit-GEMM kernel:
+ *   wp[g][chunk][tap][NgP][CK],  Ng = Cout/groups, NgP = roundup(Ng,32), chunk = c/CK within the group,
+ *   zero padded.  gain_eff = gain * (gain_ptr ? *gain_ptr : 1).
+ *   qk_head_dim > 0 re-orders output rows (head, d, {q,k}) -> (head, {q,k}, d)  (unet_edm2_b4.py:137-139).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* w;      /* master weights [Cout][Cg][ks][ks] */
+  void* wp;           /* prepared weights, ddx_wprep_bytes() bytes */
+  const float* gain_ptr;
+  float gain;
+  int32_t w_dtype, wp_dtype;
+  int32_t Cout, Cg, ksize, groups;
+  int32_t CK;         /* K chunk of the consumer kernel: 32 or 64 */
+  int32_t normalize;  /* 1 = forced weight norm inside forward (module.training) */
+  int32_t qk_head_dim;
+} ddx_wprep_desc;
+
+size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32_t groups, int32_t CK, int32_t dtype);
+int ddx_mpconv_wprep(const ddx_wprep_desc* d, ddx_stream stream);
+/* In-place forced weight normalisation of master fp32 weights (mp_tools.py:375-378). rows = Cout. */
+int ddx_normalize_weights(void* w, int32_t w_dtype, int64_t rows, int64_t fan_in, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Magnitude-preserving conv2d forward  (mp_tools.py:366-373 F.conv2d, stride 1, same padding; ksize 1|3)
+ * with the neighbouring element-wise work of Block.forward (unet_edm2_b4.py:110-158) fused in:
+ *   input   = up to two NHWC sources concatenated on channels with scales (mp_cat, mp_tools.py:294-301),
+ *             optionally 2x nearest-upsampled or 2x2 average-pooled on the fly (mp_tools.py:71-79)
+ *   prologue: bit0 = mp_silu (mp_tools.py:268), bit1 = multiply by chan_scale[b][cin]  (y*c, unet_edm2_b4.py:122)
+ *             (scale applied first, then silu)
+ *   epilogue: 0 = store; 1 = mp_sum(residual, y, t) (mp_tools.py:274-279); then clip to +-clip if clip > 0
+ * ------------------------------------------------------------------------------------------------ */
+enum { DDX_RESAMPLE_KEEP = 0, DDX_RESAMPLE_UP = 1, DDX_RESAMPLE_DOWN = 2 };
+enum { DDX_PRO_NONE = 0, DDX_PRO_SILU = 1, DDX_PRO_SCALE = 2, DDX_PRO_SCALE_SILU = 3 };
+enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1 };
+
+typedef struct {
+  const void* src0;         /* NHWC [B][sH][sW][C0] */
+  const void* src1;         /* NHWC [B][sH][sW][C1] or NULL */
+  const float* chan_scale;  /* [B][C0+C1] fp32 or NULL */
+  const void* wp;           /* prepared weights (ddx_mpconv_wprep with the same CK) */
+  const void* residual;     /* NHWC [B][H][W][Cout] or NULL */
+  void* out;                /* NHWC [B][H][W][Cout] */
+  int32_t B, H, W;          /* OUTPUT spatial size */
+  int32_t C0, C1, Cout, groups, ksize;
+  int32_t CK;               /* must equal the wprep CK */
+  int32_t resample, prologue, epilogue;
+  float scale0, scale1;     /* mp_cat weights (1,1 when unused) */
+  float res_t;              /* t of mp_sum(residual, y, t) */
+  float clip;               /* <= 0: none */
+  int32_t dtype;            /* activations and wp */
+  int32_t force_direct;     /* 1 = use the scalar reference kernel (testing / odd channel counts) */
+} ddx_conv_desc;
+
+int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
+/* CK the library wants for a conv of this shape (call before wprep). */
+int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype);
+
+/* ------------------------------------------------------------------------------------------------
+ * RMS ("pixel") normalisation over the channel axis of NHWC rows  (mp_tools.py:42-49 with dim=1,
+ * unet_edm2_b4.py:117): y = x / (eps + ||x||_2 / sqrt(C)).  rows = B*H*W.  In place allowed.
+ * ------------------------------------------------------------------------------------------------ */
+int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention over all H*W tokens  (unet_edm2_b4.py:137-148): q,k,v RMS-normalised over the head
+ * dim per token (normalize(dim=2)), softmax(q.k / sqrt(d)) v.
+ *   qk: NHWC [B][T][2C] with channels ordered (head, {q,k}, d)   <- wprep with qk_head_dim = d
+ *   v : NHWC [B][T][C]  with channels ordered (head, d)
+ *   out: NHWC [B][T][C]
+ * ------------------------------------------------------------------------------------------------ */
+int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
+                 float eps, int32_t dtype, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small-M linear layers on raw master weights (no wprep): out[b][o] = post( sum_k x[b][k] * w'[o][k] )
+ *   w' = [normalize(w[o])] * gain_eff / sqrt(K)     (mp_tools.py:359-367)
+ *   grouped: row o only sees x[b][ (o / (O/groups)) * K .. +K )          (emb_linear, groups = mlp_groups)
+ *   post: out = acc + add_const                                         (the "+ 1." of unet_edm2_b4.py:121)
+ * A batch of jobs runs in one launch (all per-block emb_linear* of a UNet forward).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* w;          /* [O][K] master weights */
+  const float* gain_ptr;  /* may be NULL */
+  float* out;             /* [M][O] fp32 */
+  float gain, add_const;
+  int32_t O, K, groups, normalize;
+} ddx_linear_job;
+
+int ddx_linear_small_batched(const ddx_linear_job* jobs_dev, int32_t njobs, int32_t max_O, const float* x, int32_t x_stride,
+                             int32_t M, int32_t w_dtype, ddx_stream stream);
+
+/* MPFourier (mp_tools.py:316-330): out[b][c] = cos(x[b]*freqs[c] + phases[c]) * sqrt(2); x = log(sigma)/4 when
+ * log_sigma_quarter != 0 (unet_edm2_b4.py:262, :238). */
+int ddx_mpfourier(const float* x, const float* freqs, const float* phases, float* out, int32_t M, int32_t C,
+                  int32_t log_sigma_quarter, ddx_stream stream);
+
+/* emb = mp_silu(mp_sum(a, b, t)) (unet_edm2_b4.py:272-274) on [M][C] fp32;  with silu=0: plain mp_sum with a
+ * per-row t (get_embeddings, unet_edm2_b4.py:232-235: a row-broadcast when a_rows == 1). */
+int ddx_mpsum_rows(const float* a, int32_t a_rows, const float* b, const float* t_rows, float t, float* out, int32_t M,
+                   int32_t C, int32_t silu, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * UNet input / output glue  (unet_edm2_b4.py:257-269,277 and :290-296)
+ *   prep : x = c_in(sigma) * x_in ; channels [x(4), 1, ln_freq[h], 0...] -> NHWC [B][H][W][Cpad]
+ *   final: D_x = c_skip*x_in + c_out*y ; optional inpainting mix with x_ref (mp_sum with t = x_ref[:, -1:])
+ * x_in, x_ref, out are NCHW fp32 (the module's public I/O); y is NHWC `dtype`.
+ * ------------------------------------------------------------------------------------------------ */
+int ddx_unet_input_prep(const float* x_nchw, const float* sigma, const float* ln_freq_h, void* out_nhwc, int32_t B,
+                        int32_t C, int32_t H, int32_t W, int32_t Cpad, float sigma_data, int32_t dtype, ddx_stream stream);
+int ddx_unet_output_combine(const void* y_nhwc, const float* x_in_nchw, const float* sigma, const float* x_ref_nchw,
+                            float* out_nchw, int32_t B, int32_t C, int32_t H, int32_t W, float sigma_data, int32_t dtype,
+                            ddx_stream stream);
+
+/* Layout conversion helpers NCHW fp32 <-> NHWC dtype (module boundary). */
+int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
+int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch plans: a recorded sequence of the calls above, replayed with one FFI call and optionally
+ * as a hipGraph (the MI355X replacement for the reference's torch.compile, modules/module.py:145-149).
+ * Recording: between ddx_plan_begin() and ddx_plan_end() every entry point above is recorded into
+ * the plan instead of being launched (thread-local).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ddx_plan ddx_plan;
+ddx_plan* ddx_plan_begin(void);
+int ddx_plan_end(ddx_plan* p);
+int ddx_plan_num_ops(const ddx_plan* p);
+int ddx_plan_run(ddx_plan* p, ddx_stream stream);            /* eager replay */
+int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream);    /* capture into a hipGraphExec */
+int ddx_plan_graph_launch(ddx_plan* p, ddx_stream stream);
+void ddx_plan_destroy(ddx_plan* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDX_HIP_H */

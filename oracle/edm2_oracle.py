@@ -1,0 +1,369 @@
+"""CPU oracle for the EDM2-UNet denoising path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU (torch fp32, no nn.Module, state-dict driven) restatement of the reference's
+algorithm for the hot path.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg
+of `bench.py` may import it; the product path (`dualdiffusion_amd/`) never does and fails loudly
+when its HIP library is missing.
+
+Parity status: PINNED.  `tools/make_golden.py` (build container only) imports the reference from
+/root/reference, runs it on seeded inputs, checks this oracle against it and commits the vectors
+under `tests/golden/`; `tests/test_oracle_golden.py` re-checks the oracle against those vectors
+everywhere.  The reference's own tests hold no golden vectors for this path.
+
+Every function cites the reference lines (under /root/reference/src) whose arithmetic it restates.
+Tensors are NCHW fp32 on the CPU; `sd` is a flat {state_dict key: tensor} mapping using the
+reference's key names.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+EPS_NORM = 1e-4
+
+
+# ----------------------------------------------------------------------------- op library (a-1 .. a-5)
+
+def rms_normalize(x: torch.Tensor, dims: Optional[Sequence[int]] = None, eps: float = EPS_NORM) -> torch.Tensor:
+    """modules/mp_tools.py:42-49.  x / (eps + ||x||_2 * sqrt(n_norm / n_x)), fp32 internally."""
+    if dims is None:
+        dims = list(range(1, x.ndim))
+    xf = x.to(torch.float32)
+    nrm = torch.sqrt((xf * xf).sum(dim=list(dims), keepdim=True))
+    nrm = eps + nrm * math.sqrt(nrm.numel() / x.numel())
+    return (xf / nrm).to(x.dtype)
+
+
+def silu_mp(x: torch.Tensor) -> torch.Tensor:
+    """modules/mp_tools.py:268-269."""
+    return x * torch.sigmoid(x) / 0.596
+
+
+def sum_mp(a: torch.Tensor, b: torch.Tensor, t) -> torch.Tensor:
+    """modules/mp_tools.py:274-279.  lerp(a, b, t) / sqrt((1-t)^2 + t^2); t float or tensor."""
+    if isinstance(t, torch.Tensor):
+        return (a + (b - a) * t) / torch.sqrt((1 - t) ** 2 + t ** 2).to(a.dtype)
+    return (a + (b - a) * t) / math.sqrt((1 - t) ** 2 + t ** 2)
+
+
+def cat_mp_weights(na: int, nb: int, t: float) -> tuple[float, float]:
+    """modules/mp_tools.py:294-301 (the two scalars)."""
+    c = math.sqrt((na + nb) / ((1 - t) ** 2 + t ** 2))
+    return c / math.sqrt(na) * (1 - t), c / math.sqrt(nb) * t
+
+
+def cat_mp(a: torch.Tensor, b: torch.Tensor, t: float = 0.5) -> torch.Tensor:
+    wa, wb = cat_mp_weights(a.shape[1], b.shape[1], t)
+    return torch.cat([wa * a, wb * b], dim=1)
+
+
+def resample2x(x: torch.Tensor, mode: str) -> torch.Tensor:
+    """modules/mp_tools.py:71-79.  'down' = 2x2 mean (not rescaled), 'up' = nearest x2."""
+    if mode == "keep":
+        return x
+    if mode == "down":
+        b, c, h, w = x.shape
+        return x.reshape(b, c, h // 2, 2, w // 2, 2).mean(dim=(3, 5))
+    if mode == "up":
+        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    raise ValueError(mode)
+
+
+def fourier_tables(num_channels: int, bandwidth: float = 1.0, eps: float = 1e-3) -> tuple[torch.Tensor, torch.Tensor]:
+    """modules/mp_tools.py:318-322: freqs = pi*erfinv(linspace(0,1-eps,C))*bw ; phases = pi/2 on even idx."""
+    freqs = torch.pi * torch.linspace(0, 1 - eps, num_channels).erfinv() * bandwidth
+    phases = torch.pi / 2 * (torch.arange(num_channels) % 2 == 0).float()
+    return freqs, phases
+
+
+def fourier_mp(x: torch.Tensor, freqs: torch.Tensor, phases: torch.Tensor) -> torch.Tensor:
+    """modules/mp_tools.py:324-330 (1-D input form)."""
+    y = x.float()[:, None] * freqs.float()[None, :] + phases.float()[None, :]
+    return torch.cos(y) * math.sqrt(2.0)
+
+
+def prepared_weight(w: torch.Tensor, gain=1.0, training: bool = False, weight_norm: bool = True) -> torch.Tensor:
+    """modules/mp_tools.py:359-364: optional forced weight-norm, then gain / sqrt(fan_in)."""
+    w = w.float()
+    if training and weight_norm:
+        w = rms_normalize(w)
+    return w * (gain / math.sqrt(w[0].numel()))
+
+
+def conv_mp(x: torch.Tensor, w: torch.Tensor, gain=1.0, groups: int = 1, training: bool = False,
+            weight_norm: bool = True) -> torch.Tensor:
+    """modules/mp_tools.py:357-373 (no bias on this path).  2-D weight -> x @ w.T, else same-pad conv."""
+    wp = prepared_weight(w, gain, training, weight_norm).to(x.dtype)
+    if wp.ndim == 2:
+        return x @ wp.t()
+    return F.conv2d(x, wp, padding=(wp.shape[-2] // 2, wp.shape[-1] // 2), groups=groups)
+
+
+# ----------------------------------------------------------------------------- attention (inside a-6)
+
+def attention_2d(qk: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+    """modules/unets/unet_edm2_b4.py:137-148.  qk: (B, 2C, H, W) with channel = (head, d, {q,k});
+    v: (B, C, H, W) with channel = (head, d).  Per-token RMS-normalised q, k, v over d, softmax(q.k/sqrt(d))."""
+    b, c2, h, w = qk.shape
+    c = c2 // 2
+    d = c // heads
+    qk5 = rms_normalize(qk.reshape(b, heads, d, 2, h * w), dims=[2])
+    q, k = qk5[:, :, :, 0], qk5[:, :, :, 1]                       # (B, heads, d, T)
+    v4 = rms_normalize(v.reshape(b, heads, d, h * w), dims=[2])
+    s = torch.einsum("bhdq,bhdk->bhqk", q, k) / math.sqrt(d)
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhqk,bhdk->bhdq", p, v4)
+    return o.reshape(b, c, h, w)
+
+
+# ----------------------------------------------------------------------------- Block (a-6)
+
+def block_forward(sd: dict, prefix: str, x: torch.Tensor, emb: torch.Tensor, *, flavor: str, resample: str,
+                  attention: bool, heads: int, groups: int, res_balance: float = 0.3, attn_balance: float = 0.3,
+                  clip: Optional[float] = 256.0, training: bool = False) -> torch.Tensor:
+    """modules/unets/unet_edm2_b4.py:110-158 (dropout = 0 on this path)."""
+    def W(name):
+        return sd[f"{prefix}.{name}.weight"]
+
+    x = resample2x(x, resample)
+    if flavor == "enc":
+        x = conv_mp(x, W("conv_skip"), training=training)
+        x = rms_normalize(x, dims=[1])
+    y = conv_mp(silu_mp(x), W("conv_res0"), groups=groups, training=training)
+    c = conv_mp(emb, W("emb_linear"), gain=sd[f"{prefix}.emb_gain"], groups=groups, training=training) + 1.0
+    y = silu_mp(y * c)
+    y = conv_mp(y, W("conv_res1"), groups=groups, training=training)
+    if flavor == "dec":
+        x = conv_mp(x, W("conv_skip"), training=training)
+    x = sum_mp(x, y, res_balance)
+    if attention:
+        c = conv_mp(emb, W("emb_linear_qk"), gain=sd[f"{prefix}.emb_gain_qk"], training=training) + 1.0
+        qk = conv_mp(x * c, W("attn_qk"), training=training)
+        v = conv_mp(x, W("attn_v"), training=training)
+        y = attention_2d(qk, v, heads)
+        c = conv_mp(emb, W("emb_linear_v"), gain=sd[f"{prefix}.emb_gain_v"], training=training) + 1.0
+        y = silu_mp(y * c)
+        y = conv_mp(y, W("attn_proj"), training=training)
+        x = sum_mp(x, y, attn_balance)
+    if clip is not None:
+        x = x.clamp(-clip, clip)
+    return x
+
+
+# ----------------------------------------------------------------------------- UNet (a-7 .. a-9)
+
+DEFAULT_UNET_CFG = dict(
+    in_channels=4, out_channels=4, in_channels_emb=512, dropout=0.0, sigma_max=200.0, sigma_min=0.03,
+    sigma_data=1.0, model_channels=256, logvar_channels=128, channel_mult=(1, 2, 3, 4, 5),
+    channel_mult_noise=None, channel_mult_emb=None, channels_per_head=64, num_layers_per_block=2,
+    label_balance=0.5, concat_balance=0.5, res_balance=0.3, attn_balance=0.3, attn_levels=(3, 4),
+    mlp_multiplier=2, mlp_groups=8)
+
+
+def unet_cfg(**overrides) -> dict:
+    cfg = dict(DEFAULT_UNET_CFG)
+    cfg.update(overrides)
+    return cfg
+
+
+def unet_topology(cfg: dict) -> dict:
+    """modules/unets/unet_edm2_b4.py:172-230: the ordered list of encoder / decoder stages.
+
+    Returns {"cblock","cnoise","cemb","enc":[...],"dec":[...]} where each stage is a dict with
+    name, kind ('conv_in' | 'block'), cin, cout, level, flavor, resample, attention, skip_in (dec only).
+    """
+    mc = cfg["model_channels"]
+    cblock = [mc * m for m in cfg["channel_mult"]]
+    cnoise = mc * cfg["channel_mult_noise"] if cfg["channel_mult_noise"] is not None else max(cblock)
+    cemb = mc * cfg["channel_mult_emb"] if cfg["channel_mult_emb"] is not None else max(cblock)
+    attn_levels = set(cfg["attn_levels"])
+    enc, dec = [], []
+    cout = cfg["in_channels"] + 2
+    for level, ch in enumerate(cblock):
+        if level == 0:
+            enc.append(dict(name="conv_in", kind="conv_in", cin=cout, cout=ch, level=0))
+            cout = ch
+        else:
+            enc.append(dict(name=f"block{level}_down", kind="block", cin=cout, cout=cout, level=level, flavor="enc",
+                            resample="down", attention=level in attn_levels))
+        for i in range(cfg["num_layers_per_block"]):
+            enc.append(dict(name=f"block{level}_layer{i}", kind="block", cin=cout, cout=ch, level=level,
+                            flavor="enc", resample="keep", attention=level in attn_levels))
+            cout = ch
+    skips = [s["cout"] for s in enc]
+    top = len(cblock) - 1
+    for level in range(top, -1, -1):
+        ch = cblock[level]
+        if level == top:
+            for nm in ("in0", "in1"):
+                dec.append(dict(name=f"block{level}_{nm}", kind="block", cin=cout, cout=cout, level=level,
+                                flavor="dec", resample="keep", attention=True, skip_in=0))
+        else:
+            dec.append(dict(name=f"block{level}_up", kind="block", cin=cout, cout=cout, level=level, flavor="dec",
+                            resample="up", attention=level in attn_levels, skip_in=0))
+        for i in range(cfg["num_layers_per_block"] + 1):
+            sk = skips.pop()
+            dec.append(dict(name=f"block{level}_layer{i}", kind="block", cin=cout + sk, cout=ch, level=level,
+                            flavor="dec", resample="keep", attention=level in attn_levels, skip_in=sk))
+            cout = ch
+    return dict(cblock=cblock, cnoise=cnoise, cemb=cemb, enc=enc, dec=dec, cout_last=cout)
+
+
+def unet_param_shapes(cfg: dict) -> dict:
+    """State-dict key -> shape for the reference UNet (unet_edm2_b4.py:180-230; checked in make_golden)."""
+    topo = unet_topology(cfg)
+    g, mm = cfg["mlp_groups"], cfg["mlp_multiplier"]
+    cemb = topo["cemb"]
+    shapes = {
+        "out_gain": (),
+        "emb_fourier.freqs": (topo["cnoise"],), "emb_fourier.phases": (topo["cnoise"],),
+        "emb_noise.weight": (cemb, topo["cnoise"]),
+        "emb_label.weight": (cemb, cfg["in_channels_emb"]),
+        "emb_label_unconditional.weight": (cemb, 1),
+        "logvar_fourier.freqs": (cfg["logvar_channels"],), "logvar_fourier.phases": (cfg["logvar_channels"],),
+        "logvar_linear.weight": (1, cfg["logvar_channels"]),
+    }
+    for side in ("enc", "dec"):
+        for st in topo[side]:
+            p = f"{side}.{st['name']}"
+            if st["kind"] == "conv_in":
+                shapes[f"{p}.weight"] = (st["cout"], st["cin"], 3, 3)
+                continue
+            cin, cout = st["cin"], st["cout"]
+            res0_in = cout if st["flavor"] == "enc" else cin
+            shapes[f"{p}.emb_gain"] = ()
+            if st["attention"]:
+                shapes[f"{p}.emb_gain_qk"] = ()
+                shapes[f"{p}.emb_gain_v"] = ()
+            shapes[f"{p}.conv_res0.weight"] = (cout * mm, res0_in // g, 3, 3)
+            shapes[f"{p}.conv_res1.weight"] = (cout, cout * mm // g, 3, 3)
+            shapes[f"{p}.conv_skip.weight"] = (cout, cin, 1, 1)
+            shapes[f"{p}.emb_linear.weight"] = (cout * mm, cemb // g, 1, 1)
+            if st["attention"]:
+                shapes[f"{p}.emb_linear_qk.weight"] = (cout, cemb, 1, 1)
+                shapes[f"{p}.emb_linear_v.weight"] = (cout, cemb, 1, 1)
+                shapes[f"{p}.attn_qk.weight"] = (cout * 2, cout, 1, 1)
+                shapes[f"{p}.attn_v.weight"] = (cout, cout, 1, 1)
+                shapes[f"{p}.attn_proj.weight"] = (cout, cout, 1, 1)
+    shapes["conv_out.weight"] = (cfg["out_channels"], topo["cout_last"], 3, 3)
+    return shapes
+
+
+def random_unet_state(cfg: dict, seed: int, gain_value: float = 0.7, normalized: bool = True) -> dict:
+    """Deterministic synthetic weights: randn per key (sorted order, one generator), forced weight-norm
+    (mp_tools.py:375-378) and every 0-d gain set to `gain_value` (SURVEY.md section 0.5a parity trap)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape in sorted(unet_param_shapes(cfg).items()):
+        if key.endswith(".freqs") or key.endswith(".phases"):
+            continue
+        if shape == ():
+            sd[key] = torch.tensor(gain_value)
+        else:
+            w = torch.randn(shape, generator=g)
+            if normalized and key != "logvar_linear.weight":
+                w = rms_normalize(w)
+            sd[key] = w
+    topo = unet_topology(cfg)
+    sd["emb_fourier.freqs"], sd["emb_fourier.phases"] = fourier_tables(topo["cnoise"])
+    sd["logvar_fourier.freqs"], sd["logvar_fourier.phases"] = fourier_tables(cfg["logvar_channels"])
+    return sd
+
+
+def hz_to_mel(f: float) -> float:
+    """modules/formats/frequency_scale.py:30-31 (numpy float64 in the reference)."""
+    return 2595.0 * math.log10(1.0 + f / 700.0)
+
+
+def mel_points_hz(n: int, fmin: float, fmax: float) -> torch.Tensor:
+    """frequency_scale.py:144-149 with scale 'mel': f32 linspace between f64 endpoints, then mel->Hz in f32."""
+    mels = torch.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n)
+    return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+
+
+def ln_freq_channel(h: int, w: int, batch: int, fmin: float, fmax: float) -> torch.Tensor:
+    """unet_edm2_b4.py:244-248 == formats/old/spectrogram.py:240-244: standardised log2 mel-Hz per row."""
+    lf = mel_points_hz(h + 2, fmin, fmax)[1:-1].log2()
+    lf = lf.view(1, 1, -1, 1).repeat(batch, 1, 1, w)
+    return (lf - lf.mean()) / lf.std()
+
+
+def unet_embeddings(sd: dict, cfg: dict, emb_in: torch.Tensor, cond_mask: torch.Tensor, training: bool = False) -> torch.Tensor:
+    """unet_edm2_b4.py:232-235."""
+    u = conv_mp(torch.ones(1), sd["emb_label_unconditional.weight"], training=training)
+    c = conv_mp(rms_normalize(emb_in.float()), sd["emb_label.weight"], training=training)
+    return sum_mp(u, c, cond_mask.float().unsqueeze(1))
+
+
+def unet_sigma_logvar(sd: dict, cfg: dict, sigma: torch.Tensor) -> torch.Tensor:
+    """unet_edm2_b4.py:237-238 (logvar_linear has weight-norm disabled, unet_edm2_b4.py:187)."""
+    f = fourier_mp(sigma.flatten().log() / 4, sd["logvar_fourier.freqs"], sd["logvar_fourier.phases"])
+    return conv_mp(f, sd["logvar_linear.weight"], weight_norm=False).view(-1, 1, 1, 1).float()
+
+
+def unet_forward(sd: dict, cfg: dict, x_in: torch.Tensor, sigma: torch.Tensor, embeddings: torch.Tensor,
+                 freq_range: tuple[float, float] = (20.0, 16000.0), x_ref: Optional[torch.Tensor] = None,
+                 perturbed_input: Optional[torch.Tensor] = None, training: bool = False,
+                 collect: Optional[dict] = None) -> torch.Tensor:
+    """unet_edm2_b4.py:250-296.  `freq_range` = (freq_min, freq_max) of format.ms_freq_scale (mel scale).
+    `collect`, if given, receives every stage output by name (for layer-level parity tests)."""
+    topo = unet_topology(cfg)
+    sdata = cfg["sigma_data"]
+    sig = sigma.float().view(-1, 1, 1, 1)
+    c_skip = sdata ** 2 / (sig ** 2 + sdata ** 2)
+    c_out = sig * sdata / torch.sqrt(sig ** 2 + sdata ** 2)
+    c_in = 1 / torch.sqrt(sdata ** 2 + sig ** 2)
+    c_noise = sig.flatten().log() / 4
+    x = c_in * (perturbed_input if perturbed_input is not None else x_in).float()
+
+    emb = conv_mp(fourier_mp(c_noise, sd["emb_fourier.freqs"], sd["emb_fourier.phases"]), sd["emb_noise.weight"],
+                  training=training)
+    emb = sum_mp(emb, embeddings.float(), cfg["label_balance"])
+    emb = silu_mp(emb)[:, :, None, None]
+    if collect is not None:
+        collect["emb"] = emb
+
+    b, _, h, w = x.shape
+    x = torch.cat([x, torch.ones_like(x[:, :1]), ln_freq_channel(h, w, b, *freq_range)], dim=1)
+    heads_of = lambda cout: cout // cfg["channels_per_head"]
+    kw = dict(groups=cfg["mlp_groups"], res_balance=cfg["res_balance"], attn_balance=cfg["attn_balance"],
+              training=training)
+    skips = []
+    for st in topo["enc"]:
+        if st["kind"] == "conv_in":
+            x = conv_mp(x, sd["enc.conv_in.weight"], training=training)
+        else:
+            x = block_forward(sd, f"enc.{st['name']}", x, emb, flavor="enc", resample=st["resample"],
+                              attention=st["attention"], heads=heads_of(st["cout"]), **kw)
+        skips.append(x)
+        if collect is not None:
+            collect[f"enc.{st['name']}"] = x
+    for st in topo["dec"]:
+        if st["skip_in"]:
+            x = cat_mp(x, skips.pop(), cfg["concat_balance"])
+        x = block_forward(sd, f"dec.{st['name']}", x, emb, flavor="dec", resample=st["resample"],
+                          attention=st["attention"], heads=heads_of(st["cout"]), **kw)
+        if collect is not None:
+            collect[f"dec.{st['name']}"] = x
+    x = conv_mp(x, sd["conv_out.weight"], gain=sd["out_gain"], training=training)
+    d_x = c_skip * x_in.float() + c_out * x.float()
+    if x_ref is not None:
+        d_x = sum_mp(x_ref[:, :-1].float(), d_x, x_ref[:, -1:].float())
+    return d_x
+
+
+def unet_latent_shape(cfg: dict, shape: Sequence[int]) -> tuple:
+    """unet_edm2_b4.py:240-242."""
+    q = 2 ** (len(cfg["channel_mult"]) - 1)
+    return tuple(shape[0:2]) + ((shape[2] // q) * q, (shape[3] // q) * q)
+
+
+# ----------------------------------------------------------------------------- schedule (a-16)
+
+def schedule_edm2(steps: int, sigma_max: float, sigma_min: float, rho: float = 7.0) -> torch.Tensor:
+    """sampling/schedule.py:34-37,57-59."""
+    t = torch.linspace(1, 0, steps + 1)
+    return (sigma_max ** (1 / rho) + (1 - t) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho

@@ -1,0 +1,248 @@
+"""GPU parity of the individual HIP ops (through the C ABI) against the CPU oracle.
+
+Tolerances: float32 kernels use exact-fp32 MFMA / fp32 VALU, so they must match the fp32 oracle to 2e-5 rel-L2.
+bfloat16 kernels keep fp32 accumulation; they are compared with the oracle run on the same bf16-rounded inputs
+and weights, which leaves only operand re-rounding after the fused prologue and the bf16 output rounding: 8e-3.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import edm2_oracle as O
+from tests.util import load_golden, rel_l2, to_nchw, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 8e-3}
+
+
+def _ops():
+    from dualdiffusion_amd import ops
+    return ops
+
+
+def _round(x, dt):
+    return x.to(dt).float()
+
+
+CONV_CASES = {
+    # name: (B, H, W, C0, C1, Cout, groups, ksize, resample, prologue, residual, clip)
+    "res0_L0": (2, 16, 24, 256, 0, 512, 8, 3, "keep", "silu", False, 0.0),
+    "res1_L0_fused": (2, 16, 24, 512, 0, 256, 8, 3, "keep", "scale_silu", True, 256.0),
+    "res0_cat": (2, 8, 12, 256, 512, 512, 8, 3, "keep", "silu", False, 0.0),
+    "res0_up": (1, 8, 12, 512, 0, 1024, 8, 3, "up", "silu", False, 0.0),
+    "skip_down": (2, 8, 12, 256, 0, 256, 1, 1, "down", "none", False, 0.0),
+    "skip_cat": (1, 8, 12, 512, 256, 256, 1, 1, "keep", "none", False, 0.0),
+    "proj_fused": (2, 4, 11, 256, 0, 256, 1, 1, "keep", "scale_silu", True, 2.0),
+    "qk_scale": (2, 4, 11, 128, 0, 256, 1, 1, "keep", "scale", False, 0.0),
+    "odd_size": (3, 5, 43, 64, 0, 96, 8, 3, "keep", "silu", False, 0.0),
+    "conv_out": (2, 8, 20, 256, 0, 4, 1, 3, "keep", "none", False, 0.0),
+    "wide_n": (1, 6, 10, 768, 0, 1536, 8, 3, "keep", "none", False, 0.0),
+    "tiny_m": (1, 2, 3, 1280, 0, 1280, 8, 3, "keep", "silu", True, 256.0),
+}
+
+
+def _conv_case(name, dtype, force_direct=False, training=False):
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    B, H, W, C0, C1, Cout, groups, ks, resample, prologue, has_res, clip = CONV_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    sh, sw = {"keep": (H, W), "up": (H // 2, W // 2), "down": (H * 2, W * 2)}[resample]
+    a = _round(torch.randn(B, C0, sh, sw, generator=g) * 1.3, dtype)
+    b = _round(torch.randn(B, C1, sh, sw, generator=g), dtype) if C1 else None
+    Cin = C0 + C1
+    w = torch.randn(Cout, Cin // groups, ks, ks, generator=g) * 0.9
+    gain = torch.tensor(0.8)
+    cs = torch.randn(B, Cin, generator=g) * 0.3 + 1.0
+    res = _round(torch.randn(B, Cout, H, W, generator=g), dtype) if has_res else None
+    s0, s1 = O.cat_mp_weights(C0, C1, 0.5) if C1 else (1.0, 1.0)
+
+    # ---- oracle (NCHW fp32)
+    x = torch.cat([s0 * a, s1 * b], dim=1) if C1 else a
+    x = O.resample2x(x, resample)
+    if "scale" in prologue:
+        x = x * cs[:, :, None, None]
+    if "silu" in prologue:
+        x = O.silu_mp(x)
+    wp_ref = O.prepared_weight(w, gain, training=training)
+    if dtype == torch.bfloat16:
+        x, wp_ref = _round(x, dtype), _round(wp_ref, dtype)
+    y = torch.nn.functional.conv2d(x, wp_ref, padding=ks // 2, groups=groups)
+    if has_res:
+        y = O.sum_mp(res, y, 0.3)
+    if clip > 0:
+        y = y.clamp(-clip, clip)
+
+    # ---- HIP
+    pw = ops.wprep(w.cuda(), groups, dtype, gain_ptr=gain.cuda().reshape(1), normalize=training)
+    pro = {"none": L.PRO_NONE, "silu": L.PRO_SILU, "scale": L.PRO_SCALE, "scale_silu": L.PRO_SCALE_SILU}[prologue]
+    rs = {"keep": L.RESAMPLE_KEEP, "up": L.RESAMPLE_UP, "down": L.RESAMPLE_DOWN}[resample]
+    out = ops.conv2d(to_nhwc(a, dtype), pw, out_hw=(H, W), src1=to_nhwc(b, dtype) if C1 else None, scale0=s0, scale1=s1, resample=rs,
+                     prologue=pro, chan_scale=cs.cuda() if "scale" in prologue else None,
+                     residual=to_nhwc(res, dtype) if has_res else None, res_t=0.3, clip=clip, force_direct=force_direct)
+    torch.cuda.synchronize()
+    return rel_l2(to_nchw(out), y)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_mfma(name, dtype):
+    e = _conv_case(name, dtype)
+    print(f"conv {name} {dtype}: rel-L2 {e:.3e}")
+    assert e < TOL[dtype], (name, e)
+
+
+@pytest.mark.parametrize("name", ["res1_L0_fused", "res0_cat", "skip_down", "res0_up", "odd_size"])
+def test_conv_direct(name):
+    e = _conv_case(name, torch.float32, force_direct=True)
+    assert e < TOL[torch.float32], (name, e)
+
+
+def test_conv_training_weight_norm():
+    for dt in (torch.float32, torch.bfloat16):
+        e = _conv_case("res1_L0_fused", dt, training=True)
+        assert e < TOL[dt], e
+
+
+def test_mpconv_golden_ops():
+    """MPConv fixtures produced by the reference itself (tests/golden/ops.safetensors), via wprep + conv kernels."""
+    ops = _ops()
+    t, m = load_golden("ops")
+    for nm in ("c3g", "c1", "c3"):
+        g = m[f"mpconv.{nm}.groups"]
+        w, x, gain = t[f"mpconv.{nm}.w"], t[f"mpconv.{nm}.x"], t[f"mpconv.{nm}.gain"]
+        for mode in ("eval", "train"):
+            for use_gain in (False, True):
+                pw = ops.wprep(w.cuda(), g, torch.float32, gain_ptr=gain.cuda().reshape(1) if use_gain else None, normalize=mode == "train")
+                y = ops.conv2d(to_nhwc(x), pw)
+                ref = t[f"mpconv.{nm}.{mode}.out_gain" if use_gain else f"mpconv.{nm}.{mode}.out"]
+                assert rel_l2(to_nchw(y), ref) < 2e-5, (nm, mode, use_gain)
+
+
+def test_qk_row_permutation():
+    """wprep(qk_head_dim=d) must emit channels ordered (head, {q,k}, d) from the reference's (head, d, {q,k})."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    C, heads, d = 128, 2, 64
+    w = torch.randn(2 * C, C, 1, 1, generator=g)
+    x = torch.randn(1, C, 3, 5, generator=g)
+    ref = O.conv_mp(x, w)                                     # (1, 2C, 3, 5) channel = (head, d, s)
+    ref = ref.reshape(1, heads, d, 2, 3, 5).permute(0, 1, 3, 2, 4, 5).reshape(1, 2 * C, 3, 5)
+    pw = ops.wprep(w.cuda(), 1, torch.float32, qk_head_dim=d)
+    y = ops.conv2d(to_nhwc(x), pw)
+    assert rel_l2(to_nchw(y), ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C", [256, 1280, 2560, 24])
+def test_pixelnorm(C, dtype):
+    ops = _ops()
+    x = _round(torch.randn(3, C, 5, 7, generator=torch.Generator().manual_seed(C)) * 2, dtype)
+    ref = O.rms_normalize(x, [1])
+    y = ops.pixelnorm(to_nhwc(x, dtype))
+    assert rel_l2(to_nchw(y), ref) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 4, 86, 2, 64), (1, 2, 43, 3, 64), (2, 3, 50, 2, 32), (1, 16, 25, 1, 64), (1, 1, 7, 1, 128)])
+def test_attention(shape, dtype):
+    """shape = (B, H, W, heads, d); T = H*W covers <1 chunk, exactly 128-multiples and ragged tails (344, 86, 150, 400, 7)."""
+    ops = _ops()
+    B, H, W, heads, d = shape
+    if d == 128 and dtype == torch.float32:
+        pytest.skip("head_dim 128 in fp32 exceeds LDS (unsupported by design)")
+    C = heads * d
+    g = torch.Generator().manual_seed(B * 1000 + H * W)
+    qk = _round(torch.randn(B, 2 * C, H, W, generator=g) * 2.0, dtype)        # reference order (head, d, s)
+    v = _round(torch.randn(B, C, H, W, generator=g), dtype)
+    ref = O.attention_2d(qk, v, heads)
+    qk_perm = qk.reshape(B, heads, d, 2, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * C, H, W)
+    y = ops.attention(to_nhwc(qk_perm, dtype), to_nhwc(v, dtype), heads)
+    e = rel_l2(to_nchw(y), ref)
+    print(f"attention {shape} {dtype}: {e:.3e}")
+    assert e < (2e-5 if dtype == torch.float32 else 1e-2), e
+
+
+def test_attention_spike_rescale():
+    """Online-softmax rescale branch: one key dominates in a LATER chunk, forcing a large running-max jump."""
+    ops = _ops()
+    B, H, W, heads, d = 1, 3, 100, 1, 64       # T = 300 -> 3 chunks
+    g = torch.Generator().manual_seed(9)
+    qk = torch.randn(B, 2 * d, H, W, generator=g)
+    v = torch.randn(B, d, H, W, generator=g)
+    q5 = qk.reshape(B, 1, d, 2, H * W)
+    q5[0, 0, :, 1, 290] = q5[0, 0, :, 0, 17] * 40.0   # key 290 aligned with query 17 (normalised anyway -> cos = 1)
+    ref = O.attention_2d(qk, v, heads)
+    qk_perm = qk.reshape(B, heads, d, 2, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * d, H, W)
+    y = ops.attention(to_nhwc(qk_perm), to_nhwc(v), heads)
+    assert rel_l2(to_nchw(y), ref) < 2e-5
+
+
+def test_small_linear_and_fourier():
+    ops = _ops()
+    t, _ = load_golden("ops")
+    dev = "cuda"
+    for ch in (32, 128, 256):
+        x = t[f"mpfourier{ch}.in"].cuda()
+        out = torch.empty(x.numel(), ch, device=dev)
+        ops.mpfourier(x, t[f"mpfourier{ch}.freqs"].cuda(), t[f"mpfourier{ch}.phases"].cuda(), out, False)
+        assert rel_l2(out, t[f"mpfourier{ch}.out"]) < 2e-6
+    w, x, gain = t["mpconv.lin.w"], t["mpconv.lin.x"], t["mpconv.lin.gain"]
+    for mode in ("eval", "train"):
+        out = torch.empty(x.shape[0], w.shape[0], device=dev)
+        tab = ops.make_linear_jobs([(w.cuda(), gain.cuda().reshape(1), out, 1.0, 0.0, 1, mode == "train")], dev)
+        ops.linear_small(tab, 1, w.shape[0], x.cuda(), x.shape[0], torch.float32)
+        assert rel_l2(out, t[f"mpconv.lin.{mode}.out_gain"]) < 2e-6, mode
+    # grouped (emb_linear: groups = 8) with the "+1"
+    g = torch.Generator().manual_seed(3)
+    wg = torch.randn(64, 12, 1, 1, generator=g)
+    e = torch.randn(5, 96, generator=g)
+    ref = O.conv_mp(e[:, :, None, None], wg, gain=0.7, groups=8)[:, :, 0, 0] + 1.0
+    out = torch.empty(5, 64, device=dev)
+    tab = ops.make_linear_jobs([(wg.cuda(), None, out, 0.7, 1.0, 8, False)], dev)
+    ops.linear_small(tab, 1, 64, e.cuda(), 5, torch.float32)
+    assert rel_l2(out, ref) < 2e-6
+    # mp_sum rows (+silu)
+    a, b = torch.randn(5, 96, generator=g), torch.randn(5, 96, generator=g)
+    out = torch.empty(5, 96, device=dev)
+    ops.mpsum_rows(a.cuda(), b.cuda(), out, t=0.5, silu=True)
+    assert rel_l2(out, O.silu_mp(O.sum_mp(a, b, 0.5))) < 2e-6
+    tr = torch.tensor([0., 1., 0., 1., 1.])
+    ops.mpsum_rows(a[:1].cuda().contiguous(), b.cuda(), out, t_rows=tr.cuda())
+    assert rel_l2(out, O.sum_mp(a[:1], b, tr[:, None])) < 2e-6
+
+
+def test_normalize_weights_inplace():
+    ops = _ops()
+    w = torch.randn(40, 7, 3, 3, generator=torch.Generator().manual_seed(1)) * 3
+    wc = w.cuda()
+    ops.normalize_weights_(wc)
+    assert rel_l2(wc, O.rms_normalize(w)) < 1e-6
+
+
+def test_layout_roundtrip_and_io_glue():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 6, 10, generator=g)
+    sig = torch.tensor([0.3, 7.0])
+    lnf = torch.randn(6, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        nh = ops.nchw_to_nhwc(x.cuda(), dt)
+        assert rel_l2(to_nchw(nh), x) < (1e-7 if dt == torch.float32 else 4e-3)
+        assert rel_l2(ops.nhwc_to_nchw(nh), x) < (1e-7 if dt == torch.float32 else 4e-3)
+    prep = torch.empty(2, 6, 10, 8, device="cuda")
+    ops.unet_input_prep(x.cuda(), sig.cuda(), lnf.cuda(), prep, 1.0)
+    c_in = 1 / torch.sqrt(1 + sig ** 2)
+    ref = torch.cat([x * c_in.view(-1, 1, 1, 1), torch.ones(2, 1, 6, 10), lnf.view(1, 1, 6, 1).expand(2, 1, 6, 10), torch.zeros(2, 2, 6, 10)], 1)
+    assert rel_l2(to_nchw(prep), ref) < 1e-6
+    y = torch.randn(2, 4, 6, 10, generator=g)
+    xr = torch.cat([torch.randn(2, 4, 6, 10, generator=g), torch.rand(2, 1, 6, 10, generator=g)], 1)
+    out = torch.empty(2, 4, 6, 10, device="cuda")
+    c_skip = 1 / (sig ** 2 + 1)
+    c_out = sig / torch.sqrt(sig ** 2 + 1)
+    d = c_skip.view(-1, 1, 1, 1) * x + c_out.view(-1, 1, 1, 1) * y
+    ops.unet_output_combine(to_nhwc(y), x.cuda(), sig.cuda(), None, out, 1.0)
+    assert rel_l2(out, d) < 1e-6
+    ops.unet_output_combine(to_nhwc(y), x.cuda(), sig.cuda(), xr.cuda(), out, 1.0)
+    assert rel_l2(out, O.sum_mp(xr[:, :-1], d, xr[:, -1:])) < 1e-6

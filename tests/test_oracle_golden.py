@@ -1,0 +1,92 @@
+"""CPU: the oracle (oracle/edm2_oracle.py) against the golden vectors produced from the reference
+(tools/make_golden.py).  This is what pins the oracle; the GPU tests then compare the HIP path with it."""
+import torch
+
+from oracle import edm2_oracle as O
+from tests.util import load_golden, rel_l2
+
+TOL = 2e-6
+
+
+def test_ops_golden():
+    t, m = load_golden("ops")
+    assert rel_l2(O.rms_normalize(t["normalize.w4.in"]), t["normalize.w4.out"]) < TOL
+    assert rel_l2(O.rms_normalize(t["normalize.act.in"], [1]), t["normalize.act.out"]) < TOL
+    assert rel_l2(O.rms_normalize(t["normalize.qk.in"], [2]), t["normalize.qk.out"]) < TOL
+    act = t["normalize.act.in"]
+    assert rel_l2(O.silu_mp(act), t["mp_silu.out"]) < TOL
+    assert rel_l2(O.sum_mp(act, t["mp_sum.b"], 0.3), t["mp_sum.t03.out"]) < TOL
+    assert rel_l2(O.sum_mp(act, t["mp_sum.b"], t["mp_sum.tt"]), t["mp_sum.tt.out"]) < TOL
+    assert rel_l2(O.cat_mp(act, t["mp_cat.b"], 0.5), t["mp_cat.out"]) < TOL
+    assert rel_l2(O.resample2x(t["resample.in"], "down"), t["resample.down.out"]) < TOL
+    assert torch.equal(O.resample2x(t["resample.in"], "up"), t["resample.up.out"])
+    for ch in (32, 128, 256):
+        fr, ph = O.fourier_tables(ch)
+        assert torch.equal(fr, t[f"mpfourier{ch}.freqs"]) and torch.equal(ph, t[f"mpfourier{ch}.phases"])
+        assert rel_l2(O.fourier_mp(t[f"mpfourier{ch}.in"], fr, ph), t[f"mpfourier{ch}.out"]) < TOL
+    for nm in ("c3g", "c1", "lin", "c3"):
+        g = m[f"mpconv.{nm}.groups"]
+        w, x, gain = t[f"mpconv.{nm}.w"], t[f"mpconv.{nm}.x"], t[f"mpconv.{nm}.gain"]
+        for mode in ("eval", "train"):
+            tr = mode == "train"
+            assert rel_l2(O.conv_mp(x, w, groups=g, training=tr), t[f"mpconv.{nm}.{mode}.out"]) < 5e-6
+            assert rel_l2(O.conv_mp(x, w, gain=gain, groups=g, training=tr), t[f"mpconv.{nm}.{mode}.out_gain"]) < 5e-6
+
+
+def test_blocks_golden():
+    t, m = load_golden("blocks")
+    for nm, c in m["cases"].items():
+        sd = {k[len(nm) + 1:]: v for k, v in t.items() if k.startswith(nm + ".blk.")}
+        for mode in ("eval", "train"):
+            y = O.block_forward(sd, "blk", t[f"{nm}.x"], t[f"{nm}.emb"], flavor=c["flavor"], resample=c["resample"],
+                                attention=c["attn"], heads=c["cout"] // m["channels_per_head"], groups=8, training=mode == "train")
+            assert rel_l2(y, t[f"{nm}.{mode}.out"]) < 5e-6, (nm, mode)
+
+
+def _unet_case(name):
+    t, m = load_golden(name)
+    cfg = O.unet_cfg(**m["cfg"])
+    if m["weights"] == "stored":
+        sd = {k[3:]: v for k, v in t.items() if k.startswith("sd.")}
+    else:
+        sd = O.random_unet_state(cfg, m["seed"])
+    return t, m, cfg, sd
+
+
+def test_unet_tiny_golden():
+    """BASELINE.json config 1: tiny EDM2 UNet, CPU float32."""
+    t, m, cfg, sd = _unet_case("unet_tiny")
+    mask = t["mask"].bool()
+    emb = O.unet_embeddings(sd, cfg, t["clap"], mask)
+    assert rel_l2(emb, t["embeddings"]) < TOL
+    assert rel_l2(O.unet_sigma_logvar(sd, cfg, t["sigma"]), t["logvar"]) < TOL
+    coll = {}
+    out = O.unet_forward(sd, cfg, t["x_in"], t["sigma"], t["embeddings"], collect=coll)
+    assert rel_l2(out, t["out"]) < 1e-5
+    for k in [k for k in t if k.startswith("stage.")]:
+        assert rel_l2(coll[k[6:]], t[k]) < 1e-5, k
+    out2 = O.unet_forward(sd, cfg, t["x_in"], t["sigma"], t["embeddings"], x_ref=t["x_ref"], perturbed_input=t["perturbed_input"])
+    assert rel_l2(out2, t["out_xref"]) < 1e-5
+    sd_t = {k: (v * t[f"trainscale.{k}"].view(-1, *([1] * (v.ndim - 1))) if v.ndim >= 2 else v) for k, v in sd.items()}
+    out_t = O.unet_forward(sd_t, cfg, t["x_in"], t["sigma"], t["embeddings"], training=True)
+    assert rel_l2(out_t, t["out_train_unnormalized"]) < 1e-5
+    assert O.unet_latent_shape(cfg, (2, 4, 37, 70)) == (2, 4, 36, 70)
+
+
+def test_unet_seeded_golden():
+    for name in ("unet_small", "unet_wide"):
+        t, m, cfg, sd = _unet_case(name)
+        out = O.unet_forward(sd, cfg, t["x_in"], t["sigma"], t["embeddings"])
+        assert rel_l2(out, t["out"]) < 1e-5, name
+
+
+def test_schedule_golden():
+    t, _ = load_golden("schedule")
+    for k, ref in t.items():
+        parts = k[len("edm2."):].split(".")
+        # key = edm2.<n>.<smax>.<smin>.<rho> with float fields containing one dot each
+        n = int(parts[0])
+        smax = float(parts[1] + "." + parts[2])
+        smin = float(parts[3] + "." + parts[4])
+        rho = float(parts[5] + "." + parts[6])
+        assert rel_l2(O.schedule_edm2(n, smax, smin, rho), ref) < 1e-6

@@ -1,0 +1,303 @@
+"""Generate golden vectors from the reference (BUILD CONTAINER ONLY; needs /root/reference).
+
+    python tools/make_golden.py [--only unet|ops|...]
+
+Imports the reference through tools/ref_import.py, runs it on seeded inputs on CPU fp32, checks
+our CPU oracle (oracle/) against it, and writes inputs + expected outputs as small safetensors
+fixtures under tests/golden/.  Only data is written: no reference source travels.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import types
+
+import torch
+from safetensors.torch import save_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_import  # noqa: E402
+
+ref_import.install()
+from oracle import edm2_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def save(name: str, tensors: dict, meta: dict) -> None:
+    meta = dict(meta)
+    meta["torch"] = torch.__version__
+    meta["threads"] = torch.get_num_threads()
+    tensors = {k: v.detach().contiguous().clone() for k, v in tensors.items()}
+    path = os.path.join(GOLD, name + ".safetensors")
+    save_file(tensors, path, metadata={"meta": json.dumps(meta)})
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1e6:.2f} MB, {len(tensors)} tensors)")
+
+
+def check(tag: str, ours: torch.Tensor, ref: torch.Tensor, tol: float = 2e-6) -> None:
+    e = rel_l2(ours, ref)
+    print(f"    oracle vs reference  {tag:<40s} rel-L2 {e:.2e}")
+    assert e <= tol, (tag, e)
+
+
+class FakeFormat:
+    """unet_edm2_b4.py:246 only needs format.ms_freq_scale.get_unscaled(n, device)."""
+
+    def __init__(self, fmin=20.0, fmax=16000.0):
+        from modules.formats.frequency_scale import FrequencyScale
+        self.ms_freq_scale = FrequencyScale("mel", fmin, fmax, 32000, 3201, 256)
+
+
+# --------------------------------------------------------------------------------------------- ops
+
+def gen_ops() -> None:
+    print("ops")
+    from modules import mp_tools as R
+    g = torch.Generator().manual_seed(100)
+    t, m = {}, {}
+    w4 = torch.randn(16, 4, 3, 3, generator=g)
+    act = torch.randn(2, 24, 5, 7, generator=g) * 3
+    qk = torch.randn(2, 3, 8, 2, 35, generator=g)
+    t["normalize.w4.in"], t["normalize.w4.out"] = w4, R.normalize(w4)
+    t["normalize.act.in"], t["normalize.act.out"] = act, R.normalize(act, dim=1)
+    t["normalize.qk.in"], t["normalize.qk.out"] = qk, R.normalize(qk, dim=2)
+    check("normalize.w4", O.rms_normalize(w4), t["normalize.w4.out"])
+    check("normalize.act", O.rms_normalize(act, [1]), t["normalize.act.out"])
+    check("normalize.qk", O.rms_normalize(qk, [2]), t["normalize.qk.out"])
+
+    t["mp_silu.out"] = R.mp_silu(act)
+    check("mp_silu", O.silu_mp(act), t["mp_silu.out"])
+    b2 = torch.randn(2, 24, 5, 7, generator=g)
+    t["mp_sum.b"] = b2
+    t["mp_sum.t03.out"] = R.mp_sum(act, b2, t=0.3)
+    tt = torch.tensor([0.0, 1.0]).view(2, 1, 1, 1)
+    t["mp_sum.tt"] = tt
+    t["mp_sum.tt.out"] = R.mp_sum(act, b2, t=tt)
+    check("mp_sum 0.3", O.sum_mp(act, b2, 0.3), t["mp_sum.t03.out"])
+    check("mp_sum tensor", O.sum_mp(act, b2, tt), t["mp_sum.tt.out"])
+    c2 = torch.randn(2, 40, 5, 7, generator=g)
+    t["mp_cat.b"] = c2
+    t["mp_cat.out"] = R.mp_cat(act, c2, t=0.5)
+    check("mp_cat", O.cat_mp(act, c2, 0.5), t["mp_cat.out"])
+    ev = torch.randn(2, 8, 6, 10, generator=g)
+    t["resample.in"] = ev
+    t["resample.down.out"] = R.resample_2d(ev, "down")
+    t["resample.up.out"] = R.resample_2d(ev, "up")
+    check("resample down", O.resample2x(ev, "down"), t["resample.down.out"])
+    check("resample up", O.resample2x(ev, "up"), t["resample.up.out"])
+
+    for ch in (32, 128, 256):
+        f = R.MPFourier(ch)
+        x = torch.randn(5, generator=g)
+        t[f"mpfourier{ch}.freqs"], t[f"mpfourier{ch}.phases"] = f.freqs, f.phases
+        t[f"mpfourier{ch}.in"], t[f"mpfourier{ch}.out"] = x, f(x)
+        fr, ph = O.fourier_tables(ch)
+        assert torch.equal(fr, f.freqs) and torch.equal(ph, f.phases)
+        check(f"mpfourier{ch}", O.fourier_mp(x, fr, ph), t[f"mpfourier{ch}.out"])
+
+    # MPConv: 3x3 grouped, 1x1, linear; eval and train (fused weight norm); float and 0-d tensor gain
+    cases = {"c3g": ((32, 4, 3, 3), 8, (2, 32, 6, 9)), "c1": ((24, 16, 1, 1), 1, (2, 16, 6, 9)), "lin": ((24, 16), 1, (3, 16)),
+             "c3": ((8, 6, 3, 3), 1, (2, 6, 6, 9))}
+    for nm, (wshape, groups, xshape) in cases.items():
+        if len(wshape) == 4:
+            conv = R.MPConv(wshape[1] * groups, wshape[0], kernel=wshape[2:], groups=groups)
+        else:
+            conv = R.MPConv(wshape[1], wshape[0], kernel=())
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(wshape, generator=g) * 1.7)
+        x = torch.randn(xshape, generator=g)
+        gain = torch.tensor(0.37)
+        t[f"mpconv.{nm}.w"], t[f"mpconv.{nm}.x"], t[f"mpconv.{nm}.gain"] = conv.weight.detach(), x, gain
+        for mode in ("eval", "train"):
+            conv.train(mode == "train")
+            with torch.no_grad():
+                y1, yg = conv(x), conv(x, gain=gain)
+            t[f"mpconv.{nm}.{mode}.out"], t[f"mpconv.{nm}.{mode}.out_gain"] = y1, yg
+            check(f"mpconv.{nm}.{mode}", O.conv_mp(x, conv.weight.detach(), groups=groups, training=mode == "train"), y1, 5e-6)
+            check(f"mpconv.{nm}.{mode}.gain", O.conv_mp(x, conv.weight.detach(), gain=gain, groups=groups,
+                                                        training=mode == "train"), yg, 5e-6)
+        m[f"mpconv.{nm}.groups"] = groups
+    save("ops", t, m)
+
+
+# --------------------------------------------------------------------------------------------- blocks
+
+def gen_blocks() -> None:
+    print("blocks")
+    from modules.unets.unet_edm2_b4 import Block
+    g = torch.Generator().manual_seed(200)
+    t, m = {}, {"cases": {}}
+    cases = {
+        "enc_keep": dict(level=0, cin=32, cout=64, flavor="enc", resample="keep", attn=False, hw=(8, 12)),
+        "enc_down_attn": dict(level=1, cin=64, cout=64, flavor="enc", resample="down", attn=True, hw=(8, 12)),
+        "dec_up": dict(level=0, cin=64, cout=64, flavor="dec", resample="up", attn=False, hw=(4, 6)),
+        "dec_attn": dict(level=1, cin=96, cout=64, flavor="dec", resample="keep", attn=True, hw=(4, 7)),
+    }
+    cemb = 48
+    for nm, c in cases.items():
+        blk = Block(c["level"], c["cin"], c["cout"], cemb, flavor=c["flavor"], resample_mode=c["resample"],
+                    use_attention=c["attn"], channels_per_head=32, mlp_groups=8, mlp_multiplier=2)
+        with torch.no_grad():
+            for k, p in blk.named_parameters():
+                if p.ndim == 0:
+                    p.fill_(0.7 if "qk" not in k else -0.4)
+                else:
+                    p.copy_(O.rms_normalize(torch.randn(p.shape, generator=g)))
+        x = torch.randn(2, c["cin"], *c["hw"], generator=g) * 1.5
+        emb = torch.randn(2, cemb, 1, 1, generator=g)
+        sd = {f"blk.{k}": v.detach() for k, v in blk.state_dict().items()}
+        for mode in ("eval", "train"):
+            blk.train(mode == "train")
+            with torch.no_grad():
+                y = blk(x.clone(), emb)
+            ours = O.block_forward(sd, "blk", x, emb, flavor=c["flavor"], resample=c["resample"], attention=c["attn"],
+                                   heads=c["cout"] // 32, groups=8, training=mode == "train")
+            check(f"block.{nm}.{mode}", ours, y, 5e-6)
+            t[f"{nm}.{mode}.out"] = y
+        for k, v in sd.items():
+            t[f"{nm}.{k}"] = v
+        t[f"{nm}.x"], t[f"{nm}.emb"] = x, emb
+        m["cases"][nm] = {k: v for k, v in c.items()}
+    m["cemb"] = cemb
+    m["channels_per_head"] = 32
+    save("blocks", t, m)
+
+
+# --------------------------------------------------------------------------------------------- UNet
+
+def make_ref_unet(cfg: dict):
+    from modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    c = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}
+    return UNet(UNetConfig(**c)).requires_grad_(False).train(False)
+
+
+def run_unet_case(name: str, cfg: dict, seed: int, B: int, H: int, W: int, sigmas, store_weights: bool,
+                  stages: tuple = (), with_xref: bool = False) -> None:
+    print(f"unet case {name}")
+    unet = make_ref_unet(cfg)
+    shapes = O.unet_param_shapes(cfg)
+    ref_sd = unet.state_dict()
+    assert {k: tuple(v.shape) for k, v in ref_sd.items()} == {k: tuple(v) for k, v in shapes.items()}, "param shapes differ"
+    sd = O.random_unet_state(cfg, seed)
+    unet.load_state_dict(sd)
+    fmt = FakeFormat()
+    g = torch.Generator().manual_seed(seed + 1)
+    sigma = torch.tensor(sigmas, dtype=torch.float32)
+    assert sigma.numel() == B
+    x_in = torch.randn(B, cfg["in_channels"], H, W, generator=g) * torch.sqrt(sigma ** 2 + 1).view(-1, 1, 1, 1)
+    clap = torch.randn(B, cfg["in_channels_emb"], generator=g)
+    mask = torch.tensor([i % 2 == 0 for i in range(B)])
+    t = {"x_in": x_in, "sigma": sigma, "clap": clap, "mask": mask.to(torch.uint8)}
+    with torch.no_grad():
+        emb = unet.get_embeddings(clap, mask)
+        out = unet(x_in, sigma, fmt, emb)
+        logvar = unet.get_sigma_loss_logvar(sigma)
+    t["embeddings"], t["out"], t["logvar"] = emb, out, logvar
+    check("get_embeddings", O.unet_embeddings(sd, cfg, clap, mask), emb)
+    check("sigma_logvar", O.unet_sigma_logvar(sd, cfg, sigma), logvar)
+    coll = {}
+    ours = O.unet_forward(sd, cfg, x_in, sigma, emb, collect=coll)
+    check("forward", ours, out, 1e-5)
+    assert float((out - x_in * (1 / (sigma ** 2 + 1)).view(-1, 1, 1, 1)).abs().max()) > 1e-3, "vacuous (gains zero?)"
+    if with_xref:
+        x_ref = torch.cat([torch.randn(B, cfg["out_channels"], H, W, generator=g),
+                           torch.rand(B, 1, H, W, generator=g)], dim=1)
+        pert = x_in + 0.1 * torch.randn(x_in.shape, generator=g)
+        with torch.no_grad():
+            out2 = unet(x_in, sigma, fmt, emb, x_ref=x_ref, perturbed_input=pert)
+        t["x_ref"], t["perturbed_input"], t["out_xref"] = x_ref, pert, out2
+        check("forward x_ref", O.unet_forward(sd, cfg, x_in, sigma, emb, x_ref=x_ref, perturbed_input=pert), out2, 1e-5)
+    # train-mode forward (fused weight norm in every MPConv): weights here are already normalised, so
+    # perturb them first to make the test meaningful
+    sd_t = {k: (v * (1.0 + 0.5 * torch.rand(v.shape[0], *([1] * (v.ndim - 1)), generator=g)) if v.ndim >= 2 else v)
+            for k, v in sd.items()}
+    unet.load_state_dict(sd_t)
+    unet.train(True)
+    with torch.no_grad():
+        out_t = unet(x_in, sigma, fmt, emb)
+    unet.train(False)
+    check("forward train-mode", O.unet_forward(sd_t, cfg, x_in, sigma, emb, training=True), out_t, 1e-5)
+    t["out_train_unnormalized"] = out_t
+    # the un-normalised weights are sd[k] * trainscale[k] (per output row): keep just the factors
+    for k, v in sd_t.items():
+        if v.ndim >= 2:
+            t[f"trainscale.{k}"] = (v.flatten(1)[:, :1] / sd[k].flatten(1)[:, :1]).flatten()
+    # hook stage outputs from the reference for layer-level parity
+    if stages:
+        unet.load_state_dict(sd)
+        got = {}
+        hooks = []
+        for side in ("enc", "dec"):
+            for nm, mod in getattr(unet, side).items():
+                key = f"{side}.{nm}"
+                if key in stages:
+                    hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=key: got.__setitem__(key, o.detach().clone())))
+        with torch.no_grad():
+            unet(x_in, sigma, fmt, emb)
+        for h in hooks:
+            h.remove()
+        for k in stages:
+            check(f"stage {k}", coll[k], got[k], 1e-5)
+            t[f"stage.{k}"] = got[k]
+    if store_weights:
+        for k, v in sd.items():
+            t[f"sd.{k}"] = v
+    meta = dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, seed=seed, B=B, H=H, W=W,
+                weights="stored" if store_weights else "oracle.random_unet_state(cfg, seed)", freq_range=[20.0, 16000.0],
+                params=sum(v.numel() for v in sd.values()))
+    save(name, t, meta)
+
+
+def gen_unet() -> None:
+    # BASELINE.json config 1: tiny EDM2 UNet, CPU fp32 plumbing case
+    tiny = O.unet_cfg(model_channels=32, channel_mult=(1, 2), num_layers_per_block=2, attn_levels=(1,),
+                      channels_per_head=32, mlp_groups=8, mlp_multiplier=2, channel_mult_noise=1, channel_mult_emb=2)
+    run_unet_case("unet_tiny", tiny, seed=0, B=2, H=32, W=32, sigmas=[0.5, 5.0], store_weights=True,
+                  stages=("enc.block0_layer0", "enc.block1_down", "dec.block1_in0", "dec.block1_layer2", "dec.block0_up"),
+                  with_xref=True)
+    # MFMA-shaped small case: channel counts are multiples of 8 per group (vector path) with K/N padding,
+    # three levels incl. odd widths; weights re-derived from the seed (not stored)
+    small = O.unet_cfg(model_channels=64, channel_mult=(1, 2, 3), num_layers_per_block=1, attn_levels=(2,),
+                       channels_per_head=64, channel_mult_noise=1, channel_mult_emb=2)
+    run_unet_case("unet_small", small, seed=7, B=2, H=16, W=44, sigmas=[0.08, 30.0], store_weights=False,
+                  stages=("enc.conv_in", "enc.block0_layer0", "enc.block1_down", "enc.block2_layer0", "dec.block2_in0",
+                          "dec.block2_layer1", "dec.block1_up", "dec.block0_layer1"))
+    # full-width channels (Cg = 32.., exactly the default model's level-0/1 block shapes) on a small image
+    wide = O.unet_cfg(model_channels=256, channel_mult=(1, 2), num_layers_per_block=1, attn_levels=(1,),
+                      channel_mult_noise=1, channel_mult_emb=3)
+    run_unet_case("unet_wide", wide, seed=11, B=2, H=16, W=24, sigmas=[0.3, 2.0], store_weights=False,
+                  stages=("enc.block0_layer0", "enc.block1_layer0", "dec.block1_layer0", "dec.block0_up"))
+
+
+def gen_schedule() -> None:
+    print("schedule")
+    from sampling.schedule import SamplingSchedule
+    t = {}
+    for n, smax, smin, rho in ((4, 200.0, 0.03, 7.0), (100, 200.0, 0.03, 7.0), (30, 80.0, 0.002, 5.0)):
+        ref = SamplingSchedule.get_schedule("edm2", n, sigma_max=smax, sigma_min=smin, rho=rho)
+        t[f"edm2.{n}.{smax}.{smin}.{rho}"] = ref
+        check(f"schedule {n}", O.schedule_edm2(n, smax, smin, rho), ref, 1e-6)
+    save("schedule", t, {})
+
+
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    for k, fn in GENS.items():
+        if a.only is None or k in a.only:
+            fn()
+    print("done")
