@@ -78,6 +78,8 @@ PROTOTYPES = {
     "ddx_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddx_plan_graph_build": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddx_plan_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_plan_op_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ddx_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "ddx_plan_destroy": (None, [C.c_void_p]),
 }
 
@@ -162,6 +164,18 @@ class Plan:
 
     def graph_launch(self, stream: Optional[int] = None) -> None:
         check(lib().ddx_plan_graph_launch(self._h, stream if stream is not None else current_stream()), "plan_graph_launch")
+
+    def profile(self, reps: int = 3, stream: Optional[int] = None) -> list:
+        """Eager replay with a hipEvent pair around every op: [(tag, flops, bytes, mean_ms)] per op."""
+        n = self.num_ops
+        ms = (C.c_float * n)()
+        check(lib().ddx_plan_profile(self._h, stream if stream is not None else current_stream(), reps, ms), "plan_profile")
+        out = []
+        for i in range(n):
+            tag, fl, by = C.c_char_p(), C.c_double(), C.c_double()
+            check(lib().ddx_plan_op_info(self._h, i, C.byref(tag), C.byref(fl), C.byref(by)), "plan_op_info")
+            out.append((tag.value.decode(), fl.value, by.value, float(ms[i])))
+        return out
 
     @property
     def has_graph(self) -> bool:

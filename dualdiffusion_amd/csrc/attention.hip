@@ -259,5 +259,6 @@ extern "C" int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B,
     if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, B, T, heads, eps, s);
     if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, B, T, heads, eps, s);
     return launch_attn<float, 128>(qk, v, out, B, T, heads, eps, s);
-  }, stream);
+  }, stream, "attention", 4.0 * B * heads * (double)T * T * head_dim,
+     (double)dtype_size(dtype) * 4.0 * B * T * heads * head_dim);
 }

@@ -19,12 +19,17 @@ constexpr float kMpSiluInv = 1.0f / 0.596f;
 
 // ---- dispatch: launch now, or record into the thread-local plan (plan.cpp)
 using LaunchFn = std::function<int(hipStream_t)>;
-int dispatch(LaunchFn&& fn, ddx_stream stream);
+int dispatch(LaunchFn&& fn, ddx_stream stream, const char* tag = "op", double flops = 0.0, double bytes = 0.0);
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
 
 // ---- scalar helpers
-__device__ __forceinline__ float mp_silu_f(float x) { return x / (1.0f + __expf(-x)) * kMpSiluInv; }
+// mp_silu(x) = x * sigmoid(x) / 0.596 with v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence:
+// 6 VALU instructions per element instead of ~16 (the fused conv prologue runs this on every staged activation).
+__device__ __forceinline__ float mp_silu_f(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);
+  return (x * kMpSiluInv) * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

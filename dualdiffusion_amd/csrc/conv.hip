@@ -64,7 +64,7 @@ extern "C" size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32
 }
 
 extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype) {
-  (void)dtype;
+  if (ksize == 1 && dtype == DDX_BF16 && Cg >= 128 && Cg % 128 == 0) return 128;
   if (ksize == 1 && Cg >= 64) return 64;
   return 32;
 }
@@ -72,7 +72,7 @@ extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype
 extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
   if (!dp || !dp->w || !dp->wp) return set_error(DDX_ERR_ARG, "wprep: null");
   const ddx_wprep_desc d = *dp;
-  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 32 && d.CK != 64))
+  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 32 && d.CK != 64 && d.CK != 128))
     return set_error(DDX_ERR_ARG, "wprep: bad shape");
   if (d.qk_head_dim > 0 && (d.groups != 1 || d.Cout % (2 * d.qk_head_dim))) return set_error(DDX_ERR_ARG, "wprep: bad qk_head_dim");
   return dispatch([d](hipStream_t s) -> int {
@@ -92,7 +92,7 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
     else return set_error(DDX_ERR_ARG, "wprep: dtype");
 #undef DDX_WPREP
     return check_launch("wprep");
-  }, stream);
+  }, stream, "wprep");
 }
 
 extern "C" int ddx_normalize_weights(void* w, int32_t w_dtype, int64_t rows, int64_t fan_in, ddx_stream stream) {
@@ -135,7 +135,11 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   p.clip = d.clip;
   const int ks = d.ksize, dt = d.dtype;
   const bool mfma = !d.force_direct && conv_mfma_supported(p, ks, dt);
+  const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
+  const double es = (double)dtype_size(dt);
+  const double bytes = es * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) +
+                             (double)p.Cout * p.Cg * ks * ks);
   return dispatch([p, ks, dt, mfma](hipStream_t s) -> int {
     return mfma ? launch_conv_mfma(p, ks, dt, s) : launch_conv_direct(p, ks, dt, s);
-  }, stream);
+  }, stream, mfma ? (ks == 3 ? "conv3x3_mfma" : "conv1x1_mfma") : "conv_direct", flops, bytes);
 }

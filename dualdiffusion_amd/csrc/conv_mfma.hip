@@ -7,14 +7,21 @@
 //   output tile  = TH x TW pixels of one image (<= BM = WM*MF*32)  x  BN = WN*NF*32 output channels of one group
 //   K loop       = chunks of CK input channels of the group; per chunk
 //       stage   : the (TH+2)x(TW+2) input halo of the chunk -> LDS, ONCE (not 9x im2col), with the fused
-//                 prologue (mp_cat scales, y*c, mp_silu, nearest-up / avg-pool gather) applied in fp32 on the way
+//                 prologue (mp_cat scales, y*c, mp_silu, nearest-up / avg-pool gather) applied in fp32 on the way;
 //                 the chunk of prepared weights [tap][BN][CK] -> LDS
 //       compute : for each of the ks*ks taps the activation fragment is the same LDS tile read at a shifted row,
 //                 v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (fp32 parity path), fp32 accumulate
+//   Staging is register-staged and split (issue early / write late): all global loads of chunk c+1 are issued
+//   back-to-back BEFORE the MFMA phase of chunk c and only converted + written to LDS after it, so HBM/L2 latency
+//   hides under the matrix work instead of serialising one round trip per loader iteration.
 //   MFMA orientation: A operand = weights (rows = output channels), B operand = activations (cols = pixels), so
 //   every lane ends up with 4 consecutive output channels of ONE pixel -> vector epilogue on NHWC rows.
 //   LDS rows are padded by 16 B: a row stride of CK*sizeof(T)+16 bytes makes the 16-lane groups of ds_read_b128 hit
-//   16 distinct bank slots (stride 80 B -> slot = 5r mod 16, stride 144 B -> 9r mod 16; both bijective).
+//   16 distinct bank slots (stride 80 B -> slot = 5r mod 16, 144 B -> 9r, 272 B -> 17r; all bijective mod 16).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
 #include "conv_params.hpp"
 
 namespace ddx {
@@ -37,16 +44,25 @@ template <> struct Mfma<float> {
   }
 };
 
-template <typename T, int KS, int CK, int WM, int WN, int MF, int NF>
+// halo rows a tile configuration may stage (bounds the per-thread register staging)
+constexpr int arows_max(int KS, int BM) { return KS == 3 ? (BM == 256 ? 352 : 208) : BM; }
+
+template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, bool DN>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int V = CK / EV;
+  constexpr int RPP = 256 / V;  // halo rows covered per staging pass
   constexpr int STRIDE = CK + EV;
-  constexpr int BN = WN * NF * 32;
+  constexpr int BM = WM * MF * 32, BN = WN * NF * 32;
   constexpr int KM = Mfma<T>::KM;
+  constexpr int AI = (arows_max(KS, BM) * V + 255) / 256;  // activation vectors per thread per chunk
+  constexpr int BI = (TAPS * BN * V + 255) / 256;           // weight vectors per thread per chunk
+  constexpr bool PIPE = sizeof(T) == 2;                     // prefetch across the MFMA phase (bf16 path)
   using Frag = typename Mfma<T>::Frag;
+  using VT = decltype(Vec16<T>().v);
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sA = reinterpret_cast<T*>(smem);
@@ -87,146 +103,298 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int v = tid % V;
+  const int r0 = tid / V;
   const T* wp = reinterpret_cast<const T*>(p.wp);
+  const bool do_silu = (p.prologue & DDX_PRO_SILU) != 0;
 
-  for (int ch = 0; ch < p.nchunk; ++ch) {
-    // ------------------------------------------------------------ stage the activation halo (fused prologue)
-    {
-      const int cg = ch * CK + v * EV;  // channel inside the group
-      const bool cvalid = cg < p.Cg;
-      const int cabs = g * p.Cg + cg;   // channel of the (virtually concatenated) input
-      const bool first = cabs < p.C0;
-      const T* src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
-      const int Cs = first ? p.C0 : p.C1;
-      const int cc = first ? cabs : cabs - p.C0;
-      const float sscale = first ? p.scale0 : p.scale1;
-      float cs[EV];
+  // per-item source pixel offsets (in pixels of the source image); invalid items load pixel 0 and are zeroed at
+  // commit time, so the issue phase is straight-line code (no per-item branches -> no forced vmcnt(0) at joins)
+  int apix[AI];
+  unsigned avalid = 0;
 #pragma unroll
-      for (int e = 0; e < EV; ++e) cs[e] = sscale;
-      if ((p.prologue & DDX_PRO_SCALE) && cvalid) {
-        const float* csp = p.cscale + (size_t)b * p.Cin + cabs;
-#pragma unroll
-        for (int e = 0; e < EV; e += 4) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(csp + e);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) cs[e + q] *= t4[q];
-        }
-      }
-      const bool do_silu = (p.prologue & DDX_PRO_SILU) != 0;
-      for (int r = tid / V; r < R; r += 256 / V) {
-        const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
-        const int ww = r - hh * TWP;
-        const int ih = h0 - PAD + hh, iw = w0 - PAD + ww;
-        Vec16<T> o;
-        if (cvalid && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-          float f[EV];
-          if (p.resample == DDX_RESAMPLE_DOWN) {
-            const size_t base = (((size_t)b * p.sH + 2 * ih) * p.sW + 2 * iw) * Cs + cc;
-            Vec16<T> a0, a1, a2, a3;
-            a0.v = *reinterpret_cast<const decltype(a0.v)*>(src + base);
-            a1.v = *reinterpret_cast<const decltype(a0.v)*>(src + base + Cs);
-            a2.v = *reinterpret_cast<const decltype(a0.v)*>(src + base + (size_t)p.sW * Cs);
-            a3.v = *reinterpret_cast<const decltype(a0.v)*>(src + base + (size_t)p.sW * Cs + Cs);
-#pragma unroll
-            for (int e = 0; e < EV; ++e) f[e] = 0.25f * ((a0.get(e) + a1.get(e)) + (a2.get(e) + a3.get(e)));
-          } else {
-            const int sh = (p.resample == DDX_RESAMPLE_UP) ? (ih >> 1) : ih;
-            const int sw = (p.resample == DDX_RESAMPLE_UP) ? (iw >> 1) : iw;
-            Vec16<T> a0;
-            a0.v = *reinterpret_cast<const decltype(a0.v)*>(src + (((size_t)b * p.sH + sh) * p.sW + sw) * Cs + cc);
-#pragma unroll
-            for (int e = 0; e < EV; ++e) f[e] = a0.get(e);
-          }
-#pragma unroll
-          for (int e = 0; e < EV; ++e) {
-            float x = f[e] * cs[e];
-            if (do_silu) x = mp_silu_f(x);
-            o.set(e, x);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < EV; ++e) o.set(e, 0.f);
-        }
-        *reinterpret_cast<decltype(o.v)*>(sA + (size_t)r * STRIDE + v * EV) = o.v;
-      }
-    }
-    // ------------------------------------------------------------ stage the weights of this chunk
-    {
-      const T* wsrc = wp + ((size_t)(g * p.nchunk + ch) * TAPS * p.NgP) * CK;
-      for (int idx = tid; idx < TAPS * BN * V; idx += 256) {
-        const int v2 = idx % V;
-        const int rn = idx / V;
-        const int tap = rn / BN;
-        const int n = rn - tap * BN;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (n0 + n < p.NgP) val = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(tap * p.NgP + n0 + n)) * CK + v2 * EV);
-        *reinterpret_cast<uint4*>(sB + (size_t)rn * STRIDE + v2 * EV) = val;
-      }
-    }
-    __syncthreads();
-    // ------------------------------------------------------------ tensor-core part
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int toff = (tap / KS) * TWP + (tap % KS);
-#pragma unroll
-      for (int ks = 0; ks < CK / KM; ++ks) {
-        Frag wf[NF], xf[MF];
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-          wf[i] = Mfma<T>::load(sB + (size_t)(tap * BN + (wn * NF + i) * 32 + l31) * STRIDE + ks * KM, khalf);
-#pragma unroll
-        for (int j = 0; j < MF; ++j) xf[j] = Mfma<T>::load(sA + (size_t)(arow[j] + toff) * STRIDE + ks * KM, khalf);
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-#pragma unroll
-          for (int j = 0; j < MF; ++j) acc[i][j] = Mfma<T>::mma(wf[i], xf[j], acc[i][j]);
-      }
-    }
-    __syncthreads();
+  for (int i = 0; i < AI; ++i) {
+    const int r = r0 + i * RPP;
+    const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
+    const int ww = r - hh * TWP;
+    const int ih = h0 - PAD + hh, iw = w0 - PAD + ww;
+    const bool ok = r < R && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+    int pix;
+    if (DN) pix = (b * p.sH + 2 * ih) * p.sW + 2 * iw;
+    else if (p.resample == DDX_RESAMPLE_UP) pix = (b * p.sH + (ih >> 1)) * p.sW + (iw >> 1);
+    else pix = (b * p.sH + ih) * p.sW + iw;
+    apix[i] = ok ? pix : 0;
+    avalid |= (ok ? 1u : 0u) << i;
   }
 
-  // ---------------------------------------------------------------- epilogue: lane owns pixel (col), 4-channel runs
-  T* out = reinterpret_cast<T*>(p.out);
-  const T* res = reinterpret_cast<const T*>(p.res);
+  VT areg[AI];
+  u32x4 breg[BI];
+  float cs[EV];
+  bool cvalid_cur = false;
+  float sscale_cur = 1.0f;
+
+  // ---- issue: the global loads of one chunk, nothing consumed (except the rare DN gather).  Split into a setup
+  // step and per-item loads so that the bf16 kernel can spread the loads between the MFMA groups of the previous
+  // chunk: a burst of 15 KiB per wave in front of the matrix phase keeps the wave in the (L1-throughput bound)
+  // VMEM issue queue and nothing overlaps.
+  const T* a_src = nullptr;
+  int a_cs = 0, a_cc = 0;
+  const T* w_src = nullptr;
+  auto issue_setup = [&](int ch) {
+    const int cg = ch * CK + v * EV;  // channel inside the group
+    const bool cvalid = cg < p.Cg;
+    const int cabs = cvalid ? g * p.Cg + cg : 0;   // channel of the (virtually concatenated) input
+    const bool first = cabs < p.C0;
+    a_src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
+    a_cs = first ? p.C0 : p.C1;
+    a_cc = first ? cabs : cabs - p.C0;
+    cvalid_cur = cvalid;
+    sscale_cur = first ? p.scale0 : p.scale1;
+    if (p.prologue & DDX_PRO_SCALE) {  // raw per-(b, channel) factors; folded with the source scale at commit time
+      const float* csp = p.cscale + (size_t)b * p.Cin + cabs;
+#pragma unroll
+      for (int e = 0; e < EV; e += 4) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(csp + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cs[e + q] = t4[q];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EV; ++e) cs[e] = 1.0f;
+    }
+    w_src = wp + ((size_t)(g * p.nchunk + ch) * TAPS * p.NgP) * CK;
+  };
+  auto issue_a = [&](int i) {
+    const T* sp = a_src + (size_t)apix[i] * a_cs + a_cc;
+    if (DN) {  // 2x2 average on the fly (the 1x1 skip conv of "down" blocks)
+      Vec16<T> a0, a1, a2, a3;
+      a0.v = *reinterpret_cast<const VT*>(sp);
+      a1.v = *reinterpret_cast<const VT*>(sp + a_cs);
+      a2.v = *reinterpret_cast<const VT*>(sp + (size_t)p.sW * a_cs);
+      a3.v = *reinterpret_cast<const VT*>(sp + (size_t)p.sW * a_cs + a_cs);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) a0.set(e, 0.25f * ((a0.get(e) + a1.get(e)) + (a2.get(e) + a3.get(e))));
+      areg[i] = a0.v;
+    } else {
+      areg[i] = *reinterpret_cast<const VT*>(sp);
+    }
+  };
+  auto issue_b = [&](int i) {
+    const int idx = min(tid + i * 256, TAPS * BN * V - 1);
+    const int v2 = idx % V;
+    const int rn = idx / V;
+    const int tap = rn / BN;
+    const int n = min(n0 + rn - tap * BN, p.NgP - 1);  // rows past NgP only feed outputs that are never stored
+    breg[i] = *reinterpret_cast<const u32x4*>(w_src + ((size_t)(tap * p.NgP + n)) * CK + v2 * EV);
+  };
+  auto issue = [&](int ch) {
+    issue_setup(ch);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) issue_a(i);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) issue_b(i);
+  };
+
+  // ---- commit: fused prologue in fp32, pack, write LDS
+  auto commit_a = [&](auto silu_tag) {
+    constexpr bool SILU = decltype(silu_tag)::value;
+    float csf[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) csf[e] = cs[e] * sscale_cur;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int r = r0 + i * RPP;
+      Vec16<T> a, o;
+      a.v = areg[i];
+      const bool ok = cvalid_cur && ((avalid >> i) & 1u);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) {
+        float x = a.get(e) * csf[e];
+        if (SILU) x = mp_silu_f(x);
+        o.set(e, x);
+      }
+      VT ov = o.v;
+      if (!ok) {
+        Vec16<T> z;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) z.set(e, 0.f);
+        ov = z.v;
+      }
+      if (r < R) *reinterpret_cast<VT*>(sA + (size_t)r * STRIDE + v * EV) = ov;
+    }
+  };
+  // prologue-free fast path: the staged vectors go to LDS untouched (no unpack / scale / repack VALU work)
+  const bool do_raw = !DN && p.prologue == DDX_PRO_NONE && p.scale0 == 1.0f && (p.src1 == nullptr || p.scale1 == 1.0f);
+  auto commit_raw = [&]() {
+    Vec16<T> z;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) z.set(e, 0.f);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int r = r0 + i * RPP;
+      const bool ok = cvalid_cur && ((avalid >> i) & 1u);
+      if (r < R) *reinterpret_cast<VT*>(sA + (size_t)r * STRIDE + v * EV) = ok ? areg[i] : z.v;
+    }
+  };
+  auto commit = [&]() {
+    if (do_raw) commit_raw();
+    else if (do_silu) commit_a(std::true_type{});
+    else commit_a(std::false_type{});
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < TAPS * BN * V) *reinterpret_cast<u32x4*>(sB + (size_t)(idx / V) * STRIDE + (idx % V) * EV) = breg[i];
+    }
+  };
+
+  // Keep the staged registers opaque until the MFMA phase is over: without this hipcc hoists the bf16->f32 unpacking
+  // of the first loads above the matrix loop, which puts a vmcnt wait (one memory latency) in front of every chunk.
+  auto pin = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) asm volatile("" : "+v"(areg[i]));
+#pragma unroll
+    for (int i = 0; i < BI; ++i) asm volatile("" : "+v"(breg[i]));
+#pragma unroll
+    for (int e = 0; e < EV; ++e) asm volatile("" : "+v"(cs[e]));
+  };
+
+  // MFMA phase of the current chunk; with `prefetch` the loads of the next chunk are issued in small groups
+  // between the MFMA groups (SLOTS groups per chunk)
+  constexpr int SLOTS = TAPS * (CK / KM);
+  constexpr int LPS = (AI + BI + SLOTS - 1) / SLOTS;  // loads per slot
+  auto compute = [&](auto prefetch_tag) {
+    constexpr bool prefetch = decltype(prefetch_tag)::value;
+    // fragments of slot s+1 are read while the MFMAs of slot s run (explicit double buffering), so that the
+    // scheduling barrier that pins the global loads between the MFMA groups does not expose LDS latency
+    Frag wf[2][NF], xf[2][MF];
+    auto load_frags = [&](int slot, int buf) {
+      const int tap = slot / (CK / KM), ks = slot % (CK / KM);
+      const int toff = (tap / KS) * TWP + (tap % KS);
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+        wf[buf][i] = Mfma<T>::load(sB + (size_t)(tap * BN + (wn * NF + i) * 32 + l31) * STRIDE + ks * KM, khalf);
+#pragma unroll
+      for (int j = 0; j < MF; ++j) xf[buf][j] = Mfma<T>::load(sA + (size_t)(arow[j] + toff) * STRIDE + ks * KM, khalf);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+      const int cur = slot & 1;
+      if (slot + 1 < SLOTS) load_frags(slot + 1, cur ^ 1);
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = Mfma<T>::mma(wf[cur][i], xf[cur][j], acc[i][j]);
+      if (PIPE && prefetch) {
+#pragma unroll
+        for (int q = 0; q < LPS; ++q) {
+          const int li = slot * LPS + q;
+          if (li < AI) issue_a(li);
+          else if (li < AI + BI) issue_b(li - AI);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every load behind the last MFMA
+      }
+    }
+  };
+
+  issue(0);
+  commit();
+  __syncthreads();
+  if constexpr (PIPE) {
+    // steady state: chunk ch is multiplied while chunk ch+1 is loaded (interleaved), then converted and written.
+    // The last chunk is peeled so that the staged registers never meet at a control-flow join (a phi there makes
+    // hipcc copy them right after the loads, i.e. wait for every load inside the matrix phase).
+    for (int ch = 0; ch + 1 < p.nchunk; ++ch) {
+      issue_setup(ch + 1);
+      compute(std::true_type{});
+      __syncthreads();  // every wave is done reading this chunk
+      pin();
+      commit();
+      __syncthreads();
+    }
+    compute(std::false_type{});
+  } else {
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+      compute(std::false_type{});
+      __syncthreads();
+      if (ch + 1 < p.nchunk) {
+        issue(ch + 1);
+        commit();
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- epilogue
+  // The accumulators (lane = one pixel, 4-channel runs) are transposed through LDS so that global traffic is fully
+  // coalesced: 16 consecutive lanes cover the BN contiguous channels of one NHWC pixel (whole 128-byte lines for the
+  // residual read and the store) instead of 32 lanes touching 32 different lines with 8 bytes each.
+  constexpr int ES = BN + 4;  // fp32 row stride of the transpose buffer: 8 rows x (ES*4 B) tile all 32 banks once
+  float* sE = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
     const int ml = (wm * MF + j) * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 y4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * q + e];
+        *reinterpret_cast<f32x4*>(sE + (size_t)ml * ES + (wn * NF + i) * 32 + 8 * q + 4 * khalf) = y4;
+      }
+  }
+  __syncthreads();
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* res = reinterpret_cast<const T*>(p.res);
+  constexpr int G4 = BN / 4;            // 4-channel groups per pixel
+  constexpr int EI = BM * G4 / 256;     // items per thread
+  using V4 = decltype(Vec4<T>().v);
+  // all residual loads are issued first (clamped addresses, no per-item branches), then combined and stored:
+  // a load->wait->store chain per item would cost one memory latency per item
+  long eoff[EI];
+  V4 rres[EI];
+#pragma unroll
+  for (int it = 0; it < EI; ++it) {
+    const int idx = tid + it * 256;
+    const int ml = idx / G4, c4 = idx % G4;
     const int th = (int)(((float)ml + 0.5f) * inv_TW);
     const int tw = ml - th * TW;
     const int h = h0 + th, w = w0 + tw;
-    if (ml >= MT || h >= p.H || w >= p.W) continue;
-    const size_t pix = (((size_t)b * p.H + h) * p.W + w) * p.Cout + (size_t)g * p.Ng;
+    const int n = n0 + c4 * 4;
+    const bool ok = ml < MT && h < p.H && w < p.W && n < p.Ng;
+    eoff[it] = ok ? (long)((((size_t)b * p.H + h) * p.W + w) * p.Cout + (size_t)g * p.Ng + n) : -1;
+  }
+  if (p.epilogue == DDX_EPI_MPSUM) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
+    for (int it = 0; it < EI; ++it) rres[it] = *reinterpret_cast<const V4*>(res + (eoff[it] < 0 ? 0 : eoff[it]));
+  }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + (wn * NF + i) * 32 + 8 * q + 4 * khalf;
-        if (n >= p.Ng) continue;
-        float y[4];
+  for (int it = 0; it < EI; ++it) {
+    const int idx = tid + it * 256;
+    const int ml = idx / G4, c4 = idx % G4;
+    const f32x4 y4 = *reinterpret_cast<const f32x4*>(sE + (size_t)ml * ES + c4 * 4);
+    float y[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = acc[i][j][4 * q + e];
-        if (p.epilogue == DDX_EPI_MPSUM) {
-          Vec4<T> rv;
-          rv.v = *reinterpret_cast<const decltype(rv.v)*>(res + pix + n);
+    for (int e = 0; e < 4; ++e) y[e] = y4[e];
+    if (p.epilogue == DDX_EPI_MPSUM) {
+      Vec4<T> rv;
+      rv.v = rres[it];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = rv.get(e) * p.res_a + y[e] * p.res_b;
-        }
-        if (p.clip > 0.f) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
-        }
-        Vec4<T> ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov.set(e, y[e]);
-        *reinterpret_cast<decltype(ov.v)*>(out + pix + n) = ov.v;
-      }
+      for (int e = 0; e < 4; ++e) y[e] = rv.get(e) * p.res_a + y[e] * p.res_b;
     }
+    if (p.clip > 0.f) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
+    }
+    Vec4<T> ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov.set(e, y[e]);
+    if (eoff[it] >= 0) *reinterpret_cast<V4*>(out + eoff[it]) = ov.v;
   }
 }
 
 // ------------------------------------------------------------------------------------------- host side
-
-struct TileCfg { int WM, WN, MF, NF; };
 
 static inline int elem_vec(int dtype) { return dtype == DDX_BF16 ? 8 : 4; }
 
@@ -237,7 +405,9 @@ bool conv_mfma_supported(const ConvParams& p, int ksize, int dtype) {
   if (p.Cg % ev) return false;
   if (p.Ng % 4 || p.Cout % 4) return false;
   if ((p.prologue & DDX_PRO_SCALE) && (p.Cin % 4)) return false;
-  if (p.CK != 32 && p.CK != 64) return false;
+  if (p.CK != 32 && p.CK != 64 && p.CK != 128) return false;
+  if (ksize == 3 && (p.CK != 32 || p.resample == DDX_RESAMPLE_DOWN)) return false;
+  if ((size_t)p.B * p.sH * p.sW >= (size_t)1 << 31) return false;
   return true;
 }
 
@@ -250,7 +420,9 @@ static void best_tile(int H, int W, int BM, int pad, int max_rows, int* TH, int*
       const int rows = (th + 2 * pad) * (tw + 2 * pad);
       if (rows > max_rows) continue;
       const long tiles = (long)ceil_div(H, th) * ceil_div(W, tw);
-      const double u = (double)H * W / ((double)tiles * BM);
+      // a 32-lane activation fragment that stays inside one tile row reads 32 consecutive LDS rows (bank-conflict
+      // free with the 16-byte row padding); fragments that wrap tile rows are ~2-way conflicted: small penalty
+      const double u = (double)H * W / ((double)tiles * BM) * ((tw % 32 == 0 || pad == 0) ? 1.0 : 0.9);
       const double halo = (double)rows / (th * tw);
       if (u > best + 1e-9 || (u > best - 1e-9 && halo < best_halo)) { best = u; best_halo = halo; bth = th; btw = tw; }
     }
@@ -268,16 +440,17 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
   Choice best{}; double best_score = -1;
   for (int bi = 0; bi < 2; ++bi) {
     const int BM = bms[bi];
-    const int bns256[3] = {96, 64, 32};
+    const int bns256[2] = {64, 32};
     const int bns128[1] = {64};
     const int* bns = BM == 256 ? bns256 : bns128;
-    const int nb = BM == 256 ? 3 : 1;
+    const int nb = BM == 256 ? 2 : 1;
     for (int ni = 0; ni < nb; ++ni) {
       const int BN = bns[ni];
       int TH, TW; double um;
-      best_tile(p.H, p.W, BM, pad, 400, &TH, &TW, &um);
+      best_tile(p.H, p.W, BM, pad, arows_max(ksize, BM), &TH, &TW, &um);
       const int rows = (TH + 2 * pad) * (TW + 2 * pad);
-      const size_t smem = ((size_t)rows + (size_t)taps * BN) * stride * es;
+      size_t smem = ((size_t)rows + (size_t)taps * BN) * stride * es;
+      smem = std::max(smem, (size_t)BM * (BN + 4) * sizeof(float));  // epilogue transpose buffer
       if (smem > 160 * 1024) continue;
       const double un = (double)p.Ng / round_up(p.Ng, BN);
       // efficiency prior: wider N tiles amortise LDS reads; two workgroups per CU hide the staging
@@ -300,9 +473,9 @@ void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype) {
   p.inv_TWP = 1.0f / (float)(c.TW + 2 * pad);
 }
 
-template <typename T, int KS, int CK, int WM, int WN, int MF, int NF>
-static int launch_cfg(const ConvParams& p, size_t smem, hipStream_t s) {
-  auto kern = conv_mfma_kernel<T, KS, CK, WM, WN, MF, NF>;
+template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, bool DN>
+static int launch_cfg2(const ConvParams& p, size_t smem, hipStream_t s) {
+  auto kern = conv_mfma_kernel<T, KS, CK, WM, WN, MF, NF, DN>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -315,9 +488,16 @@ static int launch_cfg(const ConvParams& p, size_t smem, hipStream_t s) {
   return check_launch("conv_mfma");
 }
 
+template <typename T, int KS, int CK, int WM, int WN, int MF, int NF>
+static int launch_cfg(const ConvParams& p, size_t smem, hipStream_t s) {
+  if constexpr (KS == 1) {
+    if (p.resample == DDX_RESAMPLE_DOWN) return launch_cfg2<T, KS, CK, WM, WN, MF, NF, true>(p, smem, s);
+  }
+  return launch_cfg2<T, KS, CK, WM, WN, MF, NF, false>(p, smem, s);
+}
+
 template <typename T, int KS, int CK>
 static int launch_ks(const ConvParams& p, const Choice& c, hipStream_t s) {
-  if (c.BM == 256 && c.BN == 96) return launch_cfg<T, KS, CK, 4, 1, 2, 3>(p, c.smem, s);
   if (c.BM == 256 && c.BN == 64) return launch_cfg<T, KS, CK, 4, 1, 2, 2>(p, c.smem, s);
   if (c.BM == 256 && c.BN == 32) return launch_cfg<T, KS, CK, 4, 1, 2, 1>(p, c.smem, s);
   if (c.BM == 128 && c.BN == 64) return launch_cfg<T, KS, CK, 2, 2, 2, 1>(p, c.smem, s);
@@ -327,6 +507,7 @@ static int launch_ks(const ConvParams& p, const Choice& c, hipStream_t s) {
 template <typename T>
 static int launch_t(const ConvParams& p, int ksize, const Choice& c, hipStream_t s) {
   if (ksize == 3 && p.CK == 32) return launch_ks<T, 3, 32>(p, c, s);
+  if (ksize == 1 && p.CK == 128) return launch_ks<T, 1, 128>(p, c, s);
   if (ksize == 1 && p.CK == 64) return launch_ks<T, 1, 64>(p, c, s);
   if (ksize == 1 && p.CK == 32) return launch_ks<T, 1, 32>(p, c, s);
   return set_error(DDX_ERR_UNSUPPORTED, "conv_mfma: ksize/CK combination not built");
@@ -334,6 +515,8 @@ static int launch_t(const ConvParams& p, int ksize, const Choice& c, hipStream_t
 
 int launch_conv_mfma(const ConvParams& p_in, int ksize, int dtype, hipStream_t s) {
   ConvParams p = p_in;
+  static const int dbg = getenv("DDX_CONV_DEBUG") ? atoi(getenv("DDX_CONV_DEBUG")) : 0;
+  p.debug = dbg;
   const Choice c = choose(p, ksize, dtype);
   if (c.BM == 0) return set_error(DDX_ERR_UNSUPPORTED, "conv_mfma: no tile fits LDS");
   conv_mfma_plan_tiles(p, ksize, dtype);

@@ -170,35 +170,62 @@ __global__ void mpsum_rows_kernel(const float* __restrict__ a, int a_rows, const
 template <typename TW_>
 __global__ __launch_bounds__(256) void linear_small_kernel(const ddx_linear_job* __restrict__ jobs, const float* __restrict__ x,
                                                            int x_stride, int M, float eps) {
+  // 16 lanes per output row (16 rows per workgroup), 16-byte weight loads when K allows
+  constexpr int EV = 16 / (int)sizeof(TW_);
   const ddx_linear_job jb = jobs[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (o >= jb.O) return;
-  const TW_* wr = reinterpret_cast<const TW_*>(jb.w) + (size_t)o * jb.K;
+  const int sub = threadIdx.x & 15;
+  const int o = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool active = o < jb.O;
+  const int oc = active ? o : 0;
+  const TW_* wr = reinterpret_cast<const TW_*>(jb.w) + (size_t)oc * jb.K;
   const int og = jb.O / jb.groups;
-  const float* xg = x + (size_t)(o / og) * jb.K;  // grouped: channel block of this output row
+  const float* xg = x + (size_t)(oc / og) * jb.K;  // grouped: channel block of this output row
   constexpr int MB = 8;
+  const bool vec = (jb.K % EV) == 0 && (x_stride % 4) == 0;
   for (int m0 = 0; m0 < M; m0 += MB) {
     float acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
     float ss = 0.f;
-    for (int k = lane; k < jb.K; k += 64) {
-      const float wv = to_f32<TW_>(wr[k]);
-      ss += wv * wv;
+    if (vec) {
+      for (int k = sub * EV; k < jb.K; k += 16 * EV) {
+        Vec16<TW_> wv;
+        wv.v = *reinterpret_cast<const decltype(wv.v)*>(wr + k);
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
-        if (m0 + m < M) acc[m] += wv * xg[(size_t)(m0 + m) * x_stride + k];
+        for (int e = 0; e < EV; ++e) { const float f = wv.get(e); ss += f * f; }
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          if (m0 + m < M) {
+            const float* xp = xg + (size_t)(m0 + m) * x_stride + k;
+#pragma unroll
+            for (int e = 0; e < EV; e += 4) {
+              const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp + e);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[m] += wv.get(e + q) * x4[q];
+            }
+          }
+      }
+    } else {
+      for (int k = sub; k < jb.K; k += 16) {
+        const float wv = to_f32<TW_>(wr[k]);
+        ss += wv * wv;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          if (m0 + m < M) acc[m] += wv * xg[(size_t)(m0 + m) * x_stride + k];
+      }
     }
-    ss = wave_sum(ss);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     float sc = jb.gain;
     if (jb.gain_ptr) sc *= *jb.gain_ptr;
     sc *= rsqrtf((float)jb.K);
     if (jb.normalize) sc /= (eps + sqrtf(ss) * rsqrtf((float)jb.K));
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-      const float r = wave_sum(acc[m]);
-      if (lane == 0 && m0 + m < M) jb.out[(size_t)(m0 + m) * jb.O + o] = r * sc + jb.add_const;
+      float r = acc[m];
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+      if (active && sub == 0 && m0 + m < M) jb.out[(size_t)(m0 + m) * jb.O + o] = r * sc + jb.add_const;
     }
   }
 }
@@ -218,7 +245,7 @@ extern "C" int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C
     else
       hipLaunchKernelGGL(pixelnorm_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, rows, C, eps);
     return check_launch("pixelnorm");
-  }, stream);
+  }, stream, "pixelnorm", 0.0, 2.0 * (double)rows * C * (double)dtype_size(dtype));
 }
 
 extern "C" int ddx_unet_input_prep(const float* x_nchw, const float* sigma, const float* ln_freq_h, void* out_nhwc, int32_t B,
@@ -291,11 +318,11 @@ extern "C" int ddx_linear_small_batched(const ddx_linear_job* jobs_dev, int32_t 
                                         int32_t M, int32_t w_dtype, ddx_stream stream) {
   if (!jobs_dev || njobs <= 0 || max_O <= 0 || !x || M <= 0) return set_error(DDX_ERR_ARG, "linear_small: bad args");
   return dispatch([=](hipStream_t s) -> int {
-    dim3 grid((max_O + 3) / 4, njobs);
+    dim3 grid((max_O + 15) / 16, njobs);
     if (w_dtype == DDX_BF16)
       hipLaunchKernelGGL(linear_small_kernel<bf16>, grid, dim3(256), 0, s, jobs_dev, x, x_stride, M, 1e-4f);
     else
       hipLaunchKernelGGL(linear_small_kernel<float>, grid, dim3(256), 0, s, jobs_dev, x, x_stride, M, 1e-4f);
     return check_launch("linear_small");
-  }, stream);
+  }, stream, "linear_small");
 }

@@ -9,8 +9,11 @@
 
 #include "common.hpp"
 
+struct ddx_op_meta { const char* tag; double flops, bytes; };
+
 struct ddx_plan {
   std::vector<ddx::LaunchFn> ops;
+  std::vector<ddx_op_meta> meta;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   bool recording = false;
@@ -35,9 +38,10 @@ int check_launch(const char* what) {
   return DDX_OK;
 }
 
-int dispatch(LaunchFn&& fn, ddx_stream stream) {
+int dispatch(LaunchFn&& fn, ddx_stream stream, const char* tag, double flops, double bytes) {
   if (g_recording) {
     g_recording->ops.emplace_back(std::move(fn));
+    g_recording->meta.push_back(ddx_op_meta{tag, flops, bytes});
     return DDX_OK;
   }
   return fn(reinterpret_cast<hipStream_t>(stream));
@@ -78,8 +82,8 @@ extern "C" int ddx_plan_run(ddx_plan* p, ddx_stream stream) {
 extern "C" int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream) {
   if (!p || p->recording) return ddx::set_error(DDX_ERR_ARG, "plan_graph_build: bad plan");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
-  if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+  if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
     return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipStreamBeginCapture");
   int rc = DDX_OK;
@@ -89,11 +93,11 @@ extern "C" int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream) {
   }
   hipGraph_t g = nullptr;
   const hipError_t e = hipStreamEndCapture(s, &g);
-  if (rc != DDX_OK) { if (g) hipGraphDestroy(g); return rc; }
+  if (rc != DDX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess || !g) return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipStreamEndCapture");
   hipGraphExec_t ex = nullptr;
   if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipGraphInstantiate");
   }
   p->graph = g;
@@ -108,10 +112,47 @@ extern "C" int ddx_plan_graph_launch(ddx_plan* p, ddx_stream stream) {
   return DDX_OK;
 }
 
+extern "C" int ddx_plan_op_info(const ddx_plan* p, int i, const char** tag, double* flops, double* bytes) {
+  if (!p || i < 0 || i >= (int)p->ops.size()) return ddx::set_error(DDX_ERR_ARG, "plan_op_info: bad index");
+  if (tag) *tag = p->meta[i].tag;
+  if (flops) *flops = p->meta[i].flops;
+  if (bytes) *bytes = p->meta[i].bytes;
+  return DDX_OK;
+}
+
+// Eager replay with a hipEvent pair around every op, on the launch stream; ms_out[i] = mean milliseconds of op i.
+extern "C" int ddx_plan_profile(ddx_plan* p, ddx_stream stream, int reps, float* ms_out) {
+  if (!p || p->recording || reps <= 0 || !ms_out) return ddx::set_error(DDX_ERR_ARG, "plan_profile: bad args");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = p->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return ddx::set_error(DDX_ERR_LAUNCH, "plan_profile: hipEventCreate");
+  for (size_t i = 0; i < n; ++i) ms_out[i] = 0.f;
+  int rc = DDX_OK;
+  for (int r = 0; r < reps && rc == DDX_OK; ++r) {
+    (void)hipEventRecord(ev[0], s);
+    for (size_t i = 0; i < n; ++i) {
+      rc = p->ops[i](s);
+      if (rc != DDX_OK) break;
+      (void)hipEventRecord(ev[i + 1], s);
+    }
+    if (rc != DDX_OK) break;
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = ddx::set_error(DDX_ERR_LAUNCH, "plan_profile: sync"); break; }
+    for (size_t i = 0; i < n; ++i) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      ms_out[i] += ms / (float)reps;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
 extern "C" void ddx_plan_destroy(ddx_plan* p) {
   if (!p) return;
   if (ddx::g_recording == p) ddx::g_recording = nullptr;
-  if (p->exec) hipGraphExecDestroy(p->exec);
-  if (p->graph) hipGraphDestroy(p->graph);
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
   delete p;
 }

@@ -443,7 +443,9 @@ class _UNetEngine:
             if not self.fplan.has_graph:
                 self.fplan.run()                     # warm-up outside capture (function attributes, lazy module load)
                 torch.cuda.current_stream().synchronize()
-                self.fplan.graph_build()
+                cap = torch.cuda.Stream(device=self.dev)   # the legacy default stream cannot be captured
+                self.fplan.graph_build(cap.cuda_stream)
+                cap.synchronize()
             self.fplan.graph_launch()
         else:
             self.fplan.run()

@@ -170,6 +170,9 @@ int ddx_plan_num_ops(const ddx_plan* p);
 int ddx_plan_run(ddx_plan* p, ddx_stream stream);            /* eager replay */
 int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream);    /* capture into a hipGraphExec */
 int ddx_plan_graph_launch(ddx_plan* p, ddx_stream stream);
+/* per-op metadata (kernel family tag, algorithmic flops and bytes) and a hipEvent-timed eager replay */
+int ddx_plan_op_info(const ddx_plan* p, int i, const char** tag, double* flops, double* bytes);
+int ddx_plan_profile(ddx_plan* p, ddx_stream stream, int reps, float* ms_out);
 void ddx_plan_destroy(ddx_plan* p);
 
 #ifdef __cplusplus

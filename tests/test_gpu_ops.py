@@ -189,10 +189,11 @@ def test_small_linear_and_fourier():
         ops.mpfourier(x, t[f"mpfourier{ch}.freqs"].cuda(), t[f"mpfourier{ch}.phases"].cuda(), out, False)
         assert rel_l2(out, t[f"mpfourier{ch}.out"]) < 2e-6
     w, x, gain = t["mpconv.lin.w"], t["mpconv.lin.x"], t["mpconv.lin.gain"]
+    wd, xd, gd = w.cuda(), x.cuda(), gain.cuda().reshape(1)   # the job table stores raw pointers: keep these alive
     for mode in ("eval", "train"):
         out = torch.empty(x.shape[0], w.shape[0], device=dev)
-        tab = ops.make_linear_jobs([(w.cuda(), gain.cuda().reshape(1), out, 1.0, 0.0, 1, mode == "train")], dev)
-        ops.linear_small(tab, 1, w.shape[0], x.cuda(), x.shape[0], torch.float32)
+        tab = ops.make_linear_jobs([(wd, gd, out, 1.0, 0.0, 1, mode == "train")], dev)
+        ops.linear_small(tab, 1, w.shape[0], xd, x.shape[0], torch.float32)
         assert rel_l2(out, t[f"mpconv.lin.{mode}.out_gain"]) < 2e-6, mode
     # grouped (emb_linear: groups = 8) with the "+1"
     g = torch.Generator().manual_seed(3)
@@ -200,8 +201,9 @@ def test_small_linear_and_fourier():
     e = torch.randn(5, 96, generator=g)
     ref = O.conv_mp(e[:, :, None, None], wg, gain=0.7, groups=8)[:, :, 0, 0] + 1.0
     out = torch.empty(5, 64, device=dev)
-    tab = ops.make_linear_jobs([(wg.cuda(), None, out, 0.7, 1.0, 8, False)], dev)
-    ops.linear_small(tab, 1, 64, e.cuda(), 5, torch.float32)
+    wgd, ed = wg.cuda(), e.cuda()
+    tab = ops.make_linear_jobs([(wgd, None, out, 0.7, 1.0, 8, False)], dev)
+    ops.linear_small(tab, 1, 64, ed, 5, torch.float32)
     assert rel_l2(out, ref) < 2e-6
     # mp_sum rows (+silu)
     a, b = torch.randn(5, 96, generator=g), torch.randn(5, 96, generator=g)

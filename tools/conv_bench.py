@@ -1,0 +1,78 @@
+"""Micro-benchmark of single conv layers of the default UNet through the C ABI (GPU box only).
+
+    python tools/conv_bench.py [--cases name,name] [--iters 50] [--dtype bf16]
+
+Used to iterate on conv_mfma.hip and as the target command for rocprofv3 --pmc runs.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dualdiffusion_amd import _lib as L  # noqa: E402
+from dualdiffusion_amd import ops  # noqa: E402
+
+# name: (B, H, W, C0, C1, Cout, groups, ksize, resample, prologue, residual)
+CASES = {
+    "L0_res0_enc": (4, 32, 688, 256, 0, 512, 8, 3, 0, L.PRO_SILU, False),
+    "L0_res1_enc": (4, 32, 688, 512, 0, 256, 8, 3, 0, L.PRO_SCALE_SILU, True),
+    "L0_up_res0": (4, 32, 688, 512, 0, 1024, 8, 3, 1, L.PRO_SILU, False),
+    "L0_up_res1": (4, 32, 688, 1024, 0, 512, 8, 3, 0, L.PRO_SCALE_SILU, True),
+    "L0_up_res1_raw": (4, 32, 688, 1024, 0, 512, 8, 3, 0, L.PRO_NONE, True),
+    "L0_res0_enc_raw": (4, 32, 688, 256, 0, 512, 8, 3, 0, L.PRO_NONE, False),
+    "L1_res1_raw": (4, 16, 344, 1024, 0, 512, 8, 3, 0, L.PRO_NONE, True),
+    "L0_skip_512_raw": (4, 32, 688, 512, 0, 512, 1, 1, 0, L.PRO_NONE, False),
+    "L0_skip_512": (4, 32, 688, 512, 0, 512, 1, 1, 1, L.PRO_NONE, False),
+    "L0_skip_cat": (4, 32, 688, 512, 256, 256, 1, 1, 0, L.PRO_NONE, False),
+    "L1_res0_dec": (4, 16, 344, 768, 512, 1024, 8, 3, 0, L.PRO_SILU, False),
+    "L1_res1": (4, 16, 344, 1024, 0, 512, 8, 3, 0, L.PRO_SCALE_SILU, True),
+    "L2_res0": (4, 8, 172, 768, 0, 1536, 8, 3, 0, L.PRO_SILU, False),
+    "L3_res0": (4, 4, 86, 1024, 0, 2048, 8, 3, 0, L.PRO_SILU, False),
+    "L4_res0": (4, 2, 43, 1280, 0, 2560, 8, 3, 0, L.PRO_SILU, False),
+    "L4_qk": (4, 2, 43, 1280, 0, 2560, 1, 1, 0, L.PRO_SCALE, False),
+    "L4_proj": (4, 2, 43, 1280, 0, 1280, 1, 1, 0, L.PRO_SCALE_SILU, True),
+    "L3_qk": (4, 4, 86, 1024, 0, 2048, 1, 1, 0, L.PRO_SCALE, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = "cuda"
+    for name in a.cases.split(","):
+        B, H, W, C0, C1, Cout, G, ks, rs, pro, has_res = CASES[name]
+        sh, sw = (H // 2, W // 2) if rs == 1 else ((H * 2, W * 2) if rs == 2 else (H, W))
+        a0 = torch.randn(B, sh, sw, C0, device=dev).to(dt)
+        a1 = torch.randn(B, sh, sw, C1, device=dev).to(dt) if C1 else None
+        w = torch.randn(Cout, (C0 + C1) // G, ks, ks, device=dev)
+        cs = torch.rand(B, C0 + C1, device=dev) + 0.5
+        res = torch.randn(B, H, W, Cout, device=dev).to(dt) if has_res else None
+        out = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
+        pw = ops.wprep(w, G, dt)
+        raw = name.endswith('_raw')
+        kw = dict(out_hw=(H, W), src1=a1, scale0=1.0 if raw else 0.8, scale1=1.0 if raw else 1.1, resample=rs, prologue=pro,
+                  chan_scale=cs if pro & L.PRO_SCALE else None, residual=res, res_t=0.3, clip=256.0, out=out)
+        for _ in range(3):
+            ops.conv2d(a0, pw, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            ops.conv2d(a0, pw, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / a.iters * 1e3
+        fl = 2.0 * B * H * W * Cout * ((C0 + C1) // G) * ks * ks
+        by = (a0.numel() + (a1.numel() if C1 else 0) + out.numel() * (2 if has_res else 1)) * a0.element_size()
+        print(f"{name:14s} {us:9.1f} us  {fl / 1e9:8.2f} GFLOP  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:8.1f} GB/s (algorithmic)")
+
+
+if __name__ == "__main__":
+    main()
