@@ -93,17 +93,13 @@ def main() -> None:
     ap.add_argument("--layer-table", action="store_true", help="print the per-op hipEvent profile (rank 0)")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from dualdiffusion_amd import distributed as D
+    rank, world, local_rank = D.world()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    D.init(backend="nccl", device=dev)   # no-op for a single process; "nccl" is RCCL on ROCm
 
     from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
 
@@ -125,27 +121,22 @@ def main() -> None:
         for _ in range(a.warmup):
             out = unet(x, sigma, fmt, emb)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             out = unet(x, sigma, fmt, emb)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     assert torch.isfinite(out).all(), "non-finite UNet output"
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    total_steps, elapsed = D.replica_throughput(a.steps, elapsed)   # steps summed over ranks, time = max over ranks
 
     line = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        value = world * a.steps / elapsed
+        value = total_steps / elapsed
         # ---- roofline of the dominant kernel family, measured live with hipEvents on the launch stream
         eng = next(iter(unet._engines.values()))
         prof = eng.fplan.profile(reps=3)
@@ -177,7 +168,8 @@ def main() -> None:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(unet, (20.0, 16000.0))
     if world > 1:
-        dist.barrier()
+        import torch.distributed as dist
+        D.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line))

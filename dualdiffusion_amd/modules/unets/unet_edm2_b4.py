@@ -93,6 +93,8 @@ class BlockWeights(torch.nn.Module):
 
 class UNet(DualDiffusionUNet):
 
+    config_class = UNetConfig
+
     def __init__(self, config: UNetConfig) -> None:
         super().__init__()
         self.config = config

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ddx_hip.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ddx_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_entry_points():
+    syms = _declared_symbols()
+    for must in ("ddx_mpconv2d_fwd", "ddx_mpconv_wprep", "ddx_attn_fwd", "ddx_pixelnorm_fwd", "ddx_plan_begin", "ddx_plan_graph_launch"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from dualdiffusion_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        pytest.skip("libddx_hip.so not built (run `make` or __graft_entry__.build())")
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in _declared_symbols() if not hasattr(handle, s)]
+    assert not missing, f"declared in ddx_hip.h but not exported: {missing}"
+    # and the ctypes prototype table covers the whole header
+    unbound = [s for s in _declared_symbols() if s not in _lib.PROTOTYPES]
+    assert not unbound, f"no ctypes prototype for: {unbound}"
+    assert _lib.lib().ddx_version().decode().startswith("libddx_hip")
+
+
+def test_descriptor_struct_layout_matches_header():
+    """ctypes mirrors of the C descriptors: sizes follow from the field lists in the header (LP64)."""
+    from dualdiffusion_amd import _lib
+    assert ctypes.sizeof(_lib.WPrepDesc) == 3 * 8 + 4 + 9 * 4  # 3 pointers, float, 9 int32
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 12 * 4 + 4 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.LinearJob) == 3 * 8 + 2 * 4 + 4 * 4
+    lib = _lib.lib() if os.path.isfile(_lib.LIB_PATH) else None
+    if lib is not None:
+        # wprep byte count: groups * ceil(Cg/CK) * taps * roundup(Ng,32) * CK * sizeof
+        assert lib.ddx_wprep_bytes(512, 32, 3, 8, 32, _lib.DDX_BF16) == 8 * 1 * 9 * 64 * 32 * 2
+        assert lib.ddx_wprep_bytes(4, 256, 3, 1, 32, _lib.DDX_F32) == 1 * 8 * 9 * 32 * 32 * 4
+        assert lib.ddx_mpconv2d_pick_ck(32, 3, _lib.DDX_BF16) == 32
+        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_BF16) == 128
+        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_F32) == 64
+
+
+def test_null_descriptor_is_rejected_without_a_gpu():
+    from dualdiffusion_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    lib = _lib.lib()
+    assert lib.ddx_mpconv2d_fwd(None, None) == -1      # DDX_ERR_ARG, no launch attempted
+    assert b"null" in lib.ddx_last_error()
+    d = _lib.ConvDesc()
+    assert lib.ddx_mpconv2d_fwd(ctypes.byref(d), None) == -1

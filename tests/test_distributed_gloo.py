@@ -1,0 +1,58 @@
+"""CPU, world_size 2, gloo: the N > 1 helpers used by bench.py (replica aggregation) and by the data-parallel step
+(sigma broadcast, strided slices, fused scalar gather)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank: int, ws: int, port: int, out_dir: str):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dualdiffusion_amd import distributed as D
+    assert D.init(backend="gloo")
+    assert D.world() == (rank, ws, rank)
+    # replicas: rank r did 10 steps in (1 + r) seconds -> whole job = 20 steps in max = 2 s
+    units, secs = D.replica_throughput(10, 1.0 + rank)
+    assert units == 20.0 and secs == 2.0
+    # sigma for the global batch comes from rank 0 only
+    g = torch.Generator().manual_seed(100 + rank)
+    sigma = torch.rand(8, generator=g)
+    ref0 = torch.rand(8, generator=torch.Generator().manual_seed(100))
+    D.broadcast_from_rank0(sigma)
+    assert torch.equal(sigma, ref0)
+    # strided slices partition the global batch without overlap, two micro-steps of 2 samples per rank
+    mine = torch.cat([D.strided_slice(sigma, rank, ws, a, 2) for a in range(2)])
+    assert torch.equal(mine, ref0[rank::ws])
+    # one fused gather of two per-sample columns
+    loss = torch.arange(2, dtype=torch.float32) + 10 * rank
+    sig = torch.arange(2, dtype=torch.float32) + 100 * rank
+    gl, gs = D.gather_scalars([loss, sig])
+    assert gl.tolist() == [0.0, 1.0, 10.0, 11.0] and gs.tolist() == [0.0, 1.0, 100.0, 101.0]
+    D.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_world_size_2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.isfile(tmp_path / "ok0") and os.path.isfile(tmp_path / "ok1")
+
+
+def test_single_process_fallbacks():
+    from dualdiffusion_amd import distributed as D
+    assert D.replica_throughput(7, 0.5) == (7.0, 0.5)
+    x = torch.arange(4.0)
+    assert torch.equal(D.broadcast_from_rank0(x.clone()), x)
+    a, b = D.gather_scalars([x, x + 1])
+    assert torch.equal(a, x) and torch.equal(b, x + 1)

@@ -1,0 +1,92 @@
+"""CPU: host-side logic of the drop-in modules (no kernels run): state-dict layout, config handling, frequency tables,
+loud failure without a device."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import edm2_oracle as O
+
+
+def test_unet_state_dict_layout_matches_reference_contract():
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    for cfg in (O.unet_cfg(), O.unet_cfg(model_channels=32, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=32,
+                                         channel_mult_noise=1, channel_mult_emb=2)):
+        u = UNet(UNetConfig(**cfg))
+        got = {k: tuple(v.shape) for k, v in u.state_dict().items()}
+        assert got == {k: tuple(v) for k, v in O.unet_param_shapes(cfg).items()}
+        # gains are zero-initialised, weights carry conv_groups (reference mp_tools.py:346-347)
+        assert float(u.out_gain) == 0.0 and u.enc["block0_layer0"].conv_res0.weight.conv_groups == cfg["mlp_groups"]
+        assert u.get_latent_shape((2, 4, 37, 70)) == O.unet_latent_shape(cfg, (2, 4, 37, 70))
+
+
+def test_default_unet_parameter_count():
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    cfg = O.unet_cfg(channel_mult_noise=1, channel_mult_emb=3)     # config/models/default/unet.json
+    n = sum(p.numel() for p in UNet(UNetConfig(**cfg)).parameters())
+    assert abs(n - 293.1e6) < 0.1e6, n                              # 293.1 M parameters
+
+
+def test_config_roundtrip_and_unknown_keys(tmp_path):
+    from dualdiffusion_amd.modules.module import config_from_dict, load_config, save_config
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    raw = dict(O.unet_cfg(channel_mult_noise=1, channel_mult_emb=3), use_t_ranges=False, inpainting=False, label_dim=1612)
+    raw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in raw.items()}
+    cfg = config_from_dict(UNetConfig, raw)                         # stale keys of the shipped unet.json are ignored
+    assert cfg.model_channels == 256 and cfg.channel_mult_emb == 3 and not hasattr(cfg, "label_dim")
+    p = tmp_path / "unet" / "unet.json"
+    save_config(cfg, str(p))
+    assert load_config(UNetConfig, str(p)) == cfg
+    # from_pretrained / save_pretrained with {name}.json + {name}.safetensors (reference module.py:59-99)
+    tiny = UNetConfig(**O.unet_cfg(model_channels=32, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=32,
+                                   channel_mult_noise=1, channel_mult_emb=2))
+    u = UNet(tiny)
+    u.save_pretrained(str(tmp_path / "model" / "unet"))
+    assert os.path.isfile(tmp_path / "model" / "unet" / "unet.safetensors")
+    u2 = UNet.from_pretrained(str(tmp_path / "model"), subfolder="unet")
+    for k, v in u.state_dict().items():
+        assert torch.equal(v, u2.state_dict()[k])
+    assert not u2.training and not any(p.requires_grad for p in u2.parameters())
+
+
+def test_half_means_bfloat16_and_no_cpu_forward():
+    from dualdiffusion_amd._lib import DDXError
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    u = UNet(UNetConfig(**O.unet_cfg(model_channels=32, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=32,
+                                     channel_mult_noise=1, channel_mult_emb=2))).half()
+    assert u.dtype == torch.bfloat16 and u.conv_out.weight.dtype == torch.bfloat16
+    with pytest.raises(DDXError):                                    # product path must fail loudly off-device
+        u(torch.zeros(1, 4, 16, 16), torch.ones(1), None, torch.zeros(1, 64))
+    with pytest.raises(DDXError):
+        u.normalize_weights()
+
+
+def test_frequency_scale_tables():
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    fs = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+    # same points as the oracle's restatement of the reference (frequency_scale.py:144-149)
+    assert torch.equal(fs.get_unscaled(34), O.mel_points_hz(34, 20.0, 16000.0))
+    fb = fs.filters
+    assert fb.shape == (3201, 256) and float(fb.min()) == 0.0
+    edges = fs.band_edges()
+    # SURVEY.md 8 a-11 (probed on the reference): 6349 non-zeros, every band contiguous, first bands (5,7),(6,9),(8,11), last (3120,3199)
+    assert int((fb > 0).sum()) == 6349
+    assert edges[:3].tolist() == [[5, 7], [6, 9], [8, 11]] and edges[-1].tolist() == [3120, 3199]
+    width = edges[:, 1] - edges[:, 0] + 1
+    assert int(width.min()) == 3 and int(width.max()) == 80
+    nz_per_filter = (fb > 0).sum(dim=0)
+    assert torch.equal(nz_per_filter, width.to(nz_per_filter.dtype))   # contiguous support
+
+
+def test_ln_freq_rows_match_oracle():
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+
+    class Fmt:
+        ms_freq_scale = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+    u = UNet(UNetConfig(**O.unet_cfg(model_channels=32, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=32,
+                                     channel_mult_noise=1, channel_mult_emb=2)))
+    rows = u.get_ln_freqs_rows(Fmt(), 3, 32, 20)
+    ref = O.ln_freq_channel(32, 20, 3, 20.0, 16000.0)
+    assert torch.equal(rows, ref[0, 0, :, 0])
