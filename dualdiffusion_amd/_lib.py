@@ -57,7 +57,7 @@ PROTOTYPES = {
     "ddx_mpconv_wprep": (C.c_int, [C.POINTER(WPrepDesc), C.c_void_p]),
     "ddx_normalize_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "ddx_mpconv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
-    "ddx_mpconv2d_pick_ck": (C.c_int32, [C.c_int32] * 3),
+    "ddx_mpconv2d_pick_ck": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "ddx_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                C.c_int32, C.c_void_p]),

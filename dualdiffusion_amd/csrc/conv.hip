@@ -63,8 +63,10 @@ extern "C" size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32
   return (size_t)groups * nchunk * ksize * ksize * NgP * CK * dtype_size(dtype);
 }
 
-extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype) {
-  if (ksize == 1 && dtype == DDX_BF16 && Cg >= 128 && Cg % 128 == 0) return 128;
+extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix) {
+  // small-M layers run split-K over 64-channel chunks; large ones amortise barriers over 128-channel chunks
+  const bool small_m = npix > 0 && npix <= 8192;
+  if (ksize == 1 && dtype == DDX_BF16 && Cg >= 128 && Cg % 128 == 0 && !small_m) return 128;
   if (ksize == 1 && Cg >= 64) return 64;
   return 32;
 }

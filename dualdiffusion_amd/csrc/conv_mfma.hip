@@ -47,9 +47,12 @@ template <> struct Mfma<float> {
 // halo rows a tile configuration may stage (bounds the per-thread register staging)
 constexpr int arows_max(int KS, int BM) { return KS == 3 ? (BM == 256 ? 352 : 208) : BM; }
 
-template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, bool DN>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
-  static_assert(WM * WN == 4, "4 waves");
+// KSP > 1: intra-workgroup split-K for small-M (latency-bound) layers.  The workgroup has KSP groups of 4 waves; group q
+// stages and multiplies chunks q, q+KSP, ... in its own LDS region, and the partial accumulators are summed through the
+// epilogue's LDS transpose buffer.  KSP x more loads in flight per CU and KSP x fewer serial K iterations.
+template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, bool DN, int KSP>
+__global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kernel(const ConvParams p) {
+  static_assert(WM * WN == 4, "4 waves per K group");
   constexpr int TAPS = KS * KS, PAD = KS / 2;
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int V = CK / EV;
@@ -65,10 +68,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* sA = reinterpret_cast<T*>(smem);
+  const int kq = (KSP == 1) ? 0 : (int)(threadIdx.x >> 8);  // K group of this wave
+  T* sA = reinterpret_cast<T*>(smem + (size_t)kq * p.group_smem);
   T* sB = sA + (size_t)p.arows_alloc * STRIDE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // tid = thread index inside the K group
   const int wm = wave / WN, wn = wave % WN;
   const int khalf = lane >> 5, l31 = lane & 31;
 
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   const T* w_src = nullptr;
   auto issue_setup = [&](int ch) {
     const int cg = ch * CK + v * EV;  // channel inside the group
-    const bool cvalid = cg < p.Cg;
+    const bool cvalid = cg < p.Cg && ch < p.nchunk;  // (split-K groups may run past the last chunk: zero operand)
     const int cabs = cvalid ? g * p.Cg + cg : 0;   // channel of the (virtually concatenated) input
     const bool first = cabs < p.C0;
     a_src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
       for (int e = 0; e < EV; ++e) cs[e] = 1.0f;
     }
-    w_src = wp + ((size_t)(g * p.nchunk + ch) * TAPS * p.NgP) * CK;
+    w_src = wp + ((size_t)(g * p.nchunk + min(ch, p.nchunk - 1)) * TAPS * p.NgP) * CK;
   };
   auto issue_a = [&](int i) {
     const T* sp = a_src + (size_t)apix[i] * a_cs + a_cc;
@@ -296,15 +300,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     }
   };
 
-  issue(0);
+  const int nit = (p.nchunk + KSP - 1) / KSP;  // K iterations of every group (same count: shared barriers)
+  issue(kq);
   commit();
   __syncthreads();
   if constexpr (PIPE) {
     // steady state: chunk ch is multiplied while chunk ch+1 is loaded (interleaved), then converted and written.
     // The last chunk is peeled so that the staged registers never meet at a control-flow join (a phi there makes
     // hipcc copy them right after the loads, i.e. wait for every load inside the matrix phase).
-    for (int ch = 0; ch + 1 < p.nchunk; ++ch) {
-      issue_setup(ch + 1);
+    for (int it = 0; it + 1 < nit; ++it) {
+      issue_setup((it + 1) * KSP + kq);
       compute(std::true_type{});
       __syncthreads();  // every wave is done reading this chunk
       pin();
@@ -313,11 +318,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     }
     compute(std::false_type{});
   } else {
-    for (int ch = 0; ch < p.nchunk; ++ch) {
+    for (int it = 0; it < nit; ++it) {
       compute(std::false_type{});
       __syncthreads();
-      if (ch + 1 < p.nchunk) {
-        issue(ch + 1);
+      if (it + 1 < nit) {
+        issue((it + 1) * KSP + kq);
         commit();
         __syncthreads();
       }
@@ -332,23 +337,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   constexpr int ES = BN + 4;  // fp32 row stride of the transpose buffer: 8 rows x (ES*4 B) tile all 32 banks once
   float* sE = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < MF; ++j) {
-    const int ml = (wm * MF + j) * 32 + l31;
+  for (int kg = 0; kg < KSP; ++kg) {  // K groups add their partial sums one after the other
+    if (kq == kg) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i)
+      for (int j = 0; j < MF; ++j) {
+        const int ml = (wm * MF + j) * 32 + l31;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 y4;
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * q + e];
-        *reinterpret_cast<f32x4*>(sE + (size_t)ml * ES + (wn * NF + i) * 32 + 8 * q + 4 * khalf) = y4;
+          for (int q = 0; q < 4; ++q) {
+            float* dst = sE + (size_t)ml * ES + (wn * NF + i) * 32 + 8 * q + 4 * khalf;
+            f32x4 y4;
+            if (kg == 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * q + e];
+            } else {
+              y4 = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y4[e] += acc[i][j][4 * q + e];
+            }
+            *reinterpret_cast<f32x4*>(dst) = y4;
+          }
       }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   T* out = reinterpret_cast<T*>(p.out);
   const T* res = reinterpret_cast<const T*>(p.res);
   constexpr int G4 = BN / 4;            // 4-channel groups per pixel
-  constexpr int EI = BM * G4 / 256;     // items per thread
+  constexpr int NT = 256 * KSP;         // all threads of the workgroup share the store phase
+  constexpr int EI = (BM * G4 + NT - 1) / NT;  // items per thread
+  const int tid_all = threadIdx.x;
   using V4 = decltype(Vec4<T>().v);
   // all residual loads are issued first (clamped addresses, no per-item branches), then combined and stored:
   // a load->wait->store chain per item would cost one memory latency per item
@@ -356,13 +375,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   V4 rres[EI];
 #pragma unroll
   for (int it = 0; it < EI; ++it) {
-    const int idx = tid + it * 256;
+    const int idx = tid_all + it * NT;
     const int ml = idx / G4, c4 = idx % G4;
     const int th = (int)(((float)ml + 0.5f) * inv_TW);
     const int tw = ml - th * TW;
     const int h = h0 + th, w = w0 + tw;
     const int n = n0 + c4 * 4;
-    const bool ok = ml < MT && h < p.H && w < p.W && n < p.Ng;
+    const bool ok = idx < BM * G4 && ml < MT && h < p.H && w < p.W && n < p.Ng;
     eoff[it] = ok ? (long)((((size_t)b * p.H + h) * p.W + w) * p.Cout + (size_t)g * p.Ng + n) : -1;
   }
   if (p.epilogue == DDX_EPI_MPSUM) {
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
   }
 #pragma unroll
   for (int it = 0; it < EI; ++it) {
-    const int idx = tid + it * 256;
+    const int idx = min(tid_all + it * NT, BM * G4 - 1);
     const int ml = idx / G4, c4 = idx % G4;
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(sE + (size_t)ml * ES + c4 * 4);
     float y[4];
@@ -430,35 +449,42 @@ static void best_tile(int H, int W, int BM, int pad, int max_rows, int* TH, int*
   *TH = bth; *TW = btw; *util = best;
 }
 
-struct Choice { int BM, BN, TH, TW; size_t smem; };
+struct Choice { int BM, BN, TH, TW, KSP; size_t smem, group_smem; };
 
+// Tile / split-K choice.  Large-M layers: BM=256 (2 workgroups per CU overlap each other).  Small-M layers (few
+// workgroups, long serial K loop): BM=128 tiles with intra-workgroup split-K so that enough loads are in flight.
 static Choice choose(const ConvParams& p, int ksize, int dtype) {
   const int pad = ksize / 2, taps = ksize * ksize;
   const size_t es = dtype_size(dtype);
   const int stride = p.CK + elem_vec(dtype);
-  const int bms[2] = {256, 128};
+  struct Cand { int BM, BN; };
+  const Cand cands[4] = {{256, 64}, {256, 32}, {128, 64}, {128, 32}};
   Choice best{}; double best_score = -1;
-  for (int bi = 0; bi < 2; ++bi) {
-    const int BM = bms[bi];
-    const int bns256[2] = {64, 32};
-    const int bns128[1] = {64};
-    const int* bns = BM == 256 ? bns256 : bns128;
-    const int nb = BM == 256 ? 2 : 1;
-    for (int ni = 0; ni < nb; ++ni) {
-      const int BN = bns[ni];
-      int TH, TW; double um;
-      best_tile(p.H, p.W, BM, pad, arows_max(ksize, BM), &TH, &TW, &um);
-      const int rows = (TH + 2 * pad) * (TW + 2 * pad);
-      size_t smem = ((size_t)rows + (size_t)taps * BN) * stride * es;
-      smem = std::max(smem, (size_t)BM * (BN + 4) * sizeof(float));  // epilogue transpose buffer
+  for (const Cand& c : cands) {
+    const int BM = c.BM, BN = c.BN;
+    int TH, TW; double um;
+    best_tile(p.H, p.W, BM, pad, arows_max(ksize, BM), &TH, &TW, &um);
+    const int rows = (TH + 2 * pad) * (TW + 2 * pad);
+    const size_t group = (((size_t)rows + (size_t)taps * BN) * stride * es + 255) / 256 * 256;
+    const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    const long wgs = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, BN) * p.G;
+    const int ksps[3] = {1, 2, 4};
+    for (int ksp : ksps) {
+      if (ksp > 1 && (BM != 128 || dtype != DDX_BF16)) continue;       // split-K variants are built for BM=128 bf16
+      if (ksp > 1 && p.resample == DDX_RESAMPLE_DOWN) continue;        // the avg-pool gather is only built for KSP=1
+      if (ksp > 1 && p.nchunk < 2 * ksp) continue;                      // needs >= 2 iterations per group to pay
+      if (ksp == 4 && (ksize == 3 || p.CK == 128)) continue;            // register budget (128 VGPRs at 1024 threads)
+      const size_t smem = std::max(group * ksp, epi);
       if (smem > 160 * 1024) continue;
       const double un = (double)p.Ng / round_up(p.Ng, BN);
-      // efficiency prior: wider N tiles amortise LDS reads; two workgroups per CU hide the staging
-      double eff = (BN == 32 ? 0.80 : 1.0) * (smem <= 80 * 1024 ? 1.0 : 0.85) * (BM == 128 ? 0.92 : 1.0);
-      const long wgs = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, BN) * p.G;
-      if (wgs < 256) eff *= (0.5 + 0.5 * (double)wgs / 256.0);
+      double eff = (BN == 32 ? 0.80 : 1.0) * (BM == 128 ? 0.92 : 1.0);
+      if (ksp == 1 && smem > 80 * 1024) eff *= 0.85;                    // one workgroup per CU: no phase overlap
+      // parallelism: waves in flight relative to what fills the chip (256 CUs x 8 waves)
+      const double fill = std::min(1.0, (double)wgs * 4 * ksp / 2048.0);
+      eff *= 0.35 + 0.65 * fill;
+      if (ksp > 1 && wgs >= 512) eff *= 0.8;                            // enough workgroups already: plain K loop
       const double score = um * un * eff;
-      if (score > best_score) { best_score = score; best = Choice{BM, BN, TH, TW, smem}; }
+      if (score > best_score) { best_score = score; best = Choice{BM, BN, TH, TW, ksp, smem, group}; }
     }
   }
   return best;
@@ -471,11 +497,12 @@ void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype) {
   p.tiles_h = ceil_div(p.H, c.TH); p.tiles_w = ceil_div(p.W, c.TW);
   p.arows_alloc = (c.TH + 2 * pad) * (c.TW + 2 * pad);
   p.inv_TWP = 1.0f / (float)(c.TW + 2 * pad);
+  p.group_smem = (int)c.group_smem;
 }
 
-template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, bool DN>
-static int launch_cfg2(const ConvParams& p, size_t smem, hipStream_t s) {
-  auto kern = conv_mfma_kernel<T, KS, CK, WM, WN, MF, NF, DN>;
+template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, bool DN, int KSP>
+static int launch_cfg3(const ConvParams& p, size_t smem, hipStream_t s) {
+  auto kern = conv_mfma_kernel<T, KS, CK, WM, WN, MF, NF, DN, KSP>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -484,23 +511,34 @@ static int launch_cfg2(const ConvParams& p, size_t smem, hipStream_t s) {
   }
   constexpr int BN = WN * NF * 32;
   dim3 grid(p.B * p.tiles_h * p.tiles_w, ceil_div(p.Ng, BN), p.G);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * KSP), smem, s, p);
   return check_launch("conv_mfma");
 }
 
-template <typename T, int KS, int CK, int WM, int WN, int MF, int NF>
+template <typename T, int KS, int CK, int WM, int WN, int MF, int NF, int KSP>
 static int launch_cfg(const ConvParams& p, size_t smem, hipStream_t s) {
-  if constexpr (KS == 1) {
-    if (p.resample == DDX_RESAMPLE_DOWN) return launch_cfg2<T, KS, CK, WM, WN, MF, NF, true>(p, smem, s);
+  if constexpr (KS == 1 && KSP == 1) {
+    if (p.resample == DDX_RESAMPLE_DOWN) return launch_cfg3<T, KS, CK, WM, WN, MF, NF, true, KSP>(p, smem, s);
   }
-  return launch_cfg2<T, KS, CK, WM, WN, MF, NF, false>(p, smem, s);
+  return launch_cfg3<T, KS, CK, WM, WN, MF, NF, false, KSP>(p, smem, s);
 }
 
 template <typename T, int KS, int CK>
 static int launch_ks(const ConvParams& p, const Choice& c, hipStream_t s) {
-  if (c.BM == 256 && c.BN == 64) return launch_cfg<T, KS, CK, 4, 1, 2, 2>(p, c.smem, s);
-  if (c.BM == 256 && c.BN == 32) return launch_cfg<T, KS, CK, 4, 1, 2, 1>(p, c.smem, s);
-  if (c.BM == 128 && c.BN == 64) return launch_cfg<T, KS, CK, 2, 2, 2, 1>(p, c.smem, s);
+  if (c.KSP == 1) {
+    if (c.BM == 256 && c.BN == 64) return launch_cfg<T, KS, CK, 4, 1, 2, 2, 1>(p, c.smem, s);
+    if (c.BM == 256 && c.BN == 32) return launch_cfg<T, KS, CK, 4, 1, 2, 1, 1>(p, c.smem, s);
+    if (c.BM == 128 && c.BN == 64) return launch_cfg<T, KS, CK, 2, 2, 2, 1, 1>(p, c.smem, s);
+    if (c.BM == 128 && c.BN == 32) return launch_cfg<T, KS, CK, 4, 1, 1, 1, 1>(p, c.smem, s);
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (c.KSP == 2 && c.BM == 128 && c.BN == 64) return launch_cfg<T, KS, CK, 2, 2, 2, 1, 2>(p, c.smem, s);
+    if (c.KSP == 2 && c.BM == 128 && c.BN == 32) return launch_cfg<T, KS, CK, 4, 1, 1, 1, 2>(p, c.smem, s);
+    if (c.KSP == 4 && c.BM == 128 && c.BN == 32) return launch_cfg<T, KS, CK, 4, 1, 1, 1, 4>(p, c.smem, s);
+    if constexpr (KS == 1) {
+      if (c.KSP == 4 && c.BM == 128 && c.BN == 64) return launch_cfg<T, KS, CK, 2, 2, 2, 1, 4>(p, c.smem, s);
+    }
+  }
   return set_error(DDX_ERR_UNSUPPORTED, "conv_mfma: no tile configuration");
 }
 
@@ -515,8 +553,6 @@ static int launch_t(const ConvParams& p, int ksize, const Choice& c, hipStream_t
 
 int launch_conv_mfma(const ConvParams& p_in, int ksize, int dtype, hipStream_t s) {
   ConvParams p = p_in;
-  static const int dbg = getenv("DDX_CONV_DEBUG") ? atoi(getenv("DDX_CONV_DEBUG")) : 0;
-  p.debug = dbg;
   const Choice c = choose(p, ksize, dtype);
   if (c.BM == 0) return set_error(DDX_ERR_UNSUPPORTED, "conv_mfma: no tile fits LDS");
   conv_mfma_plan_tiles(p, ksize, dtype);

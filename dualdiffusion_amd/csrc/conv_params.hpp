@@ -23,7 +23,7 @@ struct ConvParams {
   // spatial tiling (MFMA kernel)
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;
-  int debug;  // ablation switches for tuning (DDX_CONV_DEBUG): 1 = no global loads, 2 = no commit, 4 = no MFMA phase
+  int group_smem;  // LDS bytes of one split-K group's staging region
 };
 
 // index into the prepared weight tensor wp[g][chunk][tap][NgP][CK]

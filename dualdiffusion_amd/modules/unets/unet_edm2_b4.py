@@ -275,12 +275,12 @@ class _UNetEngine:
         self.keep.append(t)
         return t
 
-    def _prep(self, conv: MPConvWeight, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None):
+    def _prep(self, conv: MPConvWeight, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0):
         """Allocate the prepared-weight buffer and queue its wprep; returns a PreparedWeight (filled when wplan runs)."""
         w = conv.weight
         Cg = w.shape[1]
         ks = w.shape[2]
-        CK = ops.pick_ck(cg_pad or Cg, ks, self.dt)
+        CK = ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
         nbytes = ops.lib().ddx_wprep_bytes(w.shape[0], Cg, ks, conv.groups, CK, ops.dtype_code(self.dt))
         buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         self.keep.append(buf)
@@ -344,7 +344,9 @@ class _UNetEngine:
             mm = cfg.mlp_multiplier
             rs = {"keep": RESAMPLE_KEEP, "up": RESAMPLE_UP, "down": RESAMPLE_DOWN}[blk.resample_mode]
             c_emb = cvec(blk.emb_linear, blk.emb_gain)
-            pw_res0, pw_res1, pw_skip = self._prep(blk.conv_res0), self._prep(blk.conv_res1), self._prep(blk.conv_skip)
+            npix = B * h * w
+            pw_res0, pw_res1, pw_skip = (self._prep(blk.conv_res0, npix=npix), self._prep(blk.conv_res1, npix=npix),
+                                         self._prep(blk.conv_skip, npix=npix))
             y0 = self._act(h, w, cout * mm)
             xo = self._act(h, w, cout)
             last_clip = 0.0 if blk.use_attention else 256.0
@@ -366,8 +368,8 @@ class _UNetEngine:
                 return xo
             c_qk, c_v = cvec(blk.emb_linear_qk, blk.emb_gain_qk), cvec(blk.emb_linear_v, blk.emb_gain_v)
             hd = cout // blk.num_heads
-            pw_qk = self._prep(blk.attn_qk, qk_head_dim=hd)
-            pw_v, pw_proj = self._prep(blk.attn_v), self._prep(blk.attn_proj)
+            pw_qk = self._prep(blk.attn_qk, qk_head_dim=hd, npix=npix)
+            pw_v, pw_proj = self._prep(blk.attn_v, npix=npix), self._prep(blk.attn_proj, npix=npix)
             qk, vv, ao, xa = self._act(h, w, 2 * cout), self._act(h, w, cout), self._act(h, w, cout), self._act(h, w, cout)
             steps.append(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
             steps.append(lambda: ops.conv2d(xo, pw_v, out=vv))

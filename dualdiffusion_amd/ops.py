@@ -24,20 +24,20 @@ class PreparedWeight:
         self.wp, self.Cout, self.Cg, self.ksize, self.groups, self.CK, self.dtype, self.desc = wp, Cout, Cg, ksize, groups, CK, dtype, desc
 
 
-def pick_ck(Cg: int, ksize: int, dtype: torch.dtype) -> int:
-    return int(lib().ddx_mpconv2d_pick_ck(Cg, ksize, dtype_code(dtype)))
+def pick_ck(Cg: int, ksize: int, dtype: torch.dtype, npix: int = 0) -> int:
+    return int(lib().ddx_mpconv2d_pick_ck(Cg, ksize, dtype_code(dtype), npix))
 
 
 def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float = 1.0, gain_ptr: Optional[torch.Tensor] = None,
           normalize: bool = False, qk_head_dim: int = 0, CK: Optional[int] = None, cg_pad: Optional[int] = None,
-          out: Optional[torch.Tensor] = None) -> PreparedWeight:
+          out: Optional[torch.Tensor] = None, npix: int = 0) -> PreparedWeight:
     """Prepare MPConv weights `[Cout, Cg, k, k]` for ddx_mpconv2d_fwd.  `cg_pad`: channel count of the activation
     tensor per group when it is zero-padded beyond the weight's Cg (conv_in: 6 -> 8)."""
     assert weight.is_contiguous()
     Cout, Cg = weight.shape[0], weight.shape[1]
     ksize = weight.shape[2] if weight.ndim == 4 else 1
     if CK is None:
-        CK = pick_ck(cg_pad or Cg, ksize, dtype)
+        CK = pick_ck(cg_pad or Cg, ksize, dtype, npix)
     nbytes = lib().ddx_wprep_bytes(Cout, Cg, ksize, groups, CK, dtype_code(dtype))
     if cg_pad is not None:
         assert (cg_pad + CK - 1) // CK == (Cg + CK - 1) // CK, "padded channels must stay inside the last K chunk"

@@ -94,8 +94,8 @@ typedef struct {
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
-/* CK the library wants for a conv of this shape (call before wprep). */
-int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype);
+/* CK the library wants for a conv of this shape (call before wprep).  npix = B*H*W of the output (0 = unknown). */
+int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix);
 
 /* ------------------------------------------------------------------------------------------------
  * RMS ("pixel") normalisation over the channel axis of NHWC rows  (mp_tools.py:42-49 with dim=1,

@@ -45,9 +45,10 @@ def test_descriptor_struct_layout_matches_header():
         # wprep byte count: groups * ceil(Cg/CK) * taps * roundup(Ng,32) * CK * sizeof
         assert lib.ddx_wprep_bytes(512, 32, 3, 8, 32, _lib.DDX_BF16) == 8 * 1 * 9 * 64 * 32 * 2
         assert lib.ddx_wprep_bytes(4, 256, 3, 1, 32, _lib.DDX_F32) == 1 * 8 * 9 * 32 * 32 * 4
-        assert lib.ddx_mpconv2d_pick_ck(32, 3, _lib.DDX_BF16) == 32
-        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_BF16) == 128
-        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_F32) == 64
+        assert lib.ddx_mpconv2d_pick_ck(32, 3, _lib.DDX_BF16, 0) == 32
+        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_BF16, 0) == 128
+        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_BF16, 344) == 64
+        assert lib.ddx_mpconv2d_pick_ck(1280, 1, _lib.DDX_F32, 0) == 64
 
 
 def test_null_descriptor_is_rejected_without_a_gpu():

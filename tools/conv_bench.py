@@ -55,7 +55,7 @@ def main():
         cs = torch.rand(B, C0 + C1, device=dev) + 0.5
         res = torch.randn(B, H, W, Cout, device=dev).to(dt) if has_res else None
         out = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
-        pw = ops.wprep(w, G, dt)
+        pw = ops.wprep(w, G, dt, npix=B * H * W)
         raw = name.endswith('_raw')
         kw = dict(out_hw=(H, W), src1=a1, scale0=1.0 if raw else 0.8, scale1=1.0 if raw else 1.1, resample=rs, prologue=pro,
                   chan_scale=cs if pro & L.PRO_SCALE else None, residual=res, res_t=0.3, clip=256.0, out=out)
