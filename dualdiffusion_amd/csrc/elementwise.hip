@@ -230,6 +230,18 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const ddx_linear_job*
   }
 }
 
+// out = a*x + b*y + c*z on fp32 vectors (y, z optional): the element-wise algebra of the EDM sampler step
+// (CFG lerp, Heun average, sample update + ancestral noise; reference dual_diffusion_pipeline.py:701-737).
+__global__ __launch_bounds__(256) void lincomb3_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b,
+                                                       const float* __restrict__ z, float c, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = a * x[i];
+    if (y) v += b * y[i];
+    if (z) v += c * z[i];
+    out[i] = v;
+  }
+}
+
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
 
 }  // namespace ddx
@@ -312,6 +324,15 @@ extern "C" int ddx_mpsum_rows(const float* a, int32_t a_rows, const float* b, co
     hipLaunchKernelGGL(mpsum_rows_kernel, dim3((M * C + 255) / 256), dim3(256), 0, s, a, a_rows, b, t_rows, t, out, M, C, silu);
     return check_launch("mpsum_rows");
   }, stream);
+}
+
+extern "C" int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* z, float c, float* out, int64_t n,
+                            ddx_stream stream) {
+  if (!x || !out || n <= 0) return set_error(DDX_ERR_ARG, "lincomb3: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(lincomb3_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, s, x, a, y, b, z, c, out, (size_t)n);
+    return check_launch("lincomb3");
+  }, stream, "lincomb3", 0.0, 4.0 * (double)n * (2 + (y ? 1 : 0) + (z ? 1 : 0)));
 }
 
 extern "C" int ddx_linear_small_batched(const ddx_linear_job* jobs_dev, int32_t njobs, int32_t max_O, const float* x, int32_t x_stride,

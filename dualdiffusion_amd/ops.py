@@ -141,6 +141,14 @@ def unet_output_combine(y_nhwc: torch.Tensor, x_in: torch.Tensor, sigma: torch.T
                                         dtype_code(y_nhwc.dtype), current_stream()), "unet_output_combine")
 
 
+def lincomb3(out: torch.Tensor, x: torch.Tensor, a: float, y: Optional[torch.Tensor] = None, b: float = 0.0,
+             z: Optional[torch.Tensor] = None, c: float = 0.0) -> torch.Tensor:
+    """out = a*x + b*y + c*z (fp32, contiguous, same numel)."""
+    assert out.dtype == torch.float32 and x.dtype == torch.float32 and out.is_contiguous() and x.is_contiguous()
+    check(lib().ddx_lincomb3(ptr(x), float(a), ptr(y), float(b), ptr(z), float(c), ptr(out), out.numel(), current_stream()), "lincomb3")
+    return out
+
+
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, Cn, H, W = x.shape
     if out is None:

@@ -367,3 +367,41 @@ def schedule_edm2(steps: int, sigma_max: float, sigma_min: float, rho: float = 7
     """sampling/schedule.py:34-37,57-59."""
     t = torch.linspace(1, 0, steps + 1)
     return (sigma_max ** (1 / rho) + (1 - t) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+
+
+# ----------------------------------------------------------------------------- sampler (a-15)
+
+def sampler_edm2(denoise, sample_shape, noises: list, *, num_steps: int, sigma_max: float, sigma_min: float, sigma_data: float = 1.0,
+                 rho: float = 7.0, cfg_scale: float = 1.5, use_heun: bool = True, input_perturbation: float = 1.0,
+                 input_perturbation_offset: float = 0.0, batch_size: int = 1, conditioned: bool = True):
+    """pipelines/dual_diffusion_pipeline.py:589-752 (diffusion_decode), with the random draws injected:
+    `noises[0]` is the initial noise, `noises[1:]` the ancestral noise of steps 0..num_steps-2.
+    `denoise(x, sigma_vector)` is the UNet call at batch 2B (cond rows first) when `conditioned`, else at batch B.
+    Returns (final sample, sigma schedule list)."""
+    sched = schedule_edm2(num_steps, sigma_max, sigma_min, rho)
+    sig = sched.tolist()
+    sample = noises[0] * (sched[0] ** 2 + sigma_data ** 2) ** 0.5
+    B = batch_size
+
+    def guided(x, s):
+        if conditioned:
+            out = denoise(x.repeat(2, 1, 1, 1), torch.tensor([s] * B * 2)).float()
+            return torch.lerp(out[B:], out[:B], cfg_scale)
+        return denoise(x, torch.tensor([s] * B)).float()
+
+    for i, (s_curr, s_next) in enumerate(zip(sig[:-1], sig[1:])):
+        old_next = s_next
+        ipo = math.log(s_curr) + input_perturbation_offset
+        eff = (math.tanh(ipo) / 2 + 0.5) * float(input_perturbation)        # :683-693
+        s_next = s_next * (1 - max(min(eff, 1), 0))                          # :695
+        out = guided(sample, s_curr)
+        if use_heun:                                                         # :705-721
+            t_hat = max(old_next, sigma_min) / s_curr
+            out_hat = guided(torch.lerp(out, sample, t_hat), t_hat * s_curr)
+            out = torch.lerp(out, out_hat, 0.5)
+        t = s_next / s_curr if (i + 1) < num_steps else 0
+        sample = torch.lerp(out, sample, t)                                  # :723-724
+        if i + 1 < num_steps:                                                # :734-737
+            p = max(old_next ** 2 - s_next ** 2, 0) ** 0.5
+            sample = sample + p * noises[1 + i]
+    return sample, sig

@@ -90,3 +90,26 @@ def test_schedule_golden():
         smin = float(parts[3] + "." + parts[4])
         rho = float(parts[5] + "." + parts[6])
         assert rel_l2(O.schedule_edm2(n, smax, smin, rho), ref) < 1e-6
+
+
+def test_sampler_golden():
+    """diffusion_decode restatement (CFG + Heun + input perturbation) against the reference's output, injected noises."""
+    t, m = load_golden("sampler")
+    cfg = O.unet_cfg(**m["cfg"])
+    sd = O.random_unet_state(cfg, m["seed"])
+    emb = t["embeddings"]
+    den = lambda x, s: O.unet_forward(sd, cfg, x, s, emb)
+    for case, kw in m["cases"].items():
+        noises = [t[f"{case}.noise{i}"] for i in range(m["num_steps"])]
+        out, sig = O.sampler_edm2(den, tuple(m["shape"]), noises, num_steps=m["num_steps"], sigma_max=m["sigma_max"],
+                                  sigma_min=m["sigma_min"], batch_size=m["B"], **kw)
+        assert rel_l2(out, t[f"{case}.out"]) < 2e-5, case
+
+
+def test_host_schedules_match_oracle():
+    from dualdiffusion_amd.sampling.schedule import SamplingSchedule
+    t, _ = load_golden("schedule")
+    ref = t["edm2.100.200.0.0.03.7.0"]
+    got = SamplingSchedule.get_schedule("edm2", 100, sigma_max=200.0, sigma_min=0.03, rho=7.0)
+    assert torch.equal(got, ref)
+    assert set(SamplingSchedule.get_schedules_list()) == {"edm2", "ln_linear", "linear", "cos", "scale_invariant"}

@@ -291,7 +291,48 @@ def gen_schedule() -> None:
     save("schedule", t, {})
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule}
+def gen_sampler() -> None:
+    """diffusion_decode (dual_diffusion_pipeline.py:589-752) on the tiny UNet: 4 steps, CFG + Heun + input perturbation."""
+    print("sampler")
+    from pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams
+    tiny = O.unet_cfg(model_channels=32, channel_mult=(1, 2), num_layers_per_block=2, attn_levels=(1,),
+                      channels_per_head=32, mlp_groups=8, mlp_multiplier=2, channel_mult_noise=1, channel_mult_emb=2)
+    unet = make_ref_unet(tiny)
+    sd = O.random_unet_state(tiny, 0)
+    unet.load_state_dict(sd)
+    fake = types.SimpleNamespace(format=FakeFormat())
+    B, shape = 2, (2, 4, 32, 32)
+    g = torch.Generator().manual_seed(77)
+    clap = torch.randn(B, 512, generator=g).repeat(2, 1)   # the reference needs the embedding at the CFG batch (2B rows)
+    t = {"clap": clap}
+    for case, kw in {"heun": dict(use_heun=True, cfg_scale=1.5, input_perturbation=1.0),
+                     "euler": dict(use_heun=False, cfg_scale=2.0, input_perturbation=0.5, input_perturbation_offset=-1.0)}.items():
+        params = SampleParams(seed=1234, num_steps=4, batch_size=B, length=1, sigma_max=80.0, sigma_min=0.05, sigma_data=1.0,
+                              rho=7.0, schedule="edm2", **kw)
+        with torch.no_grad():
+            ref = DualDiffusionPipeline.diffusion_decode(fake, params, quiet=True, audio_embedding=clap, sample_shape=shape, module=unet)
+        # replay the generator stream of the reference: initial noise, then one draw per non-final step
+        gen = torch.Generator().manual_seed(1234)
+        noises = [torch.randn(shape, generator=gen) for _ in range(4)]
+        mask = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
+        with torch.no_grad():
+            emb = unet.get_embeddings(clap, mask)
+        den = lambda x, s: O.unet_forward(sd, tiny, x, s, emb)
+        ours, sig = O.sampler_edm2(den, shape, noises, num_steps=4, sigma_max=80.0, sigma_min=0.05, batch_size=B,
+                                   cfg_scale=kw["cfg_scale"], use_heun=kw["use_heun"], input_perturbation=kw["input_perturbation"],
+                                   input_perturbation_offset=kw.get("input_perturbation_offset", 0.0))
+        check(f"sampler {case}", ours, ref, 2e-5)
+        t[f"{case}.out"] = ref
+        for i, n in enumerate(noises):
+            t[f"{case}.noise{i}"] = n
+    t["embeddings"] = emb
+    save("sampler", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in tiny.items()}, seed=0, B=B, shape=list(shape),
+                            cases={"heun": dict(use_heun=True, cfg_scale=1.5, input_perturbation=1.0, input_perturbation_offset=0.0),
+                                   "euler": dict(use_heun=False, cfg_scale=2.0, input_perturbation=0.5, input_perturbation_offset=-1.0)},
+                            num_steps=4, sigma_max=80.0, sigma_min=0.05))
+
+
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
