@@ -230,6 +230,36 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const ddx_linear_job*
   }
 }
 
+// 2x nearest upsample / 2x2 average pool of an NHWC tensor (reference resample_2d, mp_tools.py:71-79); H, W = OUTPUT size.
+template <typename T>
+__global__ __launch_bounds__(256) void resample2d_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int mode) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int nvec = C / EV;  // host guarantees C % EV == 0
+  const size_t total = (size_t)B * H * W * nvec;
+  const int sH = mode == DDX_RESAMPLE_UP ? H / 2 : H * 2, sW = mode == DDX_RESAMPLE_UP ? W / 2 : W * 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int v = (int)(i % nvec);
+    size_t pix = i / nvec;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H);
+    const int b = (int)(pix / H);
+    Vec16<T> o;
+    if (mode == DDX_RESAMPLE_UP) {
+      o.v = *reinterpret_cast<const decltype(o.v)*>(x + (((size_t)b * sH + (h >> 1)) * sW + (w >> 1)) * C + v * EV);
+    } else {
+      const T* sp = x + (((size_t)b * sH + 2 * h) * sW + 2 * w) * C + v * EV;
+      Vec16<T> a0, a1, a2, a3;
+      a0.v = *reinterpret_cast<const decltype(o.v)*>(sp);
+      a1.v = *reinterpret_cast<const decltype(o.v)*>(sp + C);
+      a2.v = *reinterpret_cast<const decltype(o.v)*>(sp + (size_t)sW * C);
+      a3.v = *reinterpret_cast<const decltype(o.v)*>(sp + (size_t)sW * C + C);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) o.set(e, 0.25f * ((a0.get(e) + a1.get(e)) + (a2.get(e) + a3.get(e))));
+    }
+    *reinterpret_cast<decltype(o.v)*>(y + i * EV) = o.v;
+  }
+}
+
 // out = a*x + b*y + c*z on fp32 vectors (y, z optional): the element-wise algebra of the EDM sampler step
 // (CFG lerp, Heun average, sample update + ancestral noise; reference dual_diffusion_pipeline.py:701-737).
 __global__ __launch_bounds__(256) void lincomb3_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b,
@@ -324,6 +354,22 @@ extern "C" int ddx_mpsum_rows(const float* a, int32_t a_rows, const float* b, co
     hipLaunchKernelGGL(mpsum_rows_kernel, dim3((M * C + 255) / 256), dim3(256), 0, s, a, a_rows, b, t_rows, t, out, M, C, silu);
     return check_launch("mpsum_rows");
   }, stream);
+}
+
+extern "C" int ddx_resample2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode, int32_t dtype,
+                              ddx_stream stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "resample2d: bad args");
+  if (mode != DDX_RESAMPLE_UP && mode != DDX_RESAMPLE_DOWN) return set_error(DDX_ERR_ARG, "resample2d: mode must be UP or DOWN");
+  if (mode == DDX_RESAMPLE_UP && ((H | W) & 1)) return set_error(DDX_ERR_ARG, "resample2d: upsampled size must be even");
+  if (C % (dtype == DDX_BF16 ? 8 : 4)) return set_error(DDX_ERR_UNSUPPORTED, "resample2d: channels must fill 16-byte vectors");
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t total = (size_t)B * H * W * (C / (dtype == DDX_BF16 ? 8 : 4));
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(resample2d_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, B, H, W, C, mode);
+    else
+      hipLaunchKernelGGL(resample2d_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, mode);
+    return check_launch("resample2d");
+  }, stream, "resample2d", 0.0, (double)dtype_size(dtype) * B * H * W * C * (mode == DDX_RESAMPLE_UP ? 1.25 : 5.0));
 }
 
 extern "C" int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* z, float c, float* out, int64_t n,

@@ -1,0 +1,178 @@
+"""Launch-plan builder shared by the HIP-backed modules (UNet, VAE).
+
+A module forward for a fixed (batch, size, dtype, training) is a static sequence of libddx_hip launches over static
+buffers.  `PlanBuilder` collects, while the module walks its topology once:
+  * the prepared-weight buffers and their weight-preparation launches (`wplan`, re-run when weights change),
+  * the per-block modulation vectors `c = emb_linear(emb)*gain + 1` as jobs of ONE batched small-M kernel,
+  * the activation buffers and the forward launches (`fplan`, replayed eagerly or as a hipGraph).
+It also knows how to queue one EDM2 block (reference src/modules/unets/unet_edm2_b4.py:110-158 and its VAE twin
+src/modules/old/vaes/vae_edm2.py:96-156), which is the same launch sequence for both model families.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+
+from . import ops
+from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan
+
+_RESAMPLE = {"keep": RESAMPLE_KEEP, "up": RESAMPLE_UP, "down": RESAMPLE_DOWN}
+
+
+def mp_cat_weights(na: int, nb: int, t: float) -> tuple:
+    """Scalars of the magnitude-preserving concat (reference mp_tools.py:294-301)."""
+    c = math.sqrt((na + nb) / ((1 - t) ** 2 + t ** 2))
+    return c / math.sqrt(na) * (1 - t), c / math.sqrt(nb) * t
+
+
+class PlanBuilder:
+
+    def __init__(self, device: torch.device, dtype: torch.dtype, batch: int, training: bool) -> None:
+        self.dev, self.dt, self.B, self.training = device, dtype, batch, training
+        self.keep: list = []        # every tensor the recorded launches point into
+        self.gains: list = []       # 0-d gain parameters, mirrored into one fp32 vector read by the kernels
+        self.convs: list = []       # weight-preparation specs
+        self.lin_jobs: list = []    # (weight holder, gain slot, out tensor, groups, add_const)
+        self.steps: list = []       # closures executed while recording the forward plan
+        self.wplan, self.fplan = Plan(), Plan()
+        self.gain_f32: Optional[torch.Tensor] = None
+        self._weights_key = None
+
+    # ------------------------------------------------------------------------------------------ resources
+    def f32(self, *shape) -> torch.Tensor:
+        t = torch.empty(*shape, device=self.dev, dtype=torch.float32)
+        self.keep.append(t)
+        return t
+
+    def act(self, h: int, w: int, c: int) -> torch.Tensor:
+        t = torch.empty(self.B, h, w, c, device=self.dev, dtype=self.dt)
+        self.keep.append(t)
+        return t
+
+    def gain_slot(self, p) -> int:
+        self.gains.append(p)
+        return len(self.gains) - 1
+
+    def prep(self, conv, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0, in_scale=None):
+        """Declare a conv's prepared weights; the buffer is filled whenever `wplan` runs."""
+        w = conv.weight
+        Cg, ks = w.shape[1], (w.shape[2] if w.ndim == 4 else 1)
+        CK = ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
+        nbytes = ops.lib().ddx_wprep_bytes(w.shape[0], Cg, ks, conv.groups, CK, ops.dtype_code(self.dt))
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self.keep.append(buf)
+        self.convs.append(dict(conv=conv, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad,
+                               gain_slot=self.gain_slot(gain_param) if gain_param is not None else None))
+        return ops.PreparedWeight(buf, w.shape[0], Cg, ks, conv.groups, CK, self.dt, None)
+
+    def cvec(self, lin, gain_param, add_const: float = 1.0) -> torch.Tensor:
+        """Per-(batch, channel) vector lin(emb)*gain + add_const, produced by the batched small-M kernel."""
+        out = self.f32(self.B, lin.out_channels)
+        self.lin_jobs.append((lin, self.gain_slot(gain_param) if gain_param is not None else None, out, lin.groups, add_const))
+        return out
+
+    def step(self, fn: Callable[[], None]) -> None:
+        self.steps.append(fn)
+
+    # ------------------------------------------------------------------------------------------ one EDM2 block
+    def block(self, blk, src0: torch.Tensor, src1: Optional[torch.Tensor], s0: float, s1: float, h: int, w: int,
+              mlp_multiplier: int, res_balance: float, attn_balance: float, clip: float = 256.0) -> torch.Tensor:
+        """Queue one block; `src0/src1` are its (optionally mp_cat'ed, scales s0/s1) NHWC inputs at the PRE-resample size."""
+        cout, mm = blk.out_channels, mlp_multiplier
+        rs = _RESAMPLE[blk.resample_mode]
+        npix = self.B * h * w
+        c_emb = self.cvec(blk.emb_linear, blk.emb_gain)
+        pw_res0, pw_res1 = self.prep(blk.conv_res0, npix=npix), self.prep(blk.conv_res1, npix=npix)
+        pw_skip = self.prep(blk.conv_skip, npix=npix) if blk.conv_skip is not None else None
+        y0, xo = self.act(h, w, cout * mm), self.act(h, w, cout)
+        last_clip = 0.0 if blk.use_attention else clip
+        S = self.step
+        if blk.flavor == "enc":
+            x1 = self.act(h, w, cout)
+            if pw_skip is not None:
+                S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), resample=rs, out=x1))
+            elif rs != RESAMPLE_KEEP:
+                S(lambda: ops.resample2d(src0, x1, rs))
+            if pw_skip is not None or rs != RESAMPLE_KEEP:
+                S(lambda: ops.pixelnorm(x1, out=x1))
+            else:
+                S(lambda: ops.pixelnorm(src0, out=x1))
+            S(lambda: ops.conv2d(x1, pw_res0, prologue=PRO_SILU, out=y0))
+            S(lambda: ops.conv2d(y0, pw_res1, prologue=PRO_SCALE_SILU, chan_scale=c_emb, residual=x1, res_t=res_balance,
+                                 clip=last_clip, out=xo))
+        else:
+            S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU, out=y0))
+            if pw_skip is not None:
+                sk = self.act(h, w, cout)
+                S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, out=sk))
+            elif rs != RESAMPLE_KEEP:
+                sk = self.act(h, w, cout)      # no skip conv: the residual is the (resampled) block input itself
+                S(lambda: ops.resample2d(src0, sk, rs))
+            else:
+                assert src1 is None, "a concatenated input always changes the channel count, i.e. has a skip conv"
+                sk = src0
+            S(lambda: ops.conv2d(y0, pw_res1, prologue=PRO_SCALE_SILU, chan_scale=c_emb, residual=sk, res_t=res_balance,
+                                 clip=last_clip, out=xo))
+        if not blk.use_attention:
+            return xo
+        c_qk, c_v = self.cvec(blk.emb_linear_qk, blk.emb_gain_qk), self.cvec(blk.emb_linear_v, blk.emb_gain_v)
+        heads = blk.num_heads
+        pw_qk = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix)
+        pw_v, pw_proj = self.prep(blk.attn_v, npix=npix), self.prep(blk.attn_proj, npix=npix)
+        qk, vv, ao, xa = self.act(h, w, 2 * cout), self.act(h, w, cout), self.act(h, w, cout), self.act(h, w, cout)
+        S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
+        S(lambda: ops.conv2d(xo, pw_v, out=vv))
+        S(lambda: ops.attention(qk, vv, heads, out=ao))
+        S(lambda: ops.conv2d(ao, pw_proj, prologue=PRO_SCALE_SILU, chan_scale=c_v, residual=xo, res_t=attn_balance, clip=clip, out=xa))
+        return xa
+
+    # ------------------------------------------------------------------------------------------ finalize / run
+    def gain_ptr(self, slot: Optional[int]):
+        return self.gain_f32[slot:slot + 1] if slot is not None else None
+
+    def finalize(self, emb: Optional[torch.Tensor], emb_stride: int, pre_steps: Optional[Callable[[], None]] = None) -> None:
+        """Build the job table of the modulation vectors (input `emb` [B, emb_stride] fp32) and record both plans.
+        `pre_steps` runs first inside the forward plan (front end that produces `emb`)."""
+        self.gain_f32 = torch.zeros(max(len(self.gains), 1), device=self.dev, dtype=torch.float32)
+        if self.lin_jobs:
+            self.emb_table = ops.make_linear_jobs(
+                [(lin.weight, self.gain_ptr(slot), out, 1.0, addc, groups, self.training and not getattr(lin, "disable_weight_norm", False))
+                 for (lin, slot, out, groups, addc) in self.lin_jobs], self.dev)
+            n_jobs, max_o = len(self.lin_jobs), max(lin.out_channels for (lin, *_r) in self.lin_jobs)
+            wdt = self.lin_jobs[0][0].weight.dtype
+        with self.wplan.record():
+            for sp in self.convs:
+                conv = sp["conv"]
+                ops.wprep(conv.weight, conv.groups, self.dt, gain_ptr=self.gain_ptr(sp["gain_slot"]),
+                          normalize=self.training and not conv.disable_weight_norm, qk_head_dim=sp["qk"], CK=sp["CK"],
+                          cg_pad=sp["cg_pad"], out=sp["buf"])
+        with self.fplan.record():
+            if pre_steps is not None:
+                pre_steps()
+            if self.lin_jobs:
+                ops.linear_small(self.emb_table, n_jobs, max_o, emb, self.B, wdt, x_stride=emb_stride)
+            for st in self.steps:
+                st()
+
+    def refresh_weights(self, params) -> None:
+        """Re-run weight preparation when training (forced weight norm every forward) or when any parameter changed."""
+        key = None if self.training else tuple(p._version for p in params)
+        if self.training or key != self._weights_key:
+            if self.gains:
+                self.gain_f32.copy_(torch.stack([g.detach().float().reshape(()) for g in self.gains]))
+            self.wplan.run()
+            self._weights_key = key
+
+    def launch(self, use_graph: bool) -> None:
+        if use_graph:
+            if not self.fplan.has_graph:
+                self.fplan.run()                            # warm-up outside capture (function attributes, module load)
+                torch.cuda.current_stream().synchronize()
+                cap = torch.cuda.Stream(device=self.dev)    # the legacy default stream cannot be captured
+                self.fplan.graph_build(cap.cuda_stream)
+                cap.synchronize()
+            self.fplan.graph_launch()
+        else:
+            self.fplan.run()

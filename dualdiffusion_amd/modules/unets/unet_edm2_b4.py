@@ -8,15 +8,14 @@ shape, optionally as a single hipGraph.
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Optional, Union
 
 import torch
 
 from ... import ops
-from ..._lib import DDXError, Plan
-from ..._lib import EPI_MPSUM, PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP  # noqa: F401
+from ..._lib import DDXError
+from ...engine import PlanBuilder, mp_cat_weights
 from .unet import DualDiffusionUNet, DualDiffusionUNetConfig
 
 
@@ -240,217 +239,77 @@ class _UNetEngine:
         q = 2 ** (unet.num_levels - 1)
         if H % q or W % q:
             raise DDXError(f"latent size {H}x{W} must be a multiple of {q} (see get_latent_shape)")
-        self.u, self.B, self.H, self.W, self.training = unet, B, H, W, training
-        self.dev, self.dt = unet.device, unet.dtype
-        dev, dt = self.dev, self.dt
-        f32 = dict(device=dev, dtype=torch.float32)
-        self.keep: list = []
-        self._weights_key = None
+        self.u, self.B, self.H, self.W = unet, B, H, W
+        pb = self.pb = PlanBuilder(unet.device, unet.dtype, B, training)
         self._lnf_key = None
+        cemb = unet.cemb
 
-        # ---- static I/O
-        C_in = cfg.in_channels
-        self.x_in = torch.empty(B, C_in, H, W, **f32)
-        self.x_pre = torch.empty(B, C_in, H, W, **f32)       # perturbed_input or x_in: what the body sees
-        self.sigma = torch.empty(B, **f32)
-        self.emb_in = torch.empty(B, unet.cemb, **f32)
-        self.x_ref = torch.empty(B, cfg.out_channels + 1, H, W, **f32) if with_xref else None
-        self.out = torch.empty(B, cfg.out_channels, H, W, **f32)
-        self.lnf = torch.empty(H, **f32)
+        # ---- static I/O (module boundary: NCHW fp32)
+        self.x_in = pb.f32(B, cfg.in_channels, H, W)
+        self.x_pre = pb.f32(B, cfg.in_channels, H, W)       # perturbed_input or x_in: what the body sees
+        self.sigma = pb.f32(B)
+        self.emb_in = pb.f32(B, cemb)
+        self.x_ref = pb.f32(B, cfg.out_channels + 1, H, W) if with_xref else None
+        self.out = pb.f32(B, cfg.out_channels, H, W)
+        self.lnf = pb.f32(H)
 
-        # ---- weight preparation plan
-        self.gains: list = []          # 0-d gain parameters, mirrored into one fp32 vector for the kernels
-        self.convs: list = []          # (MPConvWeight, PreparedWeight holder dict)
-        self.wplan = Plan()
-        self.fplan = Plan()
-        self._build(with_xref)
-
-    # -------------------------------------------------------------------------------------------- helpers
-    def _gain_slot(self, p: torch.nn.Parameter) -> int:
-        self.gains.append(p)
-        return len(self.gains) - 1
-
-    def _act(self, Hh: int, Ww: int, Cc: int) -> torch.Tensor:
-        t = torch.empty(self.B, Hh, Ww, Cc, device=self.dev, dtype=self.dt)
-        self.keep.append(t)
-        return t
-
-    def _prep(self, conv: MPConvWeight, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0):
-        """Allocate the prepared-weight buffer and queue its wprep; returns a PreparedWeight (filled when wplan runs)."""
-        w = conv.weight
-        Cg = w.shape[1]
-        ks = w.shape[2]
-        CK = ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
-        nbytes = ops.lib().ddx_wprep_bytes(w.shape[0], Cg, ks, conv.groups, CK, ops.dtype_code(self.dt))
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-        self.keep.append(buf)
-        spec = dict(conv=conv, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad,
-                    gain_slot=self._gain_slot(gain_param) if gain_param is not None else None)
-        self.convs.append(spec)
-        return ops.PreparedWeight(buf, w.shape[0], Cg, ks, conv.groups, CK, self.dt, None)
-
-    # -------------------------------------------------------------------------------------------- plan build
-    def _build(self, with_xref: bool) -> None:
-        u, cfg, B, H, W = self.u, self.u.config, self.B, self.H, self.W
-        dev = self.dev
-        f32 = dict(device=dev, dtype=torch.float32)
-        cemb = u.cemb
-        wa_wb = lambda na, nb, t: ((math.sqrt((na + nb) / ((1 - t) ** 2 + t ** 2)) / math.sqrt(na) * (1 - t)),
-                                   (math.sqrt((na + nb) / ((1 - t) ** 2 + t ** 2)) / math.sqrt(nb) * t))
-
-        # prepared weights + per-block emb_linear jobs are declared while walking the topology
-        lin_jobs: list = []   # (MPConvWeight, gain_slot, out tensor, groups)
-
-        def cvec(conv: MPConvWeight, gain_param) -> torch.Tensor:
-            out = torch.empty(B, conv.out_channels, **f32)
-            self.keep.append(out)
-            lin_jobs.append((conv, self._gain_slot(gain_param), out, conv.groups))
-            return out
-
-        steps: list = []  # closures executed inside fplan.record()
-
-        # ---- front end
+        # ---- front end: preconditioning + embedding (reference unet_edm2_b4.py:257-277)
         Cpad = 8
-        x0 = self._act(H, W, Cpad)
-        four = torch.empty(B, u.cnoise, **f32)
-        e0 = torch.empty(B, cemb, **f32)
-        emb = torch.empty(B, cemb, **f32)
-        self.keep += [four, e0, emb]
-        self.emb = emb
-        freqs = u.emb_fourier.freqs.float().contiguous()
-        phases = u.emb_fourier.phases.float().contiguous()
-        self.keep += [freqs, phases]
-        self._noise_job = (u.emb_noise, e0)
-
-        pw_in = self._prep(u.enc["conv_in"], cg_pad=Cpad)
+        x0 = pb.act(H, W, Cpad)
+        four, e0, emb = pb.f32(B, unet.cnoise), pb.f32(B, cemb), pb.f32(B, cemb)
+        freqs, phases = unet.emb_fourier.freqs.float().contiguous(), unet.emb_fourier.phases.float().contiguous()
+        pb.keep += [freqs, phases]
+        noise_table = ops.make_linear_jobs([(unet.emb_noise.weight, None, e0, 1.0, 0.0, 1, training)], unet.device)
+        pb.keep.append(noise_table)
 
         def front():
             ops.unet_input_prep(self.x_pre, self.sigma, self.lnf, x0, cfg.sigma_data)
             ops.mpfourier(self.sigma, freqs, phases, four, True)
-            ops.linear_small(self.noise_table, 1, cemb, four, B, u.emb_noise.weight.dtype)
+            ops.linear_small(noise_table, 1, cemb, four, B, unet.emb_noise.weight.dtype)
             ops.mpsum_rows(e0, self.emb_in, emb, t=cfg.label_balance, silu=True)
-            ops.linear_small(self.emb_table, self.emb_njobs, self.emb_max_o, emb, B, self.emb_wdtype, x_stride=cemb)
-        steps.append(front)
 
-        # ---- encoder
-        x = self._act(H, W, u.enc["conv_in"].out_channels)
-        steps.append(lambda x=x: ops.conv2d(x0, pw_in, out=x))
+        # ---- encoder / decoder (reference unet_edm2_b4.py:279-288)
+        pw_in = pb.prep(unet.enc["conv_in"], cg_pad=Cpad, npix=B * H * W)
+        x = pb.act(H, W, unet.enc["conv_in"].out_channels)
+        pb.step(lambda x=x: ops.conv2d(x0, pw_in, out=x))
         skips = [x]
-        cur_h, cur_w = H, W
-
-        def block(blk: BlockWeights, src0, src1, s0, s1, h, w):
-            """Queue one Block (reference unet_edm2_b4.py:110-158); returns the output tensor."""
-            cout = blk.out_channels
-            mm = cfg.mlp_multiplier
-            rs = {"keep": RESAMPLE_KEEP, "up": RESAMPLE_UP, "down": RESAMPLE_DOWN}[blk.resample_mode]
-            c_emb = cvec(blk.emb_linear, blk.emb_gain)
-            npix = B * h * w
-            pw_res0, pw_res1, pw_skip = (self._prep(blk.conv_res0, npix=npix), self._prep(blk.conv_res1, npix=npix),
-                                         self._prep(blk.conv_skip, npix=npix))
-            y0 = self._act(h, w, cout * mm)
-            xo = self._act(h, w, cout)
-            last_clip = 0.0 if blk.use_attention else 256.0
-            if blk.flavor == "enc":
-                x1 = self._act(h, w, cout)
-                steps.append(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), resample=rs, out=x1))
-                steps.append(lambda: ops.pixelnorm(x1, out=x1))
-                steps.append(lambda: ops.conv2d(x1, pw_res0, prologue=PRO_SILU, out=y0))
-                steps.append(lambda: ops.conv2d(y0, pw_res1, prologue=PRO_SCALE_SILU, chan_scale=c_emb, residual=x1,
-                                                res_t=cfg.res_balance, clip=last_clip, out=xo))
-            else:
-                sk = self._act(h, w, cout)
-                steps.append(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs,
-                                                prologue=PRO_SILU, out=y0))
-                steps.append(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, out=sk))
-                steps.append(lambda: ops.conv2d(y0, pw_res1, prologue=PRO_SCALE_SILU, chan_scale=c_emb, residual=sk,
-                                                res_t=cfg.res_balance, clip=last_clip, out=xo))
-            if not blk.use_attention:
-                return xo
-            c_qk, c_v = cvec(blk.emb_linear_qk, blk.emb_gain_qk), cvec(blk.emb_linear_v, blk.emb_gain_v)
-            hd = cout // blk.num_heads
-            pw_qk = self._prep(blk.attn_qk, qk_head_dim=hd, npix=npix)
-            pw_v, pw_proj = self._prep(blk.attn_v, npix=npix), self._prep(blk.attn_proj, npix=npix)
-            qk, vv, ao, xa = self._act(h, w, 2 * cout), self._act(h, w, cout), self._act(h, w, cout), self._act(h, w, cout)
-            steps.append(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
-            steps.append(lambda: ops.conv2d(xo, pw_v, out=vv))
-            steps.append(lambda: ops.attention(qk, vv, blk.num_heads, out=ao))
-            steps.append(lambda: ops.conv2d(ao, pw_proj, prologue=PRO_SCALE_SILU, chan_scale=c_v, residual=xo,
-                                            res_t=cfg.attn_balance, clip=256.0, out=xa))
-            return xa
-
-        for name, blk in u.enc.items():
+        h, w = H, W
+        bk = dict(mlp_multiplier=cfg.mlp_multiplier, res_balance=cfg.res_balance, attn_balance=cfg.attn_balance)
+        for name, blk in unet.enc.items():
             if name == "conv_in":
                 continue
             if blk.resample_mode == "down":
-                cur_h, cur_w = cur_h // 2, cur_w // 2
-            x = block(blk, x, None, 1.0, 1.0, cur_h, cur_w)
+                h, w = h // 2, w // 2
+            x = pb.block(blk, x, None, 1.0, 1.0, h, w, **bk)
             skips.append(x)
-        # ---- decoder
-        for name, blk in u.dec.items():
+        for name, blk in unet.dec.items():
             if blk.resample_mode == "up":
-                cur_h, cur_w = cur_h * 2, cur_w * 2
+                h, w = h * 2, w * 2
             if "layer" in name:
                 sk = skips.pop()
-                s0, s1 = wa_wb(x.shape[3], sk.shape[3], cfg.concat_balance)
-                x = block(blk, x, sk, s0, s1, cur_h, cur_w)
+                s0, s1 = mp_cat_weights(x.shape[3], sk.shape[3], cfg.concat_balance)
+                x = pb.block(blk, x, sk, s0, s1, h, w, **bk)
             else:
-                x = block(blk, x, None, 1.0, 1.0, cur_h, cur_w)
-        # ---- output
-        pw_out = self._prep(u.conv_out, gain_param=u.out_gain)
-        y = self._act(H, W, cfg.out_channels)
-        xl = x
-        steps.append(lambda: ops.conv2d(xl, pw_out, out=y))
-        steps.append(lambda: ops.unet_output_combine(y, self.x_in, self.sigma, self.x_ref, self.out, cfg.sigma_data))
-
-        # ---- gains vector + job tables
-        self.gain_f32 = torch.zeros(max(len(self.gains), 1), **f32)
-        gp = lambda slot: self.gain_f32[slot:slot + 1] if slot is not None else None
-        self.noise_table = ops.make_linear_jobs([(u.emb_noise.weight, None, e0, 1.0, 0.0, 1, self.training)], dev)
-        self.emb_table = ops.make_linear_jobs(
-            [(c.weight, gp(slot), out, 1.0, 1.0, groups, self.training) for (c, slot, out, groups) in lin_jobs], dev)
-        self.emb_njobs = len(lin_jobs)
-        self.emb_max_o = max(c.out_channels for (c, _, _, _) in lin_jobs)
-        self.emb_wdtype = lin_jobs[0][0].weight.dtype
-
-        with self.wplan.record():
-            for sp in self.convs:
-                conv = sp["conv"]
-                ops.wprep(conv.weight, conv.groups, self.dt, gain_ptr=gp(sp["gain_slot"]),
-                          normalize=self.training and not conv.disable_weight_norm, qk_head_dim=sp["qk"], CK=sp["CK"],
-                          cg_pad=sp["cg_pad"], out=sp["buf"])
-        with self.fplan.record():
-            for st in steps:
-                st()
-
-    # -------------------------------------------------------------------------------------------- run
-    def _refresh_weights(self) -> None:
-        key = tuple(p._version for p in self.u.parameters()) if not self.training else None
-        if self.training or key != self._weights_key:
-            if self.gains:
-                self.gain_f32.copy_(torch.stack([g.detach().float() for g in self.gains]))
-            self.wplan.run()
-            self._weights_key = key
+                x = pb.block(blk, x, None, 1.0, 1.0, h, w, **bk)
+        # ---- output (reference unet_edm2_b4.py:290-296)
+        pw_out = pb.prep(unet.conv_out, gain_param=unet.out_gain, npix=B * H * W)
+        y = pb.act(H, W, cfg.out_channels)
+        pb.step(lambda x=x: ops.conv2d(x, pw_out, out=y))
+        pb.step(lambda: ops.unet_output_combine(y, self.x_in, self.sigma, self.x_ref, self.out, cfg.sigma_data))
+        pb.finalize(emb, cemb, pre_steps=front)
+        self.fplan = pb.fplan
 
     def run(self, x_in, sigma, format, embeddings, x_ref, perturbed_input, use_graph: bool) -> torch.Tensor:
         lkey = (id(format),)
         if lkey != self._lnf_key:
             self.lnf.copy_(self.u.get_ln_freqs_rows(format, self.B, self.H, self.W))
             self._lnf_key = lkey
-        self._refresh_weights()
+        self.pb.refresh_weights(self.u.parameters())
         self.x_in.copy_(x_in)
         self.x_pre.copy_(perturbed_input if perturbed_input is not None else x_in)
         self.sigma.copy_(sigma.flatten())
         self.emb_in.copy_(embeddings)
         if x_ref is not None:
             self.x_ref.copy_(x_ref)
-        if use_graph:
-            if not self.fplan.has_graph:
-                self.fplan.run()                     # warm-up outside capture (function attributes, lazy module load)
-                torch.cuda.current_stream().synchronize()
-                cap = torch.cuda.Stream(device=self.dev)   # the legacy default stream cannot be captured
-                self.fplan.graph_build(cap.cuda_stream)
-                cap.synchronize()
-            self.fplan.graph_launch()
-        else:
-            self.fplan.run()
+        self.pb.launch(use_graph)
         return self.out.clone()

@@ -141,6 +141,13 @@ def unet_output_combine(y_nhwc: torch.Tensor, x_in: torch.Tensor, sigma: torch.T
                                         dtype_code(y_nhwc.dtype), current_stream()), "unet_output_combine")
 
 
+def resample2d(x: torch.Tensor, out: torch.Tensor, mode: int) -> torch.Tensor:
+    """2x nearest upsample (mode UP) / 2x2 average pool (mode DOWN) of an NHWC tensor into `out`."""
+    B, H, W, Cn = out.shape
+    check(lib().ddx_resample2d(ptr(x), ptr(out), B, H, W, Cn, mode, dtype_code(x.dtype), current_stream()), "resample2d")
+    return out
+
+
 def lincomb3(out: torch.Tensor, x: torch.Tensor, a: float, y: Optional[torch.Tensor] = None, b: float = 0.0,
              z: Optional[torch.Tensor] = None, c: float = 0.0) -> torch.Tensor:
     """out = a*x + b*y + c*z (fp32, contiguous, same numel)."""

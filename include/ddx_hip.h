@@ -153,6 +153,11 @@ int ddx_unet_output_combine(const void* y_nhwc, const float* x_in_nchw, const fl
                             float* out_nchw, int32_t B, int32_t C, int32_t H, int32_t W, float sigma_data, int32_t dtype,
                             ddx_stream stream);
 
+/* Stand-alone 2x nearest upsample / 2x2 average pool of an NHWC tensor (resample_2d, mp_tools.py:71-79) for the places
+ * where it cannot ride in a conv's gather (blocks without a skip conv).  H, W = OUTPUT size; mode = DDX_RESAMPLE_UP|DOWN. */
+int ddx_resample2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode, int32_t dtype,
+                   ddx_stream stream);
+
 /* out = a*x + b*y + c*z on fp32 vectors (y, z may be NULL; in place allowed): CFG lerp, Heun average and the sample
  * update + ancestral noise of the EDM sampler step (pipelines/dual_diffusion_pipeline.py:701-737). */
 int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* z, float c, float* out, int64_t n,

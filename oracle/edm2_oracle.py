@@ -405,3 +405,147 @@ def sampler_edm2(denoise, sample_shape, noises: list, *, num_steps: int, sigma_m
             p = max(old_next ** 2 - s_next ** 2, 0) ** 0.5
             sample = sample + p * noises[1 + i]
     return sample, sig
+
+
+# ----------------------------------------------------------------------------- VAE (a-14)
+
+DEFAULT_VAE_CFG = dict(in_channels=2, in_num_freqs=256, in_channels_emb=512, out_channels=2, latent_channels=4, dropout=0.0,
+                       model_channels=256, channel_mult=(1, 2, 3, 4), channel_mult_emb=None, channels_per_head=64,
+                       num_layers_per_block=2, res_balance=0.3, attn_balance=0.3, mlp_multiplier=1, mlp_groups=1,
+                       add_mid_block_attention=False, class_id_override=0, target_snr=32.0, label_dim=512)
+
+
+def vae_cfg(**overrides) -> dict:
+    cfg = dict(DEFAULT_VAE_CFG)
+    cfg.update(overrides)
+    return cfg
+
+
+def vae_topology(cfg: dict) -> dict:
+    """modules/old/vaes/vae_edm2.py:176-228: ordered encoder / decoder stages (no skip connections, no attention unless
+    add_mid_block_attention; a block has a skip conv only when its channel count changes, :84)."""
+    cblock = [cfg["model_channels"] * m for m in cfg["channel_mult"]]
+    cemb = cfg["model_channels"] * cfg["channel_mult_emb"] if cfg["channel_mult_emb"] is not None else max(cblock)
+    enc, dec = [], []
+    cout = cfg["in_channels"] + 2
+    for level, ch in enumerate(cblock):
+        if level == 0:
+            enc.append(dict(name="conv_in", kind="conv_in", cin=cout, cout=ch))
+            cout = ch
+        else:
+            enc.append(dict(name=f"block{level}_down", kind="block", cin=cout, cout=cout, flavor="enc", resample="down", attention=False))
+        for i in range(cfg["num_layers_per_block"]):
+            enc.append(dict(name=f"block{level}_layer{i}", kind="block", cin=cout, cout=ch, flavor="enc", resample="keep", attention=False))
+            cout = ch
+    c_lat = cout
+    top = len(cblock) - 1
+    for level in range(top, -1, -1):
+        ch = cblock[level]
+        if level == top:
+            for nm in ("in0", "in1"):
+                dec.append(dict(name=f"block{level}_{nm}", kind="block", cin=cout, cout=cout, flavor="dec", resample="keep",
+                                attention=cfg["add_mid_block_attention"]))
+        else:
+            dec.append(dict(name=f"block{level}_up", kind="block", cin=cout, cout=cout, flavor="dec", resample="up", attention=False))
+        for i in range(cfg["num_layers_per_block"] + 1):
+            dec.append(dict(name=f"block{level}_layer{i}", kind="block", cin=cout, cout=ch, flavor="dec", resample="keep", attention=False))
+            cout = ch
+    return dict(cblock=cblock, cemb=cemb, enc=enc, dec=dec, c_lat=c_lat, cout_last=cout)
+
+
+def vae_param_shapes(cfg: dict) -> dict:
+    topo = vae_topology(cfg)
+    g, mm, cemb = cfg["mlp_groups"], cfg["mlp_multiplier"], topo["cemb"]
+    shapes = {"latents_out_gain": (), "out_gain": (), "emb_label.weight": (cemb, cfg["label_dim"]),
+              "recon_loss_logvar": (1,), "latents_logvar": (1,)}
+    for side in ("enc", "dec"):
+        for st in topo[side]:
+            p = f"{side}.{st['name']}"
+            if st["kind"] == "conv_in":
+                shapes[f"{p}.weight"] = (st["cout"], st["cin"], 3, 3)
+                continue
+            cin, cout = st["cin"], st["cout"]
+            res0_in = cout if st["flavor"] == "enc" else cin
+            shapes[f"{p}.emb_gain"] = ()
+            shapes[f"{p}.conv_res0.weight"] = (cout * mm, res0_in // g, 3, 3)
+            shapes[f"{p}.conv_res1.weight"] = (cout, cout * mm // g, 3, 3)
+            if cin != cout:
+                shapes[f"{p}.conv_skip.weight"] = (cout, cin, 1, 1)
+            shapes[f"{p}.emb_linear.weight"] = (cout * mm, cemb // g)
+            if st["attention"]:
+                shapes[f"{p}.emb_gain_qk"] = ()
+                shapes[f"{p}.emb_gain_v"] = ()
+                shapes[f"{p}.emb_linear_qk.weight"] = (cout, cemb, 1, 1)
+                shapes[f"{p}.emb_linear_v.weight"] = (cout, cemb, 1, 1)
+                shapes[f"{p}.attn_qk.weight"] = (cout * 2, cout, 1, 1)
+                shapes[f"{p}.attn_v.weight"] = (cout, cout, 1, 1)
+                shapes[f"{p}.attn_proj.weight"] = (cout, cout, 1, 1)
+    shapes["conv_latents_out.weight"] = (cfg["latent_channels"], topo["c_lat"], 3, 3)
+    shapes["conv_latents_in.weight"] = (topo["c_lat"], cfg["latent_channels"] + 2, 3, 3)
+    shapes["conv_out.weight"] = (cfg["out_channels"], topo["cout_last"], 3, 3)
+    return shapes
+
+
+def random_vae_state(cfg: dict, seed: int, gain_value: float = 0.7) -> dict:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape in sorted(vae_param_shapes(cfg).items()):
+        if shape == ():
+            sd[key] = torch.tensor(gain_value)
+        elif key in ("recon_loss_logvar", "latents_logvar"):
+            sd[key] = torch.zeros(1)
+        else:
+            sd[key] = rms_normalize(torch.randn(shape, generator=g))
+    return sd
+
+
+def vae_block_forward(sd: dict, prefix: str, x: torch.Tensor, emb: torch.Tensor, *, flavor: str, resample: str, groups: int,
+                      res_balance: float = 0.3, clip: Optional[float] = 256.0, training: bool = False) -> torch.Tensor:
+    """modules/old/vaes/vae_edm2.py:96-156 without attention: like the UNet block, but the skip conv exists only when the
+    channel count changes (:84) and emb_linear is a plain linear on the (B, cemb) embedding (:87-88, :111-112)."""
+    skip = sd.get(f"{prefix}.conv_skip.weight")
+    x = resample2x(x, resample)
+    if flavor == "enc":
+        if skip is not None:
+            x = conv_mp(x, skip, training=training)
+        x = rms_normalize(x, dims=[1])
+    y = conv_mp(silu_mp(x), sd[f"{prefix}.conv_res0.weight"], groups=groups, training=training)
+    c = conv_mp(emb, sd[f"{prefix}.emb_linear.weight"], gain=sd[f"{prefix}.emb_gain"], training=training) + 1.0
+    y = silu_mp(y * c[:, :, None, None])
+    y = conv_mp(y, sd[f"{prefix}.conv_res1.weight"], groups=groups, training=training)
+    if flavor == "dec" and skip is not None:
+        x = conv_mp(x, skip, training=training)
+    x = sum_mp(x, y, res_balance)
+    return x.clamp(-clip, clip) if clip is not None else x
+
+
+def vae_embeddings(sd: dict, labels_like: torch.Tensor) -> torch.Tensor:
+    """vae_edm2.py:230-239 with the random draw injected: mp_silu(emb_label(normalize(labels_like)))."""
+    return silu_mp(conv_mp(rms_normalize(labels_like.float()), sd["emb_label.weight"]))
+
+
+def vae_encode(sd: dict, cfg: dict, x: torch.Tensor, emb: torch.Tensor, freq_range=(20.0, 16000.0), training: bool = False):
+    """vae_edm2.py:259-269: returns (latent mean, constant noise logvar)."""
+    topo = vae_topology(cfg)
+    b, _, h, w = x.shape
+    x = torch.cat([x, torch.ones_like(x[:, :1]), ln_freq_channel(h, w, b, *freq_range)], dim=1)
+    for st in topo["enc"]:
+        if st["kind"] == "conv_in":
+            x = conv_mp(x, sd["enc.conv_in.weight"], training=training)
+        else:
+            x = vae_block_forward(sd, f"enc.{st['name']}", x, emb, flavor="enc", resample=st["resample"], groups=cfg["mlp_groups"],
+                                  res_balance=cfg["res_balance"], training=training)
+    mean = conv_mp(x, sd["conv_latents_out.weight"], gain=sd["latents_out_gain"], training=training)
+    return mean, math.log(1 / (cfg["target_snr"] ** 2 + 1))
+
+
+def vae_decode(sd: dict, cfg: dict, z: torch.Tensor, emb: torch.Tensor, freq_range=(20.0, 16000.0), training: bool = False) -> torch.Tensor:
+    """vae_edm2.py:271-279."""
+    topo = vae_topology(cfg)
+    b, _, h, w = z.shape
+    x = torch.cat([z, torch.ones_like(z[:, :1]), ln_freq_channel(h, w, b, *freq_range)], dim=1)
+    x = conv_mp(x, sd["conv_latents_in.weight"], training=training)
+    for st in topo["dec"]:
+        x = vae_block_forward(sd, f"dec.{st['name']}", x, emb, flavor="dec", resample=st["resample"], groups=cfg["mlp_groups"],
+                              res_balance=cfg["res_balance"], training=training)
+    return conv_mp(x, sd["conv_out.weight"], gain=sd["out_gain"], training=training)

@@ -99,3 +99,49 @@ def test_unet_state_dict_keys_and_normalize_weights():
         assert rel_l2(got[k], O.rms_normalize(sd[k])) < 1e-6, k
     # logvar_linear has weight-norm disabled (unet_edm2_b4.py:187)
     assert rel_l2(got["logvar_linear.weight"], sd["logvar_linear.weight"]) < 1e-7
+
+
+def test_vae_encode_decode_fp32_and_bf16():
+    """AutoencoderKL_EDM2 on the HIP kernels against the reference's encode/decode (tests/golden/vae_small)."""
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    from dualdiffusion_amd.modules.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config
+    t, m = load_golden("vae_small")
+    cfg = O.vae_cfg(**m["cfg"])
+    sd = O.random_vae_state(cfg, m["seed"])
+
+    class Fmt:
+        fs = FrequencyScale("mel", *m["freq_range"], 32000, 3201, 256)
+
+        def get_ln_freqs(self, x):
+            ln = self.fs.get_unscaled(x.shape[2] + 2, device=x.device)[1:-1].log2()
+            ln = ln.view(1, 1, -1, 1).repeat(x.shape[0], 1, 1, x.shape[3])
+            return ((ln - ln.mean()) / ln.std()).to(x.dtype)
+
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 3e-2)):
+        vae = AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**m["cfg"])).requires_grad_(False).train(False)
+        assert set(vae.state_dict().keys()) == set(O.vae_param_shapes(cfg).keys())
+        vae.load_state_dict(sd)
+        vae = vae.to(device="cuda", dtype=dtype)
+        with torch.no_grad():
+            emb = vae.get_embeddings(t["labels_like"], labels_like=t["labels_like"])
+            assert rel_l2(emb, t["emb"]) < (1e-5 if dtype == torch.float32 else 1e-2)
+            dist = vae.encode(t["x"].cuda(), t["emb"].cuda(), Fmt())
+            rec = vae.decode(t["latents"].cuda(), t["emb"].cuda(), Fmt())
+        e1, e2 = rel_l2(dist.mode(), t["latents"]), rel_l2(rec, t["recon"])
+        print(f"vae {dtype}: encode {e1:.3e} decode {e2:.3e}")
+        assert e1 < tol and e2 < tol
+        assert abs(float(dist.logvar) - float(t["noise_logvar"])) < 1e-6
+        assert tuple(vae.get_latent_shape(t["x"].shape)) == (2, 4, 8, 12) and tuple(vae.get_sample_shape((2, 4, 8, 12))) == (2, 2, 32, 48)
+
+
+def test_resample2d():
+    from dualdiffusion_amd import _lib as L
+    from dualdiffusion_amd import ops
+    from tests.util import to_nchw, to_nhwc
+    x = torch.randn(2, 16, 6, 10, generator=torch.Generator().manual_seed(0))
+    for dt in (torch.float32, torch.bfloat16):
+        xr = x.to(dt).float()
+        up = ops.resample2d(to_nhwc(xr, dt), torch.empty(2, 12, 20, 16, device="cuda", dtype=dt), L.RESAMPLE_UP)
+        assert torch.equal(to_nchw(up), O.resample2x(xr, "up"))
+        dn = ops.resample2d(to_nhwc(xr, dt), torch.empty(2, 3, 5, 16, device="cuda", dtype=dt), L.RESAMPLE_DOWN)
+        assert rel_l2(to_nchw(dn), O.resample2x(xr, "down")) < (1e-6 if dt == torch.float32 else 4e-3)

@@ -113,3 +113,13 @@ def test_host_schedules_match_oracle():
     got = SamplingSchedule.get_schedule("edm2", 100, sigma_max=200.0, sigma_min=0.03, rho=7.0)
     assert torch.equal(got, ref)
     assert set(SamplingSchedule.get_schedules_list()) == {"edm2", "ln_linear", "linear", "cos", "scale_invariant"}
+
+
+def test_vae_golden():
+    t, m = load_golden("vae_small")
+    cfg = O.vae_cfg(**m["cfg"])
+    sd = O.random_vae_state(cfg, m["seed"])
+    assert rel_l2(O.vae_embeddings(sd, t["labels_like"]), t["emb"]) < TOL
+    mean, logvar = O.vae_encode(sd, cfg, t["x"], t["emb"], tuple(m["freq_range"]))
+    assert rel_l2(mean, t["latents"]) < 1e-5 and abs(logvar - float(t["noise_logvar"])) < 1e-6
+    assert rel_l2(O.vae_decode(sd, cfg, t["latents"], t["emb"], tuple(m["freq_range"])), t["recon"]) < 1e-5

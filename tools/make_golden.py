@@ -332,7 +332,58 @@ def gen_sampler() -> None:
                             num_steps=4, sigma_max=80.0, sigma_min=0.05))
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler}
+def gen_vae() -> None:
+    """AutoencoderKL_EDM2 (modules/old/vaes/vae_edm2.py) encode / decode on a small mel-shaped input."""
+    print("vae")
+    ref_import.install_old_vae()
+    from modules.old.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config
+    from modules.formats.frequency_scale import FrequencyScale
+    cfg = O.vae_cfg(model_channels=32, channel_mult=(1, 2, 3), num_layers_per_block=1, label_dim=24, target_snr=31.98)
+    ref = AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}))
+    ref = ref.requires_grad_(False).train(False)
+    shapes = O.vae_param_shapes(cfg)
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}, "vae param shapes differ"
+    sd = O.random_vae_state(cfg, seed=21)
+    ref.load_state_dict(sd)
+
+    class Fmt:
+        fs = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+        def get_ln_freqs(self, x):
+            ln = self.fs.get_unscaled(x.shape[2] + 2, device=x.device)[1:-1].log2()
+            ln = ln.view(1, 1, -1, 1).repeat(x.shape[0], 1, 1, x.shape[3])
+            return ((ln - ln.mean()) / ln.std()).to(x.dtype)
+
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 2, 32, 48, generator=g)
+    labels_like = torch.randn(2, cfg["label_dim"], generator=g)     # stands for the randn_like draw of get_embeddings
+    with torch.no_grad():
+        emb = R_silu(ref.emb_label(R_normalize(labels_like)))
+        dist = ref.encode(x, emb, Fmt())
+        z = dist.mode()
+        rec = ref.decode(z, emb, Fmt())
+    check("vae embeddings", O.vae_embeddings(sd, labels_like), emb)
+    mean, logvar = O.vae_encode(sd, cfg, x, emb)
+    check("vae encode", mean, z, 1e-5)
+    assert abs(float(dist.logvar) - logvar) < 1e-6
+    check("vae decode", O.vae_decode(sd, cfg, z, emb), rec, 1e-5)
+    assert tuple(ref.get_latent_shape(x.shape)) == (2, 4, 8, 12) and tuple(ref.get_sample_shape(z.shape)) == (2, 2, 32, 48)
+    save("vae_small", {"x": x, "labels_like": labels_like, "emb": emb, "latents": z, "recon": rec,
+                       "noise_logvar": torch.tensor(float(dist.logvar))},
+         dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, seed=21, freq_range=[20.0, 16000.0]))
+
+
+def R_silu(x):
+    from modules.mp_tools import mp_silu
+    return mp_silu(x)
+
+
+def R_normalize(x):
+    from modules.mp_tools import normalize
+    return normalize(x)
+
+
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
