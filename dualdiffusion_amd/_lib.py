@@ -41,6 +41,13 @@ class ConvDesc(C.Structure):
                 ("dtype", C.c_int32), ("force_direct", C.c_int32)]
 
 
+class MelStftDesc(C.Structure):
+    _fields_ = [("audio", C.c_void_p), ("window", C.c_void_p), ("twiddle", C.c_void_p), ("band_start", C.c_void_p),
+                ("band_len", C.c_void_p), ("band_w", C.c_void_p), ("out", C.c_void_p),
+                ("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("T", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
+                ("n_mel", C.c_int32), ("band_stride", C.c_int32), ("exponent", C.c_float), ("mean", C.c_float), ("scale", C.c_float)]
+
+
 class LinearJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("gain_ptr", C.c_void_p), ("out", C.c_void_p), ("gain", C.c_float),
                 ("add_const", C.c_float), ("O", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
@@ -70,6 +77,7 @@ PROTOTYPES = {
                                       C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_unet_output_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_mel_stft": (C.c_int, [C.POINTER(MelStftDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddx_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

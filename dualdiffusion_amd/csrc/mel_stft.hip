@@ -1,0 +1,121 @@
+// Fused mel-STFT: audio -> framed, windowed FFT (n_fft 6400) -> |.| -> banded mel filter bank -> ^exponent -> affine.
+//
+// Replaces the encode half of the reference's SpectrogramFormat (src/modules/formats/old/spectrogram.py:176-179,217-226:
+// torchaudio Spectrogram == torch.stft(center=True, reflect, onesided, hann^32 window), `.abs()`,
+// FrequencyScale.scale = dense (3201 x 256) matmul (src/modules/formats/frequency_scale.py:127-128), `** 0.25`,
+// `(x - sample_mean) * raw_to_sample_scale`).  What is different here:
+//   * the complex STFT (282 MB per 45 s stereo sample) never exists in HBM: one workgroup transforms a frame in LDS
+//     (mixed-radix Stockham, fft_lds.hpp) and reduces it to 256 mel values on the spot;
+//   * stereo rides in ONE complex FFT: z = left + i*right, |X_L[k]| = |Z[k] + conj(Z[N-k])|/2, |X_R[k]| = |Z[k] - conj(Z[N-k])|/2;
+//   * the mel filter bank is applied as what it is -- 256 contiguous bands of 3..80 bins (integer start/length per
+//     filter, bit-exact with the reference's non-zero support) -- not as a dense matmul (130x fewer FLOPs);
+//   * FPW consecutive frames per workgroup so that the (B, C, n_mel, T) output is written in 4*FPW-byte runs.
+// HBM-bound by design: algorithmic bytes = audio in (each sample is re-read by n_fft/hop = 25 overlapping frames, from L2)
+// + mel out.
+#include "fft_lds.hpp"
+
+namespace ddx {
+
+constexpr int kFPW = 8;      // frames per workgroup
+constexpr int kNT = 256;
+
+struct MelStftParams {
+  const float* audio; const float* window; const float2* tw;
+  const int* bstart; const int* blen; const float* bw;
+  float* out;
+  int B, C, L, T, hop, n_mel, bstride;
+  float exponent, mean, scale;
+};
+
+__device__ __forceinline__ int reflect_index(int j, int L) {
+  // torch.stft(center=True, pad_mode="reflect"): mirror without repeating the edge sample
+  if (j < 0) j = -j;
+  if (j >= L) j = 2 * (L - 1) - j;
+  return j;
+}
+
+template <int N>
+__global__ __launch_bounds__(kNT) void mel_stft_kernel(const MelStftParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* bufA = reinterpret_cast<cf*>(smem);
+  cf* bufB = bufA + N;
+  float* sOut = reinterpret_cast<float*>(bufB + N);   // [C * n_mel][kFPW]
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * kFPW;
+  const int tid = threadIdx.x;
+  const float* aL = p.audio + (size_t)b * p.C * p.L;
+  const float* aR = p.C > 1 ? aL + p.L : nullptr;
+  const int NB = N / 2 + 1;
+
+  for (int fi = 0; fi < kFPW; ++fi) {
+    const int f = f0 + fi;
+    if (f >= p.T) break;  // uniform
+    // ---- frame load: z[n] = w[n] * (left + i*right), reflect padded by N/2
+    const int base = f * p.hop - N / 2;
+    for (int n = tid; n < N; n += kNT) {
+      const int j = reflect_index(base + n, p.L);
+      const float w = p.window[n];
+      bufA[n] = cf{aL[j] * w, aR ? aR[j] * w : 0.f};
+    }
+    fft6400<false, kNT>(bufA, bufB, p.tw);  // result in bufA
+    // ---- magnitudes of both channels -> bufB (as floats)
+    float* mag = reinterpret_cast<float*>(bufB);
+    for (int k = tid; k < NB; k += kNT) {
+      const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
+      const cf sl = cadd(zk, zn), sr = csub(zk, zn);
+      mag[k] = 0.5f * sqrtf(sl.x * sl.x + sl.y * sl.y);
+      mag[NB + k] = 0.5f * sqrtf(sr.x * sr.x + sr.y * sr.y);
+    }
+    __syncthreads();
+    // ---- banded mel filter bank, exponent, affine
+    for (int o = tid; o < p.C * p.n_mel; o += kNT) {
+      const int ch = o / p.n_mel, m = o - ch * p.n_mel;
+      const float* mg = mag + ch * NB + p.bstart[m];
+      const float* wv = p.bw + (size_t)m * p.bstride;
+      float acc = 0.f;
+      for (int i = 0; i < p.blen[m]; ++i) acc += mg[i] * wv[i];
+      float v = (p.exponent == 0.25f) ? sqrtf(sqrtf(acc)) : powf(acc, p.exponent);
+      sOut[o * kFPW + fi] = (v - p.mean) * p.scale;
+    }
+    __syncthreads();
+  }
+  // ---- write the FPW frames of every (channel, mel) row as one run
+  const int nf = min(kFPW, p.T - f0);
+  for (int idx = tid; idx < p.C * p.n_mel * kFPW; idx += kNT) {
+    const int o = idx / kFPW, fi = idx - o * kFPW;
+    if (fi < nf) p.out[((size_t)b * p.C * p.n_mel + o) * p.T + f0 + fi] = sOut[idx];
+  }
+}
+
+}  // namespace ddx
+
+using namespace ddx;
+
+extern "C" int ddx_mel_stft(const ddx_melstft_desc* dp, ddx_stream stream) {
+  if (!dp) return set_error(DDX_ERR_ARG, "mel_stft: null descriptor");
+  const ddx_melstft_desc d = *dp;
+  if (!d.audio || !d.window || !d.twiddle || !d.band_start || !d.band_len || !d.band_w || !d.out)
+    return set_error(DDX_ERR_ARG, "mel_stft: null buffer");
+  if (d.B <= 0 || (d.C != 1 && d.C != 2) || d.L <= 0 || d.T <= 0 || d.hop <= 0 || d.n_mel <= 0 || d.band_stride <= 0)
+    return set_error(DDX_ERR_ARG, "mel_stft: bad size");
+  if (d.n_fft != 6400) return set_error(DDX_ERR_UNSUPPORTED, "mel_stft: only n_fft = 6400 is built");
+  if (d.L <= d.n_fft / 2) return set_error(DDX_ERR_ARG, "mel_stft: audio shorter than the reflect padding");
+  MelStftParams p{d.audio, d.window, reinterpret_cast<const float2*>(d.twiddle), d.band_start, d.band_len, d.band_w, d.out,
+                  d.B, d.C, d.L, d.T, d.hop, d.n_mel, d.band_stride, d.exponent, d.mean, d.scale};
+  return dispatch([p](hipStream_t s) -> int {
+    constexpr int N = 6400;
+    const size_t smem = 2 * (size_t)N * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
+    if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "mel_stft: too many mel bands for LDS");
+    auto kern = mel_stft_kernel<N>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(mel_stft)");
+      attr_done = true;
+    }
+    dim3 grid((p.T + kFPW - 1) / kFPW, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(kNT), smem, s, p);
+    return check_launch("mel_stft");
+  }, stream, "mel_stft", 5.0 * 6400 * 12.64 * p.T * p.B,
+     4.0 * ((double)p.B * p.C * p.L + (double)p.B * p.C * p.n_mel * p.T));
+}

@@ -1,0 +1,149 @@
+"""mel-spectrogram audio format on the HIP kernels.
+
+Drop-in for reference src/modules/formats/old/spectrogram.py (`SpectrogramFormat`, named `modules.formats.spectrogram`
+by the default model_index.json): same config fields and method signatures.  `raw_to_sample` is ONE fused kernel
+(ddx_mel_stft); constant tables (window, twiddles, mel bands) are built on the host exactly as the reference builds them
+and uploaded once.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ... import _lib as L
+from ..._lib import DDXError, check, current_stream, lib, ptr
+from .format import DualDiffusionFormat, DualDiffusionFormatConfig
+from .frequency_scale import FrequencyScale
+
+
+@dataclass
+class SpectrogramFormatConfig(DualDiffusionFormatConfig):
+    raw_to_sample_scale: float = 2.247
+    sample_to_raw_scale: float = 0.445
+    sample_mean: float = 1.295
+    abs_exp1_scale: float = 0.008
+    abs_exp1_mel_density: bool = False
+    unscaled_psd_scale: float = 0.625
+    unscaled_psd_mel_density: bool = False
+    unscaled_psd_num_fft_bins: int = 3328
+    unscaled_psd_rectify: bool = True
+    abs_exponent: float = 0.25
+    step_size_ms: int = 8
+    window_duration_ms: int = 200
+    padded_duration_ms: int = 200
+    window_exponent: float = 32
+    window_periodic: bool = True
+    freq_scale_type: str = "mel"
+    num_frequencies: int = 256
+    min_frequency: int = 20
+    max_frequency: int = 16000
+    freq_scale_norm: Optional[str] = None
+    num_fgla_iters: int = 200
+    fgla_momentum: float = 0.99
+    stereo_coherence: float = 0.67
+
+    @property
+    def stereo(self) -> bool:
+        return self.sample_raw_channels == 2
+
+    @property
+    def padded_length(self) -> int:
+        return int(self.padded_duration_ms / 1000.0 * self.sample_rate)
+
+    @property
+    def win_length(self) -> int:
+        return int(self.window_duration_ms / 1000.0 * self.sample_rate)
+
+    @property
+    def hop_length(self) -> int:
+        return int(self.step_size_ms / 1000.0 * self.sample_rate)
+
+    @property
+    def num_stft_bins(self) -> int:
+        return self.padded_length // 2 + 1
+
+
+def fft_twiddles(n: int) -> torch.Tensor:
+    """(n, 2) float32 table of exp(-2 pi i k / n), evaluated in float64."""
+    k = torch.arange(n, dtype=torch.float64) * (2.0 * math.pi / n)
+    return torch.stack([torch.cos(k), -torch.sin(k)], dim=1).to(torch.float32).contiguous()
+
+
+class SpectrogramFormat(DualDiffusionFormat):
+
+    config_class = SpectrogramFormatConfig
+
+    def __init__(self, config: SpectrogramFormatConfig) -> None:
+        super().__init__()
+        self.config = config
+        if config.win_length != config.padded_length:
+            raise DDXError("the HIP mel-STFT is built for win_length == n_fft (the reference default: 200 ms / 200 ms)")
+        self.freq_scale = FrequencyScale(config.freq_scale_type, config.min_frequency, config.max_frequency, config.sample_rate,
+                                         config.num_stft_bins, config.num_frequencies, config.freq_scale_norm)
+        # window exactly as the reference: hann(win, periodic) ** exponent in float32 (spectrogram.py:99-104)
+        self.register_buffer("window", torch.hann_window(config.win_length, periodic=config.window_periodic) ** config.window_exponent,
+                             persistent=False)
+        self.register_buffer("twiddle", fft_twiddles(config.padded_length), persistent=False)
+        edges = self.freq_scale.band_edges()
+        fb = self.freq_scale.filters
+        start, length = edges[:, 0].clone(), (edges[:, 1] - edges[:, 0] + 1)
+        empty = length <= 0
+        start[empty], length[empty] = 0, 0
+        stride = int((int(length.max()) + 3) // 4 * 4)
+        bw = torch.zeros(config.num_frequencies, stride)
+        for m in range(config.num_frequencies):
+            n = int(length[m])
+            bw[m, :n] = fb[int(start[m]):int(start[m]) + n, m]
+        self.register_buffer("band_start", start.to(torch.int32).contiguous(), persistent=False)
+        self.register_buffer("band_len", length.to(torch.int32).contiguous(), persistent=False)
+        self.register_buffer("band_w", bw.contiguous(), persistent=False)
+
+    # ---- geometry (reference spectrogram.py:164-174, 203-215)
+    def _spec_frames(self, audio_len: int) -> int:
+        c = self.config
+        return 1 + (audio_len + c.padded_length - c.win_length) // c.hop_length
+
+    def sample_raw_crop_width(self, length: Optional[int] = None) -> int:
+        c = self.config
+        frames = self._spec_frames(length or c.sample_raw_length) // 128 * 128
+        return (frames - 1) * c.hop_length + c.win_length - c.padded_length
+
+    def get_sample_shape(self, bsz: int = 1, length: Optional[int] = None) -> tuple:
+        c = self.config
+        return (bsz, c.sample_raw_channels, c.num_frequencies, self._spec_frames(self.sample_raw_crop_width(length)))
+
+    @torch.no_grad()
+    def get_ln_freqs(self, x: torch.Tensor) -> torch.Tensor:
+        """reference spectrogram.py:240-244 (host table; the modules upload the per-row values once per shape)."""
+        ln = self.freq_scale.get_unscaled(x.shape[2] + 2, device="cpu")[1:-1].log2()
+        ln = ln.view(1, 1, -1, 1).repeat(x.shape[0], 1, 1, x.shape[3])
+        return ((ln - ln.mean()) / ln.std()).to(x.dtype)
+
+    @property
+    def ms_freq_scale(self) -> FrequencyScale:   # what UNet.get_ln_freqs reads (unet_edm2_b4.py:246)
+        return self.freq_scale
+
+    # ---- encode
+    @torch.no_grad()
+    def raw_to_sample(self, raw_samples: torch.Tensor) -> torch.Tensor:
+        """(B, C, L) audio -> (B, C, n_mel, T) mel-spectrogram samples (reference spectrogram.py:217-226)."""
+        if self.device.type != "cuda":
+            raise DDXError("SpectrogramFormat is not on a ROCm device: no CPU fallback")
+        c = self.config
+        x = raw_samples.to(device=self.device, dtype=torch.float32).contiguous()
+        B, Cn, Ln = x.shape
+        T = self._spec_frames(Ln)
+        out = torch.empty(B, Cn, c.num_frequencies, T, device=self.device, dtype=torch.float32)
+        d = L.MelStftDesc(audio=ptr(x), window=ptr(self.window), twiddle=ptr(self.twiddle), band_start=ptr(self.band_start),
+                          band_len=ptr(self.band_len), band_w=ptr(self.band_w), out=ptr(out), B=B, C=Cn, L=Ln, T=T,
+                          n_fft=c.padded_length, hop=c.hop_length, n_mel=c.num_frequencies, band_stride=self.band_w.shape[1],
+                          exponent=c.abs_exponent, mean=c.sample_mean, scale=c.raw_to_sample_scale)
+        check(lib().ddx_mel_stft(C.byref(d), current_stream()), "mel_stft")
+        return out
+
+    def sample_to_raw(self, samples: torch.Tensor, n_fgla_iters: Optional[int] = None, quiet: bool = False) -> torch.Tensor:
+        raise NotImplementedError("FGLA phase reconstruction on the HIP path is not built yet")

@@ -168,6 +168,27 @@ int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, i
 int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused mel-STFT  (modules/formats/old/spectrogram.py:176-179,217-226 == torch.stft(center, reflect, onesided) -> abs ->
+ * FrequencyScale.scale (modules/formats/frequency_scale.py:127-128) -> ** abs_exponent -> (x - mean) * scale).
+ *   audio [B][C][L] fp32 (C = 1 or 2) -> out [B][C][n_mel][T] fp32, T = 1 + L / hop frames.
+ *   window [n_fft] (hann^32 etc., as the reference builds it), twiddle [n_fft] = (cos, -sin)(2 pi k / n_fft),
+ *   mel filters as contiguous bands: filter m = band_w[m][0..band_len[m]) applied to bins band_start[m]...
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* audio;
+  const float* window;
+  const float* twiddle;       /* n_fft (re, im) pairs */
+  const int32_t* band_start;  /* [n_mel] first STFT bin of each filter */
+  const int32_t* band_len;    /* [n_mel] number of bins */
+  const float* band_w;        /* [n_mel][band_stride] */
+  float* out;
+  int32_t B, C, L, T, n_fft, hop, n_mel, band_stride;
+  float exponent, mean, scale;
+} ddx_melstft_desc;
+
+int ddx_mel_stft(const ddx_melstft_desc* d, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Launch plans: a recorded sequence of the calls above, replayed with one FFI call and optionally
  * as a hipGraph (the MI355X replacement for the reference's torch.compile, modules/module.py:145-149).
  * Recording: between ddx_plan_begin() and ddx_plan_end() every entry point above is recorded into

@@ -123,3 +123,17 @@ def test_vae_golden():
     mean, logvar = O.vae_encode(sd, cfg, t["x"], t["emb"], tuple(m["freq_range"]))
     assert rel_l2(mean, t["latents"]) < 1e-5 and abs(logvar - float(t["noise_logvar"])) < 1e-6
     assert rel_l2(O.vae_decode(sd, cfg, t["latents"], t["emb"], tuple(m["freq_range"])), t["recon"]) < 1e-5
+
+
+def test_mel_golden_and_band_edges():
+    """mel-STFT oracle against the reference output; the integer band-edge table is bit-exact."""
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    t, m = load_golden("mel_stft")
+    fb = M.mel_filterbank(3201, 256, 20.0, 16000.0, 32000)
+    mel = M.raw_to_mel(t["audio"], window=M.hann_power_window(6400, 32.0), hop=256, filters=fb)
+    assert rel_l2(mel, t["mel"]) < 2e-5
+    assert int((fb > 0).sum()) == m["nnz"] and torch.equal(fb.sum(dim=0), t["filter_colsum"])
+    host = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+    assert torch.equal(host.band_edges(), t["band_edges"])          # product-side table == reference non-zero support
+    assert torch.equal(host.filters, fb)

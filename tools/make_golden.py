@@ -373,6 +373,42 @@ def gen_vae() -> None:
          dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, seed=21, freq_range=[20.0, 16000.0]))
 
 
+def make_ref_format():
+    import importlib
+    mod = importlib.import_module("modules.formats.old.spectrogram")
+    cfg = mod.SpectrogramFormatConfig()
+    cfg.sample_raw_channels, cfg.sample_raw_length = 2, 1440000      # stale base config no longer declares them
+    return mod.SpectrogramFormat(cfg), cfg
+
+
+def gen_mel() -> None:
+    """SpectrogramFormat.raw_to_sample (mel-STFT) on short stereo noise + the integer band-edge table."""
+    print("mel")
+    from oracle import mel_oracle as M
+    fmt, cfg = make_ref_format()
+    g = torch.Generator().manual_seed(31)
+    audio = torch.randn(2, 2, 32512, generator=g) * 0.1
+    audio[1] *= torch.linspace(0.1, 2.0, 32512)                       # some dynamics
+    with torch.no_grad():
+        mel = fmt.raw_to_sample(audio)
+    fb = fmt.spectrogram_converter.freq_scale.filters
+    win = fmt.spectrogram_converter.spectrogram_func.window
+    assert torch.equal(M.hann_power_window(6400, 32.0), win)
+    ofb = M.mel_filterbank(3201, 256, 20.0, 16000.0, 32000)
+    assert torch.equal(ofb, fb), "filter bank differs"
+    ours = M.raw_to_mel(audio, window=win, hop=256, filters=ofb)
+    check("raw_to_mel", ours, mel, 2e-5)
+    nz = fb > 0
+    idx = torch.arange(3201).unsqueeze(1)
+    first = torch.where(nz, idx, 3201).min(dim=0).values
+    last = torch.where(nz, idx, -1).max(dim=0).values
+    edges = torch.stack([first, last], 1).to(torch.int32)
+    assert tuple(mel.shape) == (2, 2, 256, 128)
+    assert fmt.sample_raw_crop_width() == 1408768 and tuple(fmt.get_sample_shape(bsz=3)) == (3, 2, 256, 5504)
+    save("mel_stft", {"audio": audio, "mel": mel, "band_edges": edges, "filter_colsum": fb.sum(dim=0)},
+         dict(n_fft=6400, hop=256, nnz=int(nz.sum())))
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -383,7 +419,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
