@@ -1,0 +1,218 @@
+// FGLA (fast Griffin-Lim with momentum) stereo phase reconstruction: the decode half of the reference's
+// SpectrogramFormat (src/modules/formats/old/phase_recovery.py:39-129 `griffinlim`, driven by spectrogram.py:181-185).
+//
+// Per iteration the reference does: lerp(merged, spec, t) -> angles*mags -> torch.istft -> torch.stft -> angles =
+// rebuilt.sub_(tprev, alpha=m) -> angles /= (|angles| + 1e-16) -> tprev = rebuilt, i.e. ~8 full passes over (2B, 3201, T)
+// complex64 tensors.  NB the subtraction is in place on the tensor that becomes tprev (phase_recovery.py:110-119), so the
+// carried state is u_i = rebuilt_i - m*u_{i-1} and angles_i = u_i / (|u_i| + 1e-16): ONE full-size state tensor.
+// Here one iteration is three kernels:
+//   synth    : per frame, angles are re-derived on the fly from u, multiplied by the (stereo-annealed) magnitudes,
+//              both channels packed as Z = X_L + i X_R, ONE inverse FFT-6400 in LDS, windowed frame written out;
+//   ola      : overlap-add of the 25 frames covering each sample + division by the window envelope (torch.istft);
+//   analysis : reflect-padded frame * window, forward FFT-6400, unpack both channels, u <- rebuilt - m*u in place.
+// Spectra are stored frame-major [B][T][C][n_fft/2+1] complex (the reference's [freq][time] order would make every
+// frame access strided).  HBM-bound: per iteration and sample ~2*282 MB + 141 MB read, 282 MB written for the state,
+// plus the 282 MB frame buffer round trip.
+#include "fft_lds.hpp"
+
+namespace ddx {
+
+constexpr int kFN = 6400;
+constexpr int kFNT = 256;
+
+struct FglaSynthParams {
+  const float2* u;                          // [B][T][C][NB] state (nullptr: angles = 1)
+  const float* mags;                        // [B][C][T][mstride]
+  const float* window; const float2* tw;
+  float* frames;                            // [B][T][C][N]
+  int B, C, T, mstride;
+  float t_lerp;                             // t_lerp <= 0: merged magnitudes; final: the magnitudes themselves
+  int final_pass, stereo_merge;
+};
+
+__global__ __launch_bounds__(kFNT) void fgla_synth_kernel(const FglaSynthParams p) {
+  constexpr int N = kFN, NB = N / 2 + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* bufA = reinterpret_cast<cf*>(smem);
+  cf* bufB = bufA + N;
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const size_t sbase = ((size_t)b * p.T + t) * p.C * NB;
+  for (int k = tid; k < NB; k += kFNT) {
+    cf x[2] = {cf{0.f, 0.f}, cf{0.f, 0.f}};
+    float mg[2] = {0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+      if (ch < p.C) mg[ch] = fmaxf(p.mags[(((size_t)b * p.C + ch) * p.T + t) * p.mstride + k], 0.f);  // relu of the un-mel
+    const float merged = 0.5f * (mg[0] + mg[1]);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      if (ch >= p.C) continue;
+      cf ang = {1.f, 0.f};
+      if (p.u) {
+        const float2 a = p.u[sbase + (size_t)ch * NB + k];
+        const float inv = 1.0f / (sqrtf(a.x * a.x + a.y * a.y) + 1e-16f);
+        ang = cf{a.x * inv, a.y * inv};
+      }
+      float m = mg[ch];
+      if (!p.final_pass && p.stereo_merge) m = p.t_lerp > 0.f ? merged + p.t_lerp * (mg[ch] - merged) : merged;
+      x[ch] = cf{ang.x * m, ang.y * m};
+      if (k == 0 || k == N / 2) x[ch].y = 0.f;  // c2r semantics: DC and Nyquist are real
+    }
+    // Z = X_L + i X_R ;  Z[N-k] = conj(X_L) + i conj(X_R)
+    bufA[k] = cf{x[0].x - x[1].y, x[0].y + x[1].x};
+    if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
+  }
+  fft6400<true, kFNT>(bufA, bufB, p.tw);
+  float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
+  const float invn = 1.0f / (float)N;
+  for (int n = tid; n < N; n += kFNT) {
+    const float w = p.window[n] * invn;
+    fr[n] = bufA[n].x * w;
+    if (p.C > 1) fr[N + n] = bufA[n].y * w;
+  }
+}
+
+// overlap-add + window-envelope normalisation (torch.istft, center=True, length = hop*(T-1))
+__global__ __launch_bounds__(256) void fgla_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
+                                                       float* __restrict__ audio, int B, int C, int T, int hop, int Lout) {
+  constexpr int N = kFN;
+  const size_t total = (size_t)B * C * Lout;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int j = (int)(i % Lout);
+    const int ch = (int)((i / Lout) % C);
+    const int b = (int)(i / ((size_t)Lout * C));
+    const int jp = j + N / 2;
+    int t0 = (jp - N + hop) / hop;  // ceil((jp - N + 1) / hop) for jp - N + 1 > 0
+    if (jp - N + 1 <= 0) t0 = 0;
+    const int t1 = min(jp / hop, T - 1);
+    float acc = 0.f, env = 0.f;
+    for (int t = t0; t <= t1; ++t) {
+      const int n = jp - t * hop;
+      const float w = window[n];
+      acc += frames[(((size_t)b * T + t) * C + ch) * N + n];
+      env += w * w;
+    }
+    audio[i] = acc / env;
+  }
+}
+
+struct FglaAnalysisParams {
+  const float* audio;  // [B][C][L]
+  const float* window; const float2* tw;
+  float2* u;           // [B][T][C][NB] state, updated in place: u = rebuilt - momentum * u
+  int B, C, T, L, hop;
+  float momentum;
+};
+
+__device__ __forceinline__ int reflect_idx(int j, int L) {
+  if (j < 0) j = -j;
+  if (j >= L) j = 2 * (L - 1) - j;
+  return j;
+}
+
+__global__ __launch_bounds__(kFNT) void fgla_analysis_kernel(const FglaAnalysisParams p) {
+  constexpr int N = kFN, NB = N / 2 + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* bufA = reinterpret_cast<cf*>(smem);
+  cf* bufB = bufA + N;
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* aL = p.audio + (size_t)b * p.C * p.L;
+  const float* aR = p.C > 1 ? aL + p.L : nullptr;
+  const int base = t * p.hop - N / 2;
+  for (int n = tid; n < N; n += kFNT) {
+    const int j = reflect_idx(base + n, p.L);
+    const float w = p.window[n];
+    bufA[n] = cf{aL[j] * w, aR ? aR[j] * w : 0.f};
+  }
+  fft6400<false, kFNT>(bufA, bufB, p.tw);
+  float2* ro = p.u + ((size_t)b * p.T + t) * p.C * NB;
+  for (int k = tid; k < NB; k += kFNT) {
+    const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
+    const cf sl = cadd(zk, zn), sr = csub(zk, zn);
+    const float2 ul = ro[k];
+    ro[k] = make_float2(0.5f * sl.x - p.momentum * ul.x, 0.5f * sl.y - p.momentum * ul.y);   // X_L = (Z[k] + conj Z[N-k]) / 2
+    if (p.C > 1) {
+      const float2 ur = ro[NB + k];
+      ro[NB + k] = make_float2(0.5f * sr.y - p.momentum * ur.x, -0.5f * sr.x - p.momentum * ur.y);  // X_R = (Z[k] - conj Z[N-k]) / (2i)
+    }
+  }
+}
+
+// mel samples (B, C, n_mel, T) -> linear mel amplitudes laid out [B*C][T][n_mel] for the un-mel GEMM:
+// amp = clip(x / scale + mean, 0) ** (1 / abs_exponent)   (reference spectrogram.py:232,183)
+__global__ __launch_bounds__(256) void mel_to_amp_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int n_mel, int T,
+                                                         float inv_scale, float mean, float power) {
+  const size_t total = (size_t)rows * n_mel * T;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i % n_mel);
+    const int t = (int)((i / n_mel) % T);
+    const int r = (int)(i / ((size_t)n_mel * T));
+    const float v = fmaxf(x[((size_t)r * n_mel + m) * T + t] * inv_scale + mean, 0.f);
+    y[i] = (power == 4.0f) ? (v * v) * (v * v) : powf(v, power);
+  }
+}
+
+}  // namespace ddx
+
+using namespace ddx;
+
+static int set_fft_smem(const void* kern, bool* done) {
+  if (!*done) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(fgla)");
+    *done = true;
+  }
+  return DDX_OK;
+}
+
+extern "C" int ddx_fgla_synth(const float* u, const float* mags, const float* window, const float* twiddle, float* frames, int32_t B,
+                              int32_t C, int32_t T, int32_t n_fft, int32_t mag_stride, float t_lerp, int32_t final_pass,
+                              ddx_stream stream) {
+  if (!mags || !window || !twiddle || !frames || B <= 0 || (C != 1 && C != 2) || T <= 0) return set_error(DDX_ERR_ARG, "fgla_synth: bad args");
+  if (n_fft != kFN || mag_stride < kFN / 2 + 1) return set_error(DDX_ERR_UNSUPPORTED, "fgla_synth: only n_fft = 6400 is built");
+  FglaSynthParams p{reinterpret_cast<const float2*>(u), mags, window, reinterpret_cast<const float2*>(twiddle), frames, B, C, T,
+                    mag_stride, t_lerp, final_pass, C == 2};
+  return dispatch([p](hipStream_t s) -> int {
+    static bool done = false;
+    if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_synth_kernel), &done)) return rc;
+    hipLaunchKernelGGL(fgla_synth_kernel, dim3(p.T, p.B), dim3(kFNT), 2 * kFN * sizeof(cf), s, p);
+    return check_launch("fgla_synth");
+  }, stream, "fgla_synth");
+}
+
+extern "C" int ddx_fgla_ola(const float* frames, const float* window, float* audio, int32_t B, int32_t C, int32_t T, int32_t n_fft,
+                            int32_t hop, ddx_stream stream) {
+  if (!frames || !window || !audio || B <= 0 || C <= 0 || T <= 1 || hop <= 0) return set_error(DDX_ERR_ARG, "fgla_ola: bad args");
+  if (n_fft != kFN) return set_error(DDX_ERR_UNSUPPORTED, "fgla_ola: only n_fft = 6400 is built");
+  return dispatch([=](hipStream_t s) -> int {
+    const int Lout = hop * (T - 1);
+    const size_t total = (size_t)B * C * Lout;
+    hipLaunchKernelGGL(fgla_ola_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65536)), dim3(256), 0, s, frames, window,
+                       audio, B, C, T, hop, Lout);
+    return check_launch("fgla_ola");
+  }, stream, "fgla_ola");
+}
+
+extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t B, int32_t C,
+                                 int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream) {
+  if (!audio || !window || !twiddle || !u || B <= 0 || (C != 1 && C != 2) || T <= 0 || L <= kFN / 2) return set_error(DDX_ERR_ARG, "fgla_analysis: bad args");
+  if (n_fft != kFN) return set_error(DDX_ERR_UNSUPPORTED, "fgla_analysis: only n_fft = 6400 is built");
+  FglaAnalysisParams p{audio, window, reinterpret_cast<const float2*>(twiddle), reinterpret_cast<float2*>(u), B, C, T, L, hop, momentum};
+  return dispatch([p](hipStream_t s) -> int {
+    static bool done = false;
+    if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_analysis_kernel), &done)) return rc;
+    hipLaunchKernelGGL(fgla_analysis_kernel, dim3(p.T, p.B), dim3(kFNT), 2 * kFN * sizeof(cf), s, p);
+    return check_launch("fgla_analysis");
+  }, stream, "fgla_analysis");
+}
+
+extern "C" int ddx_mel_to_amplitude(const float* mel, float* amp, int32_t rows, int32_t n_mel, int32_t T, float scale, float mean,
+                                    float power, ddx_stream stream) {
+  if (!mel || !amp || rows <= 0 || n_mel <= 0 || T <= 0 || scale == 0.f) return set_error(DDX_ERR_ARG, "mel_to_amplitude: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t total = (size_t)rows * n_mel * T;
+    hipLaunchKernelGGL(mel_to_amp_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65536)), dim3(256), 0, s, mel, amp, rows,
+                       n_mel, T, 1.0f / scale, mean, power);
+    return check_launch("mel_to_amplitude");
+  }, stream, "mel_to_amplitude");
+}

@@ -145,5 +145,53 @@ class SpectrogramFormat(DualDiffusionFormat):
         check(lib().ddx_mel_stft(C.byref(d), current_stream()), "mel_stft")
         return out
 
+    # ---- decode
+    def _unmel_weights(self):
+        """Minimum-norm un-mel operator: the reference solves lstsq(filters^T, mel) per call (frequency_scale.py:130-142);
+        the operator is constant, so its pseudo-inverse is built once (float64) and applied as a 1x1 conv / GEMM."""
+        if getattr(self, "_unmel", None) is None:
+            from ... import ops
+            pinv = torch.linalg.pinv(self.freq_scale.filters.double().t())          # (n_stft, n_mel)
+            nb = self.config.num_stft_bins
+            w = torch.zeros((nb + 3) // 4 * 4, self.config.num_frequencies, 1, 1)
+            w[:nb, :, 0, 0] = pinv.float()
+            wd = w.to(self.device).contiguous()
+            # gain = sqrt(fan_in) cancels the 1/sqrt(fan_in) of the MPConv weight path exactly (256 -> 16/16)
+            self._unmel = ops.wprep(wd, 1, torch.float32, gain=math.sqrt(self.config.num_frequencies), npix=0)
+            self._unmel_keep = wd
+        return self._unmel
+
+    @torch.no_grad()
     def sample_to_raw(self, samples: torch.Tensor, n_fgla_iters: Optional[int] = None, quiet: bool = False) -> torch.Tensor:
-        raise NotImplementedError("FGLA phase reconstruction on the HIP path is not built yet")
+        """(B, C, n_mel, T) mel samples -> (B, C, hop*(T-1)) audio by un-mel + FGLA (reference spectrogram.py:228-238)."""
+        from ... import ops
+        if self.device.type != "cuda":
+            raise DDXError("SpectrogramFormat is not on a ROCm device: no CPU fallback")
+        c = self.config
+        dev, f32 = self.device, torch.float32
+        x = samples.to(device=dev, dtype=f32).contiguous()
+        B, Cn, n_mel, T = x.shape
+        n_iter = n_fgla_iters or c.num_fgla_iters
+        N, hop, nb = c.padded_length, c.hop_length, c.num_stft_bins
+        st = current_stream()
+        amp = torch.empty(B * Cn, 1, T, n_mel, device=dev, dtype=f32)
+        check(lib().ddx_mel_to_amplitude(ptr(x), ptr(amp), B * Cn, n_mel, T, c.raw_to_sample_scale, c.sample_mean,
+                                         1.0 / c.abs_exponent, st), "mel_to_amplitude")
+        mags = ops.conv2d(amp, self._unmel_weights())                          # [B*C][1][T][nb padded to 4], relu applied on read
+        mstride = mags.shape[3]
+        u = torch.zeros(B, T, Cn, nb, 2, device=dev, dtype=f32)   # state: u_i = rebuilt_i - m*u_{i-1} (see fgla.hip)
+        frames = torch.empty(B, T, Cn, N, device=dev, dtype=f32)
+        Lout = hop * (T - 1)
+        audio = torch.empty(B, Cn, Lout, device=dev, dtype=f32)
+        momentum = c.fgla_momentum / (1 + c.fgla_momentum)
+        W, TW = ptr(self.window), ptr(self.twiddle)
+
+        def synth(state, t_lerp, final):
+            check(lib().ddx_fgla_synth(ptr(state), ptr(mags), W, TW, ptr(frames), B, Cn, T, N, mstride, t_lerp, int(final), st), "fgla_synth")
+            check(lib().ddx_fgla_ola(ptr(frames), W, ptr(audio), B, Cn, T, N, hop, st), "fgla_ola")
+
+        for i in range(n_iter):
+            synth(None if i == 0 else u, i / n_iter - c.stereo_coherence, False)   # i == 0: angles = 1 (rand_init False)
+            check(lib().ddx_fgla_analysis(ptr(audio), W, TW, ptr(u), B, Cn, T, Lout, N, hop, momentum, st), "fgla_analysis")
+        synth(u, 0.0, True)                                                         # waveform = istft(angles * specgram)
+        return audio

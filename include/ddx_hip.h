@@ -189,6 +189,28 @@ typedef struct {
 int ddx_mel_stft(const ddx_melstft_desc* d, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * FGLA stereo phase reconstruction  (modules/formats/old/phase_recovery.py:39-129 `griffinlim`; decode half of
+ * SpectrogramFormat.sample_to_raw, spectrogram.py:181-185,228-238).  n_fft = 6400 only.
+ *   mel_to_amplitude : amp[r][t][m] = clip(mel[r][m][t] / scale + mean, 0) ** power      (rows r = B*C; feeds the un-mel GEMM)
+ *   fgla_synth       : frames[b][t][c][n] = window[n] * irfft(angles * mags)[n]; angles = u / (|u| + 1e-16)
+ *                      (u == NULL: angles = 1); mags = relu(un-mel) [B][C][T][mag_stride], stereo anneal
+ *                      lerp(merged, spec, t_lerp) (t_lerp <= 0: merged), final_pass: the magnitudes themselves
+ *   fgla_ola         : audio[b][c][j] = sum_t frames / sum_t window^2        (torch.istft, center trim, length hop*(T-1))
+ *   fgla_analysis    : u[b][t][c][k] <- rfft(window * reflect_pad(audio) frame t)[k] - momentum * u[b][t][c][k]
+ *                      (torch.stft + the in-place `angles.sub_(tprev, alpha=momentum)` whose result the reference keeps
+ *                      as tprev, phase_recovery.py:110-119)
+ * The state u is frame-major [B][T][C][n_fft/2+1] complex64 (re, im pairs), zero before the first iteration.
+ * ------------------------------------------------------------------------------------------------ */
+int ddx_mel_to_amplitude(const float* mel, float* amp, int32_t rows, int32_t n_mel, int32_t T, float scale, float mean,
+                         float power, ddx_stream stream);
+int ddx_fgla_synth(const float* u, const float* mags, const float* window, const float* twiddle, float* frames, int32_t B,
+                   int32_t C, int32_t T, int32_t n_fft, int32_t mag_stride, float t_lerp, int32_t final_pass, ddx_stream stream);
+int ddx_fgla_ola(const float* frames, const float* window, float* audio, int32_t B, int32_t C, int32_t T, int32_t n_fft,
+                 int32_t hop, ddx_stream stream);
+int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t B, int32_t C,
+                      int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Launch plans: a recorded sequence of the calls above, replayed with one FFI call and optionally
  * as a hipGraph (the MI355X replacement for the reference's torch.compile, modules/module.py:145-149).
  * Recording: between ddx_plan_begin() and ddx_plan_end() every entry point above is recorded into

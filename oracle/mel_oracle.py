@@ -51,3 +51,61 @@ def raw_to_mel(audio: torch.Tensor, *, window: torch.Tensor, hop: int, filters: 
     mag = stft_frames(audio, window, hop).abs()
     mel = torch.matmul(mag.transpose(-1, -2), filters).transpose(-1, -2)
     return (mel ** exponent - mean) * scale
+
+
+def istft_frames(spec: torch.Tensor, window: torch.Tensor, hop: int) -> torch.Tensor:
+    """Documented torch.istft(center=True, length=None) semantics: irfft per frame, * window, overlap-add, divide by the
+    overlap-added squared window, trim n_fft/2 on both sides.  spec: (rows, n_fft/2+1, T) complex -> (rows, hop*(T-1))."""
+    n = window.numel()
+    rows, _, T = spec.shape
+    frames = torch.fft.irfft(spec.transpose(-1, -2), n=n, dim=-1) * window                 # (rows, T, n)
+    total = n + hop * (T - 1)
+    y = torch.zeros(rows, total, dtype=window.dtype)
+    env = torch.zeros(total, dtype=window.dtype)
+    for t in range(T):
+        y[:, t * hop:t * hop + n] += frames[:, t]
+        env[t * hop:t * hop + n] += window ** 2
+    return (y / env)[:, n // 2: n // 2 + hop * (T - 1)]
+
+
+def unmel(mel_amp: torch.Tensor, filters: torch.Tensor) -> torch.Tensor:
+    """frequency_scale.py:130-142: minimum-norm solution of filters^T X = mel (lstsq 'gels', full row rank), then relu."""
+    shape = mel_amp.shape
+    m = mel_amp.reshape(-1, shape[-2], shape[-1])
+    x = torch.linalg.lstsq(filters.t()[None], m, driver="gels").solution
+    return torch.relu(x).view(shape[:-2] + (filters.shape[0], shape[-1]))
+
+
+def griffinlim(spec: torch.Tensor, window: torch.Tensor, hop: int, n_iter: int, momentum: float, stereo_coherence: float,
+               dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """phase_recovery.py:39-129 (rand_init False, stereo True): spec (B, 2, n_stft, T) linear magnitudes -> (B, 2, L).
+    `dtype=torch.float64` runs the same iteration in double precision: the iteration re-normalises near-empty bins to unit
+    phasors, which makes the float32 result itself rounding-sensitive (~1 % after one iteration, ~8 % after four on the
+    golden input), so implementations are judged by their distance to the float64 trajectory."""
+    m = momentum / (1 + momentum)
+    shape = spec.shape
+    cdt = torch.complex128 if dtype == torch.float64 else torch.complex64
+    window = window.to(dtype)
+    s = spec.to(dtype).reshape(-1, shape[-2], shape[-1])
+    merged = ((s[0::2] + s[1::2]) / 2).repeat_interleave(2, dim=0)
+    angles = torch.ones(1, shape[-2], shape[-1], dtype=cdt)
+    tprev = torch.zeros((), dtype=cdt)
+    for i in range(n_iter):
+        t = i / n_iter - stereo_coherence
+        mags = merged + t * (s - merged) if t > 0 else merged
+        wave = istft_frames(angles * mags, window, hop)
+        rebuilt = stft_frames(wave, window, hop)
+        # phase_recovery.py:110-119: `angles = rebuilt; angles.sub_(tprev, alpha=momentum)` is IN PLACE on the tensor that
+        # `tprev = rebuilt` then keeps, so the carried state is u_i = rebuilt_i - m * u_{i-1}, not rebuilt_i itself
+        tprev = rebuilt - m * tprev
+        angles = tprev / (tprev.abs() + 1e-16)
+    wave = istft_frames(angles * s, window, hop)
+    return wave.reshape(shape[:-2] + wave.shape[-1:])
+
+
+def mel_to_raw(samples: torch.Tensor, *, window: torch.Tensor, hop: int, filters: torch.Tensor, n_iter: int, exponent: float = 0.25,
+               mean: float = 1.295, scale: float = 2.247, momentum: float = 0.99, stereo_coherence: float = 0.67,
+               dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """spectrogram.py:228-238,181-185: undo the affine + exponent, un-mel, FGLA."""
+    amp = (samples / scale + mean).clip(min=0) ** (1 / exponent)
+    return griffinlim(unmel(amp, filters), window, hop, n_iter, momentum, stereo_coherence, dtype)

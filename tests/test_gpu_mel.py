@@ -40,3 +40,82 @@ def test_mel_linearity_and_silence():
     assert rel_l2(m2, m1 * 2.0) < 1e-4                     # 16 ** 0.25 = 2
     z = fmt.raw_to_sample(torch.zeros(1, 2, 256 * 40))
     assert torch.allclose(z.cpu(), torch.full_like(z.cpu(), -c.sample_mean * c.raw_to_sample_scale), atol=1e-6)
+
+
+def test_fgla_linear_pieces_match_oracle():
+    """The two linear halves of one FGLA iteration through the C ABI, on well-conditioned inputs (unit phasors):
+    synth + overlap-add == torch.istft semantics, analysis == torch.stft semantics (tolerance 2e-5)."""
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd._lib import check, current_stream, lib, ptr
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
+    win = M.hann_power_window(6400, 32.0)
+    g = torch.Generator().manual_seed(11)
+    B, Cn, T, nb = 2, 2, 40, 3201
+    mags = torch.rand(B, Cn, nb, T, generator=g) + 0.1
+    phase = torch.rand(B, Cn, nb, T, generator=g) * 6.28318
+    spec = torch.polar(mags, phase)
+    ref_wave = M.istft_frames(spec.reshape(-1, nb, T), win, 256).reshape(B, Cn, -1)
+    st = current_stream()
+    u = torch.view_as_real(torch.polar(torch.ones_like(mags), phase)).permute(0, 3, 1, 2, 4).contiguous().cuda()   # [B][T][C][nb][2]
+    mg = torch.zeros(B, Cn, T, nb + 3)
+    mg[..., :nb] = mags.permute(0, 1, 3, 2)
+    mg = mg.contiguous().cuda()
+    frames = torch.empty(B, T, Cn, 6400, device="cuda")
+    audio = torch.empty(B, Cn, 256 * (T - 1), device="cuda")
+    check(lib().ddx_fgla_synth(ptr(u), ptr(mg), ptr(fmt.window), ptr(fmt.twiddle), ptr(frames), B, Cn, T, 6400, nb + 3, 0.0, 1, st))
+    check(lib().ddx_fgla_ola(ptr(frames), ptr(fmt.window), ptr(audio), B, Cn, T, 6400, 256, st))
+    e = rel_l2(audio, ref_wave)
+    print(f"istft piece rel-L2 {e:.3e}")
+    assert e < 2e-5
+    # analysis: u <- stft(audio) - momentum * u  (u = known tensor)
+    u0 = torch.randn(B, T, Cn, nb, 2, generator=g)
+    ud = u0.clone().cuda()
+    check(lib().ddx_fgla_analysis(ptr(audio), ptr(fmt.window), ptr(fmt.twiddle), ptr(ud), B, Cn, T, 256 * (T - 1), 6400, 256, 0.25, st))
+    ref_spec = M.stft_frames(ref_wave, win, 256)                                  # (B, C, nb, T)
+    ref_u = torch.view_as_real(ref_spec).permute(0, 3, 1, 2, 4) - 0.25 * u0
+    e = rel_l2(ud, ref_u)
+    print(f"stft piece rel-L2 {e:.3e}")
+    assert e < 2e-5
+
+
+def test_fgla_sample_to_raw_tracks_reference():
+    """un-mel (pseudo-inverse GEMM) + 4 FGLA iterations.  The iteration re-normalises near-empty bins to unit phasors, so
+    the float32 result is rounding-sensitive: the REFERENCE's own float32 output sits ~8 % (rel-L2) from the float64
+    trajectory on this input.  The HIP path must be as close to the float64 trajectory as the reference is (within 1.5x),
+    for both anneal regimes."""
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    t, m = load_golden("mel_stft")
+    g, gm = load_golden("fgla")
+    win, fb = M.hann_power_window(6400, 32.0), M.mel_filterbank(3201, 256, 20.0, 16000.0, 32000)
+    for case, coh in gm["coherence"].items():
+        fmt = SpectrogramFormat(SpectrogramFormatConfig(stereo_coherence=coh)).to(device="cuda")
+        raw = fmt.sample_to_raw(t["mel"][:1], n_fgla_iters=gm["n_iter"], quiet=True)
+        assert raw.shape == g[f"{case}.raw"].shape
+        truth = M.mel_to_raw(t["mel"][:1], window=win, hop=256, filters=fb, n_iter=gm["n_iter"], stereo_coherence=coh, dtype=torch.float64)
+        e_ref, e_gpu = rel_l2(g[f"{case}.raw"], truth), rel_l2(raw, truth)
+        print(f"FGLA {case}: reference-fp32 vs fp64 {e_ref:.3e}, HIP vs fp64 {e_gpu:.3e}")
+        assert e_gpu < 1.5 * e_ref + 1e-3, (case, e_gpu, e_ref)
+        # one iteration is still well inside the linear regime of the error growth: tight check against the float64 run
+        one = fmt.sample_to_raw(t["mel"][:1], n_fgla_iters=1, quiet=True)
+        t1 = M.mel_to_raw(t["mel"][:1], window=win, hop=256, filters=fb, n_iter=1, stereo_coherence=coh, dtype=torch.float64)
+        o1 = M.mel_to_raw(t["mel"][:1], window=win, hop=256, filters=fb, n_iter=1, stereo_coherence=coh)
+        assert rel_l2(one, t1) < 1.5 * rel_l2(o1, t1) + 1e-3
+
+
+def test_fgla_roundtrip_property():
+    """encode -> decode round trip at a longer length: the re-encoded mel of the reconstructed audio stays close to the
+    input mel (FGLA is a magnitude-consistency iteration), and one STFT/iSTFT analysis-synthesis pair is the identity."""
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
+    g = torch.Generator().manual_seed(5)
+    tt = torch.arange(256 * 200) / 32000.0
+    a = (0.1 * torch.sin(2 * torch.pi * 440 * tt) + 0.05 * torch.sin(2 * torch.pi * 1330 * tt))[None, None].repeat(1, 2, 1)
+    a = a + 0.002 * torch.randn(a.shape, generator=g)
+    mel = fmt.raw_to_sample(a)
+    rec = fmt.sample_to_raw(mel, n_fgla_iters=30, quiet=True)
+    mel2 = fmt.raw_to_sample(rec)
+    e = rel_l2(mel2[..., 16:-16], mel.cpu()[..., 16:mel2.shape[-1] - 16])
+    print(f"mel(decode(mel)) vs mel: {e:.3e}")
+    assert e < 0.15

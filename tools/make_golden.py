@@ -407,6 +407,16 @@ def gen_mel() -> None:
     assert fmt.sample_raw_crop_width() == 1408768 and tuple(fmt.get_sample_shape(bsz=3)) == (3, 2, 256, 5504)
     save("mel_stft", {"audio": audio, "mel": mel, "band_edges": edges, "filter_colsum": fb.sum(dim=0)},
          dict(n_fft=6400, hop=256, nnz=int(nz.sum())))
+    # decode: un-mel + 4 FGLA iterations (stereo anneal crosses t > 0 when coherence is lowered, so test both regimes)
+    t = {}
+    for case, coh in (("default", 0.67), ("anneal", 0.3)):
+        fmt.spectrogram_converter.inverse_spectrogram_func.stereo_coherence = coh
+        with torch.no_grad():
+            raw = fmt.sample_to_raw(mel[:1], n_fgla_iters=4, quiet=True)
+        ours = M.mel_to_raw(mel[:1], window=win, hop=256, filters=ofb, n_iter=4, stereo_coherence=coh)
+        check(f"fgla {case}", ours, raw, 2e-3)
+        t[f"{case}.raw"] = raw
+    save("fgla", t, dict(n_iter=4, coherence={"default": 0.67, "anneal": 0.3}, note="input = mel_stft.safetensors mel[:1]"))
 
 
 def R_silu(x):
