@@ -90,3 +90,26 @@ def test_ln_freq_rows_match_oracle():
     rows = u.get_ln_freqs_rows(Fmt(), 3, 32, 20)
     ref = O.ln_freq_channel(32, 20, 3, 20.0, 16000.0)
     assert torch.equal(rows, ref[0, 0, :, 0])
+
+
+def test_sigma_sampler_matches_reference_vectors():
+    """Host-side stratified sigma sampling (reference training/sigma_sampler.py) against golden vectors: all seven
+    distributions on the stratified quantiles with rand(1) = 0.5, plus the generator-driven default."""
+    from dualdiffusion_amd.training.sigma_sampler import SigmaSampler, SigmaSamplerConfig
+    from tests.util import load_golden
+    t, m = load_golden("sigma_sampler")
+    jitter = torch.tensor([m["jitter"]])
+    for dist in ("ln_sech", "ln_normal", "ln_sech^2", "ln_linear", "scale_invariant", "linear", "ln_pdf"):
+        kw = dict(m["params"].get(dist, {}))
+        if dist == "ln_pdf":
+            kw["dist_pdf"] = t["ln_pdf.pdf"].clone()
+        s = SigmaSampler(SigmaSamplerConfig(distribution=dist, **kw)).sample(m["n"], jitter=jitter)
+        assert torch.equal(s, t[dist]), dist
+        assert float(s.min()) >= 0.03 - 1e-6 and float(s.max()) <= 200.0 + 1e-4
+    torch.manual_seed(9)
+    assert torch.equal(SigmaSampler(SigmaSamplerConfig()).sample(16), t["seed9.n16"])
+    # stratification: exactly one sample per 1/n quantile bucket -> sorted output for the monotone inverse CDFs
+    s = SigmaSampler(SigmaSamplerConfig(distribution="ln_linear")).sample(32)
+    assert torch.equal(s, s.sort().values)
+    with pytest.raises(ValueError):
+        SigmaSampler(SigmaSamplerConfig(distribution="nope"))

@@ -419,6 +419,37 @@ def gen_mel() -> None:
     save("fgla", t, dict(n_iter=4, coherence={"default": 0.67, "anneal": 0.3}, note="input = mel_stft.safetensors mel[:1]"))
 
 
+def gen_sigma() -> None:
+    """SigmaSampler (training/sigma_sampler.py): every distribution's inverse CDF on stratified quantiles."""
+    print("sigma")
+    from training.sigma_sampler import SigmaSampler, SigmaSamplerConfig
+    sys.path.insert(0, ROOT)
+    from dualdiffusion_amd.training.sigma_sampler import SigmaSampler as Ours, SigmaSamplerConfig as OursCfg
+    t = {}
+    jitter = torch.tensor([0.5])                      # SURVEY.md 8d cfg 3: rand(1) = 0.5
+    n = 64
+    pdf = torch.rand(127, generator=torch.Generator().manual_seed(4)) + 0.05
+    for dist, kw in (("ln_sech", {}), ("ln_normal", dict(dist_scale=1.2, dist_offset=-0.4)), ("ln_sech^2", dict(dist_offset=0.1)),
+                     ("ln_linear", {}), ("scale_invariant", dict(dist_scale=0.7)), ("linear", dict(dist_scale=2.0)),
+                     ("ln_pdf", dict(dist_pdf=pdf.clone()))):
+        ref = SigmaSampler(SigmaSamplerConfig(distribution=dist, **kw))
+        q = (torch.arange(n) + 0.5) / n + (jitter - 0.5) / n
+        out = ref.sample_fn(n, q.clone())
+        ours = Ours(OursCfg(distribution=dist, **{k: (v.clone() if torch.is_tensor(v) else v) for k, v in kw.items()}))
+        check(f"sigma {dist}", ours.sample(n, jitter=jitter), out, 1e-6)
+        t[dist] = out
+    t["ln_pdf.pdf"] = pdf
+    torch.manual_seed(9)
+    ref = SigmaSampler(SigmaSamplerConfig())
+    a = ref.sample(16)
+    torch.manual_seed(9)
+    b = Ours(OursCfg()).sample(16)
+    assert torch.equal(a, b), "generator-driven sample differs"
+    t["seed9.n16"] = a
+    save("sigma_sampler", t, dict(n=n, jitter=0.5, params={"ln_normal": dict(dist_scale=1.2, dist_offset=-0.4), "ln_sech^2": dict(dist_offset=0.1),
+                                                        "scale_invariant": dict(dist_scale=0.7), "linear": dict(dist_scale=2.0)}))
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -429,7 +460,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
