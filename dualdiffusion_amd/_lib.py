@@ -28,7 +28,7 @@ class WPrepDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("gain_ptr", C.c_void_p), ("gain", C.c_float),
                 ("w_dtype", C.c_int32), ("wp_dtype", C.c_int32), ("Cout", C.c_int32), ("Cg", C.c_int32),
                 ("ksize", C.c_int32), ("groups", C.c_int32), ("CK", C.c_int32), ("normalize", C.c_int32),
-                ("qk_head_dim", C.c_int32)]
+                ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float)]
 
 
 class ConvDesc(C.Structure):
@@ -38,7 +38,8 @@ class ConvDesc(C.Structure):
                 ("C0", C.c_int32), ("C1", C.c_int32), ("Cout", C.c_int32), ("groups", C.c_int32), ("ksize", C.c_int32),
                 ("CK", C.c_int32), ("resample", C.c_int32), ("prologue", C.c_int32), ("epilogue", C.c_int32),
                 ("scale0", C.c_float), ("scale1", C.c_float), ("res_t", C.c_float), ("clip", C.c_float),
-                ("dtype", C.c_int32), ("force_direct", C.c_int32)]
+                ("dtype", C.c_int32), ("force_direct", C.c_int32),
+                ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float)]
 
 
 class MelStftDesc(C.Structure):
@@ -66,6 +67,9 @@ PROTOTYPES = {
     "ddx_mpconv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "ddx_mpconv2d_pick_ck": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "ddx_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_pixelnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_attn_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                   C.c_int32, C.c_void_p]),
     "ddx_attn_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                C.c_int32, C.c_void_p]),
     "ddx_linear_small_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

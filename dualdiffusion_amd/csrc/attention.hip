@@ -26,7 +26,7 @@ template <> struct AttnMma<float> {
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
-                                                       int B, int Tn, int heads, float eps) {
+                                                       const float* __restrict__ out_cs, int B, int Tn, int heads, float eps) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int VPR = D / EV;           // 16-byte vectors per token row
   constexpr int RPP = 256 / VPR;        // rows staged per pass
@@ -217,15 +217,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         Vec4<T> ov;
+        const int dd = dt * 32 + 8 * g4 + 4 * khalf;
+        if (out_cs) {  // producer-side activation of attn_proj's operand: mp_silu(o * c_v)
+          const f32x4 c4v = *reinterpret_cast<const f32x4*>(out_cs + (size_t)b * C + head * D + dd);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov.set(e, oacc[dt][4 * g4 + e] * inv_l);
-        *reinterpret_cast<decltype(ov.v)*>(orow + dt * 32 + 8 * g4 + 4 * khalf) = ov.v;
+          for (int e = 0; e < 4; ++e) ov.set(e, mp_silu_f(oacc[dt][4 * g4 + e] * inv_l * c4v[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.set(e, oacc[dt][4 * g4 + e] * inv_l);
+        }
+        *reinterpret_cast<decltype(ov.v)*>(orow + dd) = ov.v;
       }
   }
 }
 
 template <typename T, int D>
-static int launch_attn(const void* qk, const void* v, void* out, int B, int Tn, int heads, float eps, hipStream_t s) {
+static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int KC = 128;
   const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + (size_t)D * (KC + AttnMma<T>::VPAD)) * sizeof(T);
@@ -238,7 +245,7 @@ static int launch_attn(const void* qk, const void* v, void* out, int B, int Tn, 
     attr_done = true;
   }
   dim3 grid((Tn + 127) / 128, heads, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, B, Tn, heads, eps);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps);
   return check_launch("attn_fwd");
 }
 
@@ -248,17 +255,22 @@ using namespace ddx;
 
 extern "C" int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
                             float eps, int32_t dtype, ddx_stream stream) {
+  return ddx_attn_act_fwd(qk, v, out, nullptr, B, T, heads, head_dim, eps, dtype, stream);
+}
+
+extern "C" int ddx_attn_act_fwd(const void* qk, const void* v, void* out, const float* out_scale, int32_t B, int32_t T, int32_t heads,
+                                int32_t head_dim, float eps, int32_t dtype, ddx_stream stream) {
   if (!qk || !v || !out || B <= 0 || T <= 0 || heads <= 0) return set_error(DDX_ERR_ARG, "attn: bad args");
   if (head_dim != 32 && head_dim != 64 && head_dim != 128) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim must be 32, 64 or 128");
   return dispatch([=](hipStream_t s) -> int {
     if (dtype == DDX_BF16) {
-      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, B, T, heads, eps, s);
-      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, B, T, heads, eps, s);
-      return launch_attn<bf16, 128>(qk, v, out, B, T, heads, eps, s);
+      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s);
+      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, out_scale, B, T, heads, eps, s);
+      return launch_attn<bf16, 128>(qk, v, out, out_scale, B, T, heads, eps, s);
     }
-    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, B, T, heads, eps, s);
-    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, B, T, heads, eps, s);
-    return launch_attn<float, 128>(qk, v, out, B, T, heads, eps, s);
+    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, out_scale, B, T, heads, eps, s);
+    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, out_scale, B, T, heads, eps, s);
+    return launch_attn<float, 128>(qk, v, out, out_scale, B, T, heads, eps, s);
   }, stream, "attention", 4.0 * B * heads * (double)T * T * head_dim,
      (double)dtype_size(dtype) * 4.0 * B * T * heads * head_dim);
 }

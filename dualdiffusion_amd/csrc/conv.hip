@@ -2,6 +2,7 @@
 // re-layout, reference src/modules/mp_tools.py:359-364), forced weight normalisation (:375-378) and the conv forward
 // dispatcher (MFMA implicit GEMM or the scalar kernel).
 #include <cmath>
+#include <cstdlib>
 
 #include "conv_params.hpp"
 
@@ -11,7 +12,7 @@ namespace ddx {
 template <typename TW_, typename TP>
 __global__ __launch_bounds__(256) void wprep_kernel(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr,
                                                     float gain, int Cout, int Cg, int taps, int G, int CK, int normalize,
-                                                    int qk_d, float eps) {
+                                                    int qk_d, float eps, int in_split, float in_s0, float in_s1) {
   __shared__ float scratch[4];
   const int od = blockIdx.x;
   const int Ng = Cout / G, NgP = (Ng + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
@@ -38,7 +39,9 @@ __global__ __launch_bounds__(256) void wprep_kernel(const TW_* __restrict__ w, T
     const int c = i / taps, tap = i - c * taps;
     float x = to_f32<TW_>(wr[i]);
     if (normalize) x = x / inv;
-    wp[wp_index(g, n, tap, c, nchunk, taps, NgP, CK)] = from_f32<TP>(x * sc);
+    float scc = sc;
+    if (in_split > 0) scc *= (g * Cg + c < in_split) ? in_s0 : in_s1;  // mp_cat scales folded into a linear consumer
+    wp[wp_index(g, n, tap, c, nchunk, taps, NgP, CK)] = from_f32<TP>(x * scc);
   }
 }
 
@@ -86,7 +89,8 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
     }
 #define DDX_WPREP(TWT, TPT)                                                                                         \
   hipLaunchKernelGGL((wprep_kernel<TWT, TPT>), dim3(d.Cout), dim3(256), 0, s, (const TWT*)d.w, (TPT*)d.wp, d.gain_ptr, \
-                     d.gain, d.Cout, d.Cg, taps, d.groups, d.CK, d.normalize, d.qk_head_dim, 1e-4f)
+                     d.gain, d.Cout, d.Cg, taps, d.groups, d.CK, d.normalize, d.qk_head_dim, 1e-4f, d.in_split, d.in_scale0,   \
+                     d.in_scale1)
     if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_F32) DDX_WPREP(float, float);
     else if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_BF16) DDX_WPREP(float, bf16);
     else if (d.w_dtype == DDX_BF16 && d.wp_dtype == DDX_BF16) DDX_WPREP(bf16, bf16);
@@ -135,6 +139,7 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   const float t = d.res_t, nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
   p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;
   p.clip = d.clip;
+  p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   const int ks = d.ksize, dt = d.dtype;
   const bool mfma = !d.force_direct && conv_mfma_supported(p, ks, dt);
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;

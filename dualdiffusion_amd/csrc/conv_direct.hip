@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
     }
     if (p.epilogue == DDX_EPI_MPSUM) acc = to_f32<T>(reinterpret_cast<const T*>(p.res)[idx]) * p.res_a + acc * p.res_b;
     if (p.clip > 0.f) acc = fminf(fmaxf(acc, -p.clip), p.clip);
+    if (p.out2) reinterpret_cast<T*>(p.out2)[idx] = from_f32<T>(mp_silu_f(acc * p.out2_scale));
+    if (p.out_act) acc = mp_silu_f(p.out_cs ? acc * p.out_cs[(size_t)b * p.Cout + o] : acc);
     reinterpret_cast<T*>(p.out)[idx] = from_f32<T>(acc);
   }
 }

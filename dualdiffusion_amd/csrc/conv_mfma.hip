@@ -406,10 +406,27 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
     }
+    if (eoff[it] < 0) continue;
+    if (p.out2) {  // activated twin for the next block's conv_res0
+      Vec4<T> tv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
+      *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out2) + eoff[it]) = tv.v;
+    }
+    if (p.out_act) {  // producer-side mp_silu(y * c): the consumer conv then stages its operand untouched
+      if (p.out_cs) {
+        const int ch = g * p.Ng + n0 + (idx % G4) * 4;  // output channel of this item (no 64-bit modulo on the offset)
+        const f32x4 c4v = *reinterpret_cast<const f32x4*>(p.out_cs + (size_t)b * p.Cout + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] *= c4v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = mp_silu_f(y[e]);
+    }
     Vec4<T> ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov.set(e, y[e]);
-    if (eoff[it] >= 0) *reinterpret_cast<V4*>(out + eoff[it]) = ov.v;
+    *reinterpret_cast<V4*>(out + eoff[it]) = ov.v;
   }
 }
 

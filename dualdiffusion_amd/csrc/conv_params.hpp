@@ -20,6 +20,10 @@ struct ConvParams {
   float scale0, scale1;
   float res_a, res_b;  // out = res * res_a + acc * res_b
   float clip;
+  const float* out_cs;  // producer-side activation scale [B][Cout] (or null)
+  void* out2;           // activated twin of the output (or null)
+  int out_act;
+  float out2_scale;
   // spatial tiling (MFMA kernel)
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;

@@ -9,7 +9,7 @@ namespace ddx {
 // reference: normalize(x, dim=1) (src/modules/mp_tools.py:42-49) as used at unet_edm2_b4.py:117.
 // NHWC rows are contiguous: one wave per row, 16-byte lanes, two passes over registers (row cached when C small).
 template <typename T>
-__global__ __launch_bounds__(256) void pixelnorm_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int C, float eps) {
+__global__ __launch_bounds__(256) void pixelnorm_kernel(const T* __restrict__ x, T* __restrict__ y, T* __restrict__ y2, int64_t rows, int C, float eps) {
   constexpr int EV = 16 / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void pixelnorm_kernel(const T* __restrict__ x,
   for (int64_t r = wave_id; r < rows; r += nwaves) {
     const T* xr = x + r * C;
     T* yr = y + r * C;
+    T* y2r = y2 ? y2 + r * C : nullptr;
     float ss = 0.f;
     if (C % EV == 0) {
       constexpr int MAXV = 4;  // up to 4 vectors per lane cached in registers (C <= 64*4*EV)
@@ -46,25 +47,31 @@ __global__ __launch_bounds__(256) void pixelnorm_kernel(const T* __restrict__ x,
         for (int k = 0; k < MAXV; ++k) {
           const int vi = lane + k * 64;
           if (vi < nvec) {
-            Vec16<T> o;
+            Vec16<T> o, o2;
 #pragma unroll
-            for (int e = 0; e < EV; ++e) o.set(e, cache[k].get(e) / nrm);
+            for (int e = 0; e < EV; ++e) { const float q = cache[k].get(e) / nrm; o.set(e, q); o2.set(e, mp_silu_f(q)); }
             *reinterpret_cast<decltype(o.v)*>(yr + (size_t)vi * EV) = o.v;
+            if (y2r) *reinterpret_cast<decltype(o.v)*>(y2r + (size_t)vi * EV) = o2.v;
           }
         }
       } else {
         for (int vi = lane; vi < nvec; vi += 64) {
-          Vec16<T> t, o; t.v = *reinterpret_cast<const decltype(t.v)*>(xr + (size_t)vi * EV);
+          Vec16<T> t, o, o2; t.v = *reinterpret_cast<const decltype(t.v)*>(xr + (size_t)vi * EV);
 #pragma unroll
-          for (int e = 0; e < EV; ++e) o.set(e, t.get(e) / nrm);
+          for (int e = 0; e < EV; ++e) { const float q = t.get(e) / nrm; o.set(e, q); o2.set(e, mp_silu_f(q)); }
           *reinterpret_cast<decltype(o.v)*>(yr + (size_t)vi * EV) = o.v;
+          if (y2r) *reinterpret_cast<decltype(o.v)*>(y2r + (size_t)vi * EV) = o2.v;
         }
       }
     } else {
       for (int c = lane; c < C; c += 64) { const float f = to_f32<T>(xr[c]); ss += f * f; }
       ss = wave_sum(ss);
       const float nrm = eps + sqrtf(ss) * inv_sqrt_c;
-      for (int c = lane; c < C; c += 64) yr[c] = from_f32<T>(to_f32<T>(xr[c]) / nrm);
+      for (int c = lane; c < C; c += 64) {
+        const float q = to_f32<T>(xr[c]) / nrm;
+        yr[c] = from_f32<T>(q);
+        if (y2r) y2r[c] = from_f32<T>(mp_silu_f(q));
+      }
     }
   }
 }
@@ -278,16 +285,21 @@ static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 
 
 using namespace ddx;
 
-extern "C" int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream) {
+extern "C" int ddx_pixelnorm_act_fwd(const void* x, void* y, void* y_act, int64_t rows, int32_t C, float eps, int32_t dtype,
+                                     ddx_stream stream) {
   if (!x || !y || rows <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "pixelnorm: bad args");
   return dispatch([=](hipStream_t s) -> int {
     const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 16384);
     if (dtype == DDX_BF16)
-      hipLaunchKernelGGL(pixelnorm_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, rows, C, eps);
+      hipLaunchKernelGGL(pixelnorm_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (bf16*)y_act, rows, C, eps);
     else
-      hipLaunchKernelGGL(pixelnorm_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, rows, C, eps);
+      hipLaunchKernelGGL(pixelnorm_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, (float*)y_act, rows, C, eps);
     return check_launch("pixelnorm");
-  }, stream, "pixelnorm", 0.0, 2.0 * (double)rows * C * (double)dtype_size(dtype));
+  }, stream, "pixelnorm", 0.0, (y_act ? 3.0 : 2.0) * (double)rows * C * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream) {
+  return ddx_pixelnorm_act_fwd(x, y, nullptr, rows, C, eps, dtype, stream);
 }
 
 extern "C" int ddx_unet_input_prep(const float* x_nchw, const float* sigma, const float* ln_freq_h, void* out_nhwc, int32_t B,

@@ -55,16 +55,18 @@ class PlanBuilder:
         self.gains.append(p)
         return len(self.gains) - 1
 
-    def prep(self, conv, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0, in_scale=None):
-        """Declare a conv's prepared weights; the buffer is filled whenever `wplan` runs."""
+    def prep(self, conv, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0,
+             in_split: int = 0, in_scale0: float = 1.0, in_scale1: float = 1.0):
+        """Declare a conv's prepared weights; the buffer is filled whenever `wplan` runs.
+        in_split / in_scale*: mp_cat scales of a linear consumer folded into the weights."""
         w = conv.weight
         Cg, ks = w.shape[1], (w.shape[2] if w.ndim == 4 else 1)
         CK = ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
         nbytes = ops.lib().ddx_wprep_bytes(w.shape[0], Cg, ks, conv.groups, CK, ops.dtype_code(self.dt))
         buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         self.keep.append(buf)
-        self.convs.append(dict(conv=conv, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad,
-                               gain_slot=self.gain_slot(gain_param) if gain_param is not None else None))
+        self.convs.append(dict(conv=conv, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad, in_split=in_split, in_scale0=in_scale0,
+                               in_scale1=in_scale1, gain_slot=self.gain_slot(gain_param) if gain_param is not None else None))
         return ops.PreparedWeight(buf, w.shape[0], Cg, ks, conv.groups, CK, self.dt, None)
 
     def cvec(self, lin, gain_param, add_const: float = 1.0) -> torch.Tensor:
@@ -78,55 +80,70 @@ class PlanBuilder:
 
     # ------------------------------------------------------------------------------------------ one EDM2 block
     def block(self, blk, src0: torch.Tensor, src1: Optional[torch.Tensor], s0: float, s1: float, h: int, w: int,
-              mlp_multiplier: int, res_balance: float, attn_balance: float, clip: float = 256.0) -> torch.Tensor:
-        """Queue one block; `src0/src1` are its (optionally mp_cat'ed, scales s0/s1) NHWC inputs at the PRE-resample size."""
+              mlp_multiplier: int, res_balance: float, attn_balance: float, clip: float = 256.0,
+              act0: Optional[torch.Tensor] = None, act1: Optional[torch.Tensor] = None, twin_scale: Optional[float] = None):
+        """Queue one block.  `src0/src1`: raw NHWC inputs at the PRE-resample size (mp_cat scales s0/s1);
+        `act0/act1`: their activated twins mp_silu(s * x) written by the producers (None: conv_res0 falls back to the fused
+        prologue).  `twin_scale`: write mp_silu(twin_scale * out) beside the output for the next block's conv_res0.
+        Returns (out, out_twin | None).
+
+        Producer-side activation: conv_res0's epilogue stores mp_silu(y * c) and the attention kernel stores mp_silu(o * c_v),
+        so conv_res1 / attn_proj / (with twins) conv_res0 stage their operands untouched -- the per-chunk prologue VALU
+        work leaves the MFMA loop and is done once per element on fp32 accumulators instead."""
         cout, mm = blk.out_channels, mlp_multiplier
         rs = _RESAMPLE[blk.resample_mode]
         npix = self.B * h * w
         c_emb = self.cvec(blk.emb_linear, blk.emb_gain)
         pw_res0, pw_res1 = self.prep(blk.conv_res0, npix=npix), self.prep(blk.conv_res1, npix=npix)
-        pw_skip = self.prep(blk.conv_skip, npix=npix) if blk.conv_skip is not None else None
         y0, xo = self.act(h, w, cout * mm), self.act(h, w, cout)
-        last_clip = 0.0 if blk.use_attention else clip
+        attn = blk.use_attention
+        last_clip = 0.0 if attn else clip
+        twin = self.act(h, w, cout) if twin_scale is not None else None
+        tw_res1 = dict(out2=twin, out2_scale=twin_scale) if (twin is not None and not attn) else {}
         S = self.step
         if blk.flavor == "enc":
-            x1 = self.act(h, w, cout)
+            pw_skip = self.prep(blk.conv_skip, npix=npix) if blk.conv_skip is not None else None
+            x1, x1a = self.act(h, w, cout), self.act(h, w, cout)
             if pw_skip is not None:
                 S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), resample=rs, out=x1))
+                S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
             elif rs != RESAMPLE_KEEP:
                 S(lambda: ops.resample2d(src0, x1, rs))
-            if pw_skip is not None or rs != RESAMPLE_KEEP:
-                S(lambda: ops.pixelnorm(x1, out=x1))
+                S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
             else:
-                S(lambda: ops.pixelnorm(src0, out=x1))
-            S(lambda: ops.conv2d(x1, pw_res0, prologue=PRO_SILU, out=y0))
-            S(lambda: ops.conv2d(y0, pw_res1, prologue=PRO_SCALE_SILU, chan_scale=c_emb, residual=x1, res_t=res_balance,
-                                 clip=last_clip, out=xo))
+                S(lambda: ops.pixelnorm(src0, out=x1, out_act=x1a))
+            S(lambda: ops.conv2d(x1a, pw_res0, out_act=True, out_scale=c_emb, out=y0))
+            S(lambda: ops.conv2d(y0, pw_res1, residual=x1, res_t=res_balance, clip=last_clip, out=xo, **tw_res1))
         else:
-            S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU, out=y0))
-            if pw_skip is not None:
+            if act0 is not None and (src1 is None or act1 is not None):
+                S(lambda: ops.conv2d(act0, pw_res0, out_hw=(h, w), src1=act1, resample=rs, out_act=True, out_scale=c_emb, out=y0))
+            else:   # no twins available: fused prologue on the raw inputs
+                S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU,
+                                     out_act=True, out_scale=c_emb, out=y0))
+            if blk.conv_skip is not None:
+                pw_skip = self.prep(blk.conv_skip, npix=npix, in_split=src0.shape[3] if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
                 sk = self.act(h, w, cout)
-                S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, out=sk))
+                S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, resample=rs, out=sk))
             elif rs != RESAMPLE_KEEP:
                 sk = self.act(h, w, cout)      # no skip conv: the residual is the (resampled) block input itself
                 S(lambda: ops.resample2d(src0, sk, rs))
             else:
                 assert src1 is None, "a concatenated input always changes the channel count, i.e. has a skip conv"
                 sk = src0
-            S(lambda: ops.conv2d(y0, pw_res1, prologue=PRO_SCALE_SILU, chan_scale=c_emb, residual=sk, res_t=res_balance,
-                                 clip=last_clip, out=xo))
-        if not blk.use_attention:
-            return xo
+            S(lambda: ops.conv2d(y0, pw_res1, residual=sk, res_t=res_balance, clip=last_clip, out=xo, **tw_res1))
+        if not attn:
+            return xo, twin
         c_qk, c_v = self.cvec(blk.emb_linear_qk, blk.emb_gain_qk), self.cvec(blk.emb_linear_v, blk.emb_gain_v)
         heads = blk.num_heads
         pw_qk = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix)
         pw_v, pw_proj = self.prep(blk.attn_v, npix=npix), self.prep(blk.attn_proj, npix=npix)
         qk, vv, ao, xa = self.act(h, w, 2 * cout), self.act(h, w, cout), self.act(h, w, cout), self.act(h, w, cout)
+        tw_proj = dict(out2=twin, out2_scale=twin_scale) if twin is not None else {}
         S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
         S(lambda: ops.conv2d(xo, pw_v, out=vv))
-        S(lambda: ops.attention(qk, vv, heads, out=ao))
-        S(lambda: ops.conv2d(ao, pw_proj, prologue=PRO_SCALE_SILU, chan_scale=c_v, residual=xo, res_t=attn_balance, clip=clip, out=xa))
-        return xa
+        S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
+        S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
+        return xa, twin
 
     # ------------------------------------------------------------------------------------------ finalize / run
     def gain_ptr(self, slot: Optional[int]):
@@ -147,7 +164,8 @@ class PlanBuilder:
                 conv = sp["conv"]
                 ops.wprep(conv.weight, conv.groups, self.dt, gain_ptr=self.gain_ptr(sp["gain_slot"]),
                           normalize=self.training and not conv.disable_weight_norm, qk_head_dim=sp["qk"], CK=sp["CK"],
-                          cg_pad=sp["cg_pad"], out=sp["buf"])
+                          cg_pad=sp["cg_pad"], out=sp["buf"], in_split=sp["in_split"], in_scale0=sp["in_scale0"],
+                          in_scale1=sp["in_scale1"])
         with self.fplan.record():
             if pre_steps is not None:
                 pre_steps()

@@ -269,28 +269,51 @@ class _UNetEngine:
             ops.mpsum_rows(e0, self.emb_in, emb, t=cfg.label_balance, silu=True)
 
         # ---- encoder / decoder (reference unet_edm2_b4.py:279-288)
+        # Which activated twin mp_silu(s * x) does each block output need?  Encoder outputs are popped as skips by the
+        # decoder "layer" blocks (twin scale = the mp_cat weight wb of that layer); a decoder output feeds the next
+        # decoder block (wa of its mp_cat, or 1 for up / mid blocks).
+        enc_names = [n for n in unet.enc.keys()]
+        enc_ch = [unet.enc[n].out_channels for n in enc_names]
+        dec_items = list(unet.dec.items())
+        stack, x_ch = list(range(len(enc_ch))), enc_ch[-1]
+        skip_twin, dec_in = {}, []          # encoder index -> wb ; per decoder block (wa | 1.0, wb | None)
+        for name, blk in dec_items:
+            if "layer" in name:
+                i = stack.pop()
+                wa, wb = mp_cat_weights(x_ch, enc_ch[i], cfg.concat_balance)
+                skip_twin[i] = wb
+                dec_in.append((wa, wb))
+            else:
+                dec_in.append((1.0, None))
+            x_ch = blk.out_channels
+
         pw_in = pb.prep(unet.enc["conv_in"], cg_pad=Cpad, npix=B * H * W)
         x = pb.act(H, W, unet.enc["conv_in"].out_channels)
-        pb.step(lambda x=x: ops.conv2d(x0, pw_in, out=x))
-        skips = [x]
+        x_tw = pb.act(H, W, unet.enc["conv_in"].out_channels) if 0 in skip_twin else None
+        in_kw = dict(out2=x_tw, out2_scale=skip_twin[0]) if x_tw is not None else {}   # bound now: x_tw is re-assigned below
+        pb.step(lambda x=x, in_kw=in_kw: ops.conv2d(x0, pw_in, out=x, **in_kw))
+        skips = [(x, x_tw)]
         h, w = H, W
         bk = dict(mlp_multiplier=cfg.mlp_multiplier, res_balance=cfg.res_balance, attn_balance=cfg.attn_balance)
-        for name, blk in unet.enc.items():
+        for i, name in enumerate(enc_names):
             if name == "conv_in":
                 continue
+            blk = unet.enc[name]
             if blk.resample_mode == "down":
                 h, w = h // 2, w // 2
-            x = pb.block(blk, x, None, 1.0, 1.0, h, w, **bk)
-            skips.append(x)
-        for name, blk in unet.dec.items():
+            x, x_tw = pb.block(blk, x, None, 1.0, 1.0, h, w, twin_scale=skip_twin.get(i), **bk)
+            skips.append((x, x_tw))
+        x_act = None   # the last encoder output's twin carries the skip scale, not 1: the first mid block uses the fused prologue
+        for j, (name, blk) in enumerate(dec_items):
             if blk.resample_mode == "up":
                 h, w = h * 2, w * 2
+            next_scale = dec_in[j + 1][0] if j + 1 < len(dec_items) else None
             if "layer" in name:
-                sk = skips.pop()
-                s0, s1 = mp_cat_weights(x.shape[3], sk.shape[3], cfg.concat_balance)
-                x = pb.block(blk, x, sk, s0, s1, h, w, **bk)
+                sk, sk_act = skips.pop()
+                s0, s1 = dec_in[j]
+                x, x_act = pb.block(blk, x, sk, s0, s1, h, w, act0=x_act, act1=sk_act, twin_scale=next_scale, **bk)
             else:
-                x = pb.block(blk, x, None, 1.0, 1.0, h, w, **bk)
+                x, x_act = pb.block(blk, x, None, 1.0, 1.0, h, w, act0=x_act, twin_scale=next_scale, **bk)
         # ---- output (reference unet_edm2_b4.py:290-296)
         pw_out = pb.prep(unet.conv_out, gain_param=unet.out_gain, npix=B * H * W)
         y = pb.act(H, W, cfg.out_channels)

@@ -206,13 +206,17 @@ class _VAEEngine:
             first, blocks, last, last_gain = vae.conv_latents_in, list(vae.dec.values()), vae.conv_out, vae.out_gain
         pw_first = pb.prep(first, cg_pad=Cpad, npix=B * H * W)
         x = pb.act(H, W, first.out_channels)
-        pb.step(lambda x=x: ops.conv2d(x0, pw_first, out=x))
-        for blk in blocks:
+        # decoder blocks read mp_silu(x) twins written by their producers; encoder blocks normalise first and need none
+        x_act = pb.act(H, W, first.out_channels) if kind == "dec" else None
+        first_kw = dict(out2=x_act, out2_scale=1.0) if x_act is not None else {}       # bound now: x_act is re-assigned below
+        pb.step(lambda x=x, first_kw=first_kw: ops.conv2d(x0, pw_first, out=x, **first_kw))
+        for bi, blk in enumerate(blocks):
             if blk.resample_mode == "down":
                 h, w = h // 2, w // 2
             elif blk.resample_mode == "up":
                 h, w = h * 2, w * 2
-            x = pb.block(blk, x, None, 1.0, 1.0, h, w, **bk)
+            tw = 1.0 if (kind == "dec" and bi + 1 < len(blocks)) else None
+            x, x_act = pb.block(blk, x, None, 1.0, 1.0, h, w, act0=x_act, twin_scale=tw, **bk)
         pw_last = pb.prep(last, gain_param=last_gain, npix=B * h * w)
         y = pb.act(h, w, last.out_channels)
         self.out = pb.f32(B, last.out_channels, h, w)

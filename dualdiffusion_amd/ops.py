@@ -30,7 +30,8 @@ def pick_ck(Cg: int, ksize: int, dtype: torch.dtype, npix: int = 0) -> int:
 
 def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float = 1.0, gain_ptr: Optional[torch.Tensor] = None,
           normalize: bool = False, qk_head_dim: int = 0, CK: Optional[int] = None, cg_pad: Optional[int] = None,
-          out: Optional[torch.Tensor] = None, npix: int = 0) -> PreparedWeight:
+          out: Optional[torch.Tensor] = None, npix: int = 0, in_split: int = 0, in_scale0: float = 1.0,
+          in_scale1: float = 1.0) -> PreparedWeight:
     """Prepare MPConv weights `[Cout, Cg, k, k]` for ddx_mpconv2d_fwd.  `cg_pad`: channel count of the activation
     tensor per group when it is zero-padded beyond the weight's Cg (conv_in: 6 -> 8)."""
     assert weight.is_contiguous()
@@ -46,7 +47,7 @@ def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float 
     assert out.numel() >= nbytes
     d = L.WPrepDesc(w=ptr(weight), wp=ptr(out), gain_ptr=ptr(gain_ptr), gain=float(gain), w_dtype=dtype_code(weight.dtype),
                     wp_dtype=dtype_code(dtype), Cout=Cout, Cg=Cg, ksize=ksize, groups=groups, CK=CK,
-                    normalize=int(normalize), qk_head_dim=qk_head_dim)
+                    normalize=int(normalize), qk_head_dim=qk_head_dim, in_split=in_split, in_scale0=in_scale0, in_scale1=in_scale1)
     check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep")
     return PreparedWeight(out, Cout, Cg, ksize, groups, CK, dtype, d)
 
@@ -61,8 +62,10 @@ def normalize_weights_(weight: torch.Tensor) -> None:
 def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = None, src1: Optional[torch.Tensor] = None,
            scale0: float = 1.0, scale1: float = 1.0, resample: int = L.RESAMPLE_KEEP, prologue: int = L.PRO_NONE,
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
-           clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False) -> torch.Tensor:
-    """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h)."""
+           clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
+           out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0) -> torch.Tensor:
+    """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
+    out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)."""
     B, sH, sW, C0 = src0.shape
     if out_hw is None:
         out_hw = {L.RESAMPLE_KEEP: (sH, sW), L.RESAMPLE_UP: (sH * 2, sW * 2), L.RESAMPLE_DOWN: (sH // 2, sW // 2)}[resample]
@@ -73,28 +76,31 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
                    B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
                    prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
-                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=int(force_direct))
+                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=int(force_direct),
+                   out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale))
     check(lib().ddx_mpconv2d_fwd(C.byref(d), current_stream()), "mpconv2d_fwd")
     return out
 
 
-def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4) -> torch.Tensor:
-    """RMS normalisation over the last (channel) axis of contiguous rows."""
+def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4, out_act: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RMS normalisation over the last (channel) axis of contiguous rows; `out_act` also receives mp_silu(result)."""
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     if out is None:
         out = torch.empty_like(x)
-    check(lib().ddx_pixelnorm_fwd(ptr(x), ptr(out), rows, Cn, eps, dtype_code(x.dtype), current_stream()), "pixelnorm_fwd")
+    check(lib().ddx_pixelnorm_act_fwd(ptr(x), ptr(out), ptr(out_act), rows, Cn, eps, dtype_code(x.dtype), current_stream()), "pixelnorm_fwd")
     return out
 
 
-def attention(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None, eps: float = 1e-4) -> torch.Tensor:
-    """qk `[B, H, W, 2C]` (head, {q,k}, d), v `[B, H, W, C]` (head, d) -> `[B, H, W, C]`."""
+def attention(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None, eps: float = 1e-4,
+              out_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qk `[B, H, W, 2C]` (head, {q,k}, d), v `[B, H, W, C]` (head, d) -> `[B, H, W, C]`;
+    with `out_scale` [B, C] fp32 the stored result is mp_silu(o * out_scale) (operand of attn_proj)."""
     B, H, W, Cn = v.shape
     if out is None:
         out = torch.empty_like(v)
-    check(lib().ddx_attn_fwd(ptr(qk), ptr(v), ptr(out), B, H * W, heads, Cn // heads, eps, dtype_code(v.dtype), current_stream()),
-          "attn_fwd")
+    check(lib().ddx_attn_act_fwd(ptr(qk), ptr(v), ptr(out), ptr(out_scale), B, H * W, heads, Cn // heads, eps, dtype_code(v.dtype),
+                                 current_stream()), "attn_fwd")
     return out
 
 

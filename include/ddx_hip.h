@@ -55,6 +55,10 @@ typedef struct {
   int32_t CK;         /* K chunk of the consumer kernel: 32 or 64 */
   int32_t normalize;  /* 1 = forced weight norm inside forward (module.training) */
   int32_t qk_head_dim;
+  /* per-source input scaling folded into the weights (mp_cat feeding a conv without a non-linearity, i.e. conv_skip of
+   * decoder blocks): input channels < in_split are scaled by in_scale0, the rest by in_scale1.  in_split <= 0: none. */
+  int32_t in_split;
+  float in_scale0, in_scale1;
 } ddx_wprep_desc;
 
 size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32_t groups, int32_t CK, int32_t dtype);
@@ -91,6 +95,15 @@ typedef struct {
   float clip;               /* <= 0: none */
   int32_t dtype;            /* activations and wp */
   int32_t force_direct;     /* 1 = use the scalar reference kernel (testing / odd channel counts) */
+  /* producer-side activation (so that the CONSUMER conv needs no prologue and stages its operand untouched):
+   *   out_act = 1: the stored output is mp_silu(y * out_scale[b][cout]) (out_scale NULL: mp_silu(y))  -- conv_res0 feeding
+   *                conv_res1 (unet_edm2_b4.py:119-122);
+   *   out2 != NULL: additionally store out2 = mp_silu(out2_scale * y) of the final (post mp_sum / clip) value -- the
+   *                activated twin of a block output that the next block's conv_res0 reads (unet_edm2_b4.py:119). */
+  const float* out_scale;   /* [B][Cout] fp32 or NULL */
+  void* out2;               /* NHWC [B][H][W][Cout] or NULL */
+  int32_t out_act;
+  float out2_scale;
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
@@ -102,6 +115,8 @@ int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t n
  * unet_edm2_b4.py:117): y = x / (eps + ||x||_2 / sqrt(C)).  rows = B*H*W.  In place allowed.
  * ------------------------------------------------------------------------------------------------ */
 int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
+/* Same, additionally storing y_act = mp_silu(y) (the operand of the encoder block's conv_res0, unet_edm2_b4.py:117-119). */
+int ddx_pixelnorm_act_fwd(const void* x, void* y, void* y_act, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention over all H*W tokens  (unet_edm2_b4.py:137-148): q,k,v RMS-normalised over the head
@@ -112,6 +127,9 @@ int ddx_pixelnorm_fwd(const void* x, void* y, int64_t rows, int32_t C, float eps
  * ------------------------------------------------------------------------------------------------ */
 int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B, int32_t T, int32_t heads, int32_t head_dim,
                  float eps, int32_t dtype, ddx_stream stream);
+/* Same with the producer-side activation of attn_proj's operand: out = mp_silu(o * out_scale[b][c]) (unet_edm2_b4.py:150-151). */
+int ddx_attn_act_fwd(const void* qk, const void* v, void* out, const float* out_scale, int32_t B, int32_t T, int32_t heads,
+                     int32_t head_dim, float eps, int32_t dtype, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-M linear layers on raw master weights (no wprep): out[b][o] = post( sum_k x[b][k] * w'[o][k] )

@@ -37,8 +37,8 @@ def test_library_exports_every_declared_symbol():
 def test_descriptor_struct_layout_matches_header():
     """ctypes mirrors of the C descriptors: sizes follow from the field lists in the header (LP64)."""
     from dualdiffusion_amd import _lib
-    assert ctypes.sizeof(_lib.WPrepDesc) == 3 * 8 + 4 + 9 * 4  # 3 pointers, float, 9 int32
-    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 12 * 4 + 4 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.WPrepDesc) == 80  # 3 pointers, float, 10 int32, 2 floats (+4 tail padding)
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 12 * 4 + 4 * 4 + 2 * 4 + 2 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.LinearJob) == 3 * 8 + 2 * 4 + 4 * 4
     lib = _lib.lib() if os.path.isfile(_lib.LIB_PATH) else None
     if lib is not None:

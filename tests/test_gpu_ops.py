@@ -248,3 +248,44 @@ def test_layout_roundtrip_and_io_glue():
     assert rel_l2(out, d) < 1e-6
     ops.unet_output_combine(to_nhwc(y), x.cuda(), sig.cuda(), xr.cuda(), out, 1.0)
     assert rel_l2(out, O.sum_mp(xr[:, :-1], d, xr[:, -1:])) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_producer_side_activation(dtype):
+    """out_act (mp_silu(y*c) stored instead of y), out2 twin (mp_silu(s*y_final)) and mp_cat scales folded into the weights."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, H, W, C0, C1, Cout = 2, 6, 10, 64, 32, 64
+    a, b = _round(torch.randn(B, C0, H, W, generator=g), dtype), _round(torch.randn(B, C1, H, W, generator=g), dtype)
+    w3 = torch.randn(Cout, (C0 + C1) // 8, 3, 3, generator=g)
+    w1 = torch.randn(Cout, C0 + C1, 1, 1, generator=g)
+    cs = torch.rand(B, Cout, generator=g) + 0.5
+    res = _round(torch.randn(B, Cout, H, W, generator=g), dtype)
+    s0, s1 = O.cat_mp_weights(C0, C1, 0.5)
+    tol = TOL[dtype]
+    # (1) grouped 3x3 with out_act + residual + clip + twin
+    x = torch.cat([a, b], 1)
+    wp = O.prepared_weight(w3)
+    if dtype == torch.bfloat16:
+        wp = _round(wp, dtype)
+    y = O.sum_mp(res, torch.nn.functional.conv2d(x, wp, padding=1, groups=8), 0.3).clamp(-1.5, 1.5)
+    pw = ops.wprep(w3.cuda(), 8, dtype)
+    twin = torch.empty(B, H, W, Cout, device="cuda", dtype=dtype)
+    out = ops.conv2d(to_nhwc(a, dtype), pw, src1=to_nhwc(b, dtype), residual=to_nhwc(res, dtype), res_t=0.3, clip=1.5,
+                     out_act=True, out_scale=cs.cuda(), out2=twin, out2_scale=0.8)
+    assert rel_l2(to_nchw(out), O.silu_mp(y * cs[:, :, None, None])) < tol
+    assert rel_l2(to_nchw(twin), O.silu_mp(0.8 * y)) < tol
+    # (2) 1x1 conv of an mp_cat input with the scales folded into the weights (linear consumer)
+    ref = O.conv_mp(O.cat_mp(a, b, 0.5), w1)
+    pw1 = ops.wprep(w1.cuda(), 1, dtype, in_split=C0, in_scale0=s0, in_scale1=s1)
+    out = ops.conv2d(to_nhwc(a, dtype), pw1, src1=to_nhwc(b, dtype))
+    assert rel_l2(to_nchw(out), ref) < tol
+    # (3) pixel-norm with activated twin, attention with activated output
+    xa = torch.empty(B, H, W, C0, device="cuda", dtype=dtype)
+    xn = ops.pixelnorm(to_nhwc(a, dtype), out_act=xa)
+    assert rel_l2(to_nchw(xa), O.silu_mp(O.rms_normalize(a, [1]))) < (1e-5 if dtype == torch.float32 else 6e-3)
+    qk = _round(torch.randn(B, 2 * 64, H, W, generator=g), dtype)
+    v = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    qk_perm = qk.reshape(B, 1, 64, 2, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, 128, H, W)
+    ao = ops.attention(to_nhwc(qk_perm, dtype), to_nhwc(v, dtype), 1, out_scale=cs.cuda())
+    assert rel_l2(to_nchw(ao), O.silu_mp(O.attention_2d(qk, v, 1) * cs[:, :, None, None])) < (2e-5 if dtype == torch.float32 else 1e-2)
