@@ -141,12 +141,19 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   p.clip = d.clip;
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   const int ks = d.ksize, dt = d.dtype;
-  const bool mfma = !d.force_direct && conv_mfma_supported(p, ks, dt);
+  // d.force_direct selects the kernel: 0 = automatic, 1 = scalar reference kernel, 2 = register-staged MFMA kernel,
+  // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)
+  const bool mfma = d.force_direct != 1 && conv_mfma_supported(p, ks, dt);
+  static const bool dma_enabled = []() { const char* e = std::getenv("DDX_CONV_DMA"); return !e || e[0] != '0'; }();
+  if (d.force_direct == 3 && !conv_dma_supported(p, ks, dt, /*any_size=*/true))
+    return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the LDS-DMA kernel");
+  const bool dma = d.force_direct == 3 || (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double es = (double)dtype_size(dt);
   const double bytes = es * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) +
                              (double)p.Cout * p.Cg * ks * ks);
-  return dispatch([p, ks, dt, mfma](hipStream_t s) -> int {
+  return dispatch([p, ks, dt, mfma, dma](hipStream_t s) -> int {
+    if (dma) return launch_conv_dma(p, ks, s);
     return mfma ? launch_conv_mfma(p, ks, dt, s) : launch_conv_direct(p, ks, dt, s);
-  }, stream, mfma ? (ks == 3 ? "conv3x3_mfma" : "conv1x1_mfma") : "conv_direct", flops, bytes);
+  }, stream, dma ? (ks == 3 ? "conv3x3_dma" : "conv1x1_dma") : mfma ? (ks == 3 ? "conv3x3_mfma" : "conv1x1_mfma") : "conv_direct", flops, bytes);
 }

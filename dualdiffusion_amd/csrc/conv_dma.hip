@@ -1,0 +1,432 @@
+// Prologue-free bf16 MPConv forward with LDS-DMA staging (global_load_lds_dwordx4) on gfx950.
+//
+// Same math and the same fused epilogue as conv_mfma.hip (reference src/modules/mp_tools.py:366-373 plus the
+// element-wise tail of Block.forward, src/modules/unets/unet_edm2_b4.py:110-158), for the layers whose input is
+// consumed untouched (the producer already applied mp_silu / the per-channel factors; mp_cat scales live in the
+// prepared weights).  Those are all the large convs of the UNet, so their operand path is pure data movement:
+//   * every stage (SK input channels of the (TH+2)x(TW+2) halo + the [tap][BN][SK] weight slice) goes HBM/L2 -> LDS
+//     by DMA, no VGPR staging, no ds_write, no convert; NST stages in flight, ONE barrier per stage;
+//   * LDS rows are 2*SK bytes with no padding (the DMA destination is lane-linear); bank conflicts of the
+//     ds_read_b128 fragment reads are removed by XOR-swizzling the 16-byte slot of a row with bits of the row index,
+//     applied on the per-lane SOURCE address of the DMA and on the read address;
+//   * out-of-image halo rows read a zero page, so padding costs no branch;
+//   * the epilogue transposes each wave's 32x32 accumulator fragments through a wave-private LDS patch (no
+//     workgroup barrier) and stores 16 bytes per lane on NHWC rows.
+// One workgroup = 4 waves = 256 output pixels x 64 output channels; two workgroups per CU overlap each other.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv_params.hpp"
+
+namespace ddx {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kOobOffset = 0x7fffff00;  // voffset of a lane that must read zeros (beyond num_records of any tensor here)
+
+// 16 bytes per lane, global -> LDS (lane-linear destination at l).  Raw buffer addressing: the address is
+// base + voff + soff and lanes with voff + soff >= num_records write zeros -- that is the conv zero padding.
+__device__ __forceinline__ void dma16(rsrc_t rs, int voff, int soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// floor(x / d) for 0 <= x < 2^22 with inv = 1/d (uniform operands stay off the integer-division sequence)
+__device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int kBM = 256;
+
+template <int KS, int SK, int NF> struct DmaGeom {
+  static constexpr int TAPS = KS * KS, PAD = KS / 2;
+  static constexpr int BN = 32 * NF;
+  static constexpr int RB = SK * 2;          // bytes per LDS row
+  static constexpr int LPR = RB / 16;        // lanes (16-byte slots) per row
+  static constexpr int RPW = 1024 / RB;      // rows per DMA wave-instruction
+  static constexpr int AROWS = KS == 3 ? 352 : kBM;  // halo rows a tile may stage (8x32 -> 340)
+  static constexpr int APIECES = (AROWS + RPW - 1) / RPW;
+  static constexpr int BPIECES = (TAPS * BN + RPW - 1) / RPW;
+  static constexpr int A_BYTES = APIECES * 1024, B_BYTES = BPIECES * 1024;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int NST = 2;
+  static constexpr int AI = (APIECES + 3) / 4, BI = (BPIECES + 3) / 4;
+  static constexpr int EPI_WAVE = 32 * 36 * 4;  // one 32 pixel x 32 channel fp32 patch, rows padded to 36 floats
+  static constexpr int SMEM = NST * STAGE + 4 * EPI_WAVE;
+  // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
+  static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
+};
+
+// Persistent workgroups: gridDim.x workgroups walk the unit list (unit = pixel tile x channel tile x group) with a
+// stride of gridDim.x.  The stage pipeline runs across unit boundaries (the first stage of the next unit is in flight
+// while the last stage of the current one is multiplied and its epilogue runs), and the second workgroup of every CU
+// starts half a unit late so that one workgroup's memory phases (epilogue stores, first-stage latency) fall into the
+// other's matrix phase instead of both doing the same thing at the same time.
+template <int KS, int SK, int NF, int PD>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n) {
+  using GEO = DmaGeom<KS, SK, NF>;
+  constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
+  constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
+  constexpr int KSTEPS = SK / 16;
+  constexpr int MF = 2;
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int khalf = lane >> 5, l31 = lane & 31;
+  const int TW = p.TW, TWP = TW + 2 * PAD;
+  const int R = (p.TH + 2 * PAD) * TWP;
+  const float inv_TW = 1.0f / (float)TW;
+  const int ntile_px = p.B * p.tiles_h * p.tiles_w;
+  const int nk = p.Cg / SK;
+
+  const int ck_shift = __builtin_ctz(p.CK);
+  struct Unit { int b, h0, w0, n0, g; };
+  const float inv_px = 1.0f / (float)ntile_px, inv_nn = 1.0f / (float)ntile_n;
+  const float inv_tw = 1.0f / (float)p.tiles_w, inv_th = 1.0f / (float)p.tiles_h;
+  auto decode = [&](int u) {
+    Unit t;
+    const int r = fdiv(u, inv_px);
+    const int tile = u - r * ntile_px;
+    t.g = fdiv(r, inv_nn);
+    t.n0 = (r - t.g * ntile_n) * BN;
+    const int row = fdiv(tile, inv_tw);
+    t.w0 = (tile - row * p.tiles_w) * p.TW;
+    t.b = fdiv(row, inv_th);
+    t.h0 = (row - t.b * p.tiles_h) * p.TH;
+    return t;
+  };
+
+  // ---- DMA source bookkeeping (per lane): this wave moves pieces wave, wave+4, ...
+  const int lrow = lane / LPR, lslot = lane % LPR;
+  int ahh[AI], aww[AI], aslot[AI];  // tile-independent halo coordinates of this lane's rows
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int r = (wave + 4 * i) * RPW + lrow;
+    const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
+    ahh[i] = r < R ? hh - PAD : -(1 << 20);
+    aww[i] = r - hh * TWP - PAD;
+    aslot[i] = (lslot ^ GEO::swz(r)) * 8;
+  }
+  int btap[BI], bn[BI], bslot[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = min((wave + 4 * i) * RPW + lrow, TAPS * BN - 1);
+    btap[i] = r / BN;
+    bn[i] = r - btap[i] * BN;
+    bslot[i] = (lslot ^ GEO::swz(r)) * 8;
+  }
+  const rsrc_t rs0 = make_rsrc(p.src0, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
+  const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
+  const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.G * p.nchunk * TAPS * p.NgP * p.CK * 2);
+
+  // issue cursor: (unit, stage) of the next DMA batch.  Per lane only byte offsets inside the tensors are kept; the
+  // stage (input-channel) advance is a scalar offset, so one batch costs one m0 write + one buffer_load per piece.
+  int iu = blockIdx.x, iq = 0, isrc = -1;
+  Unit it{};
+  int apix[AI], avoff[AI], bvoff[BI];
+  auto issue_setup = [&](int u) {
+    it = decode(u);
+    isrc = -1;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int ih = it.h0 + ahh[i], iw = it.w0 + aww[i];
+      const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      const int pix = p.resample == DDX_RESAMPLE_UP ? (it.b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (it.b * p.sH + ih) * p.sW + iw;
+      apix[i] = ok ? pix : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int n = min(it.n0 + bn[i], p.NgP - 1);  // rows past NgP only feed outputs that are never stored
+      bvoff[i] = (((btap[i] * p.NgP + n) << ck_shift) + bslot[i]) * 2;
+    }
+  };
+  auto issue_next = [&](auto stage_tag) {
+    if (iu >= total_units) return;
+    char* sbase = smem + decltype(stage_tag)::value * GEO::STAGE;
+    const int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
+    const int src_id = cabs >= p.C0 ? 1 : 0;
+    if (src_id != isrc) {  // (re)compute the per-lane row offsets for this source's channel stride
+      isrc = src_id;
+      const int cs2 = (src_id ? p.C1 : p.C0) * 2;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * cs2 + aslot[i] * 2 : kOobOffset;
+    }
+    const int soff_a = (src_id ? cabs - p.C0 : cabs) * 2;
+    const rsrc_t rsa = src_id ? rs1 : rs0;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
+    }
+    const int k0 = iq * SK;
+    const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, sbase + GEO::A_BYTES + piece * 1024);
+    }
+    if (++iq == nk) {
+      iq = 0;
+      iu += gridDim.x;
+      if (iu < total_units) issue_setup(iu);
+    }
+  };
+
+  // ---- fragment read addresses (bytes inside a stage); the tile geometry is the same for every unit
+  int aoff[MF][TAPS];
+#pragma unroll
+  for (int j = 0; j < MF; ++j) {
+    const int ml = (wave * MF + j) * 32 + l31;
+    const int th = (int)(((float)ml + 0.5f) * inv_TW);
+    const int tw = ml - th * TW;
+    const int base = th * TWP + tw;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int r = base + (t / KS) * TWP + (t % KS);
+      aoff[j][t] = r * RB + ((khalf ^ GEO::swz(r)) << 4);  // k-step ks adds (2*ks) to the slot: XOR commutes below
+    }
+  }
+  // weight rows tap*BN + i*32 + l31: the swizzle only depends on l31
+  const int bsw = GEO::swz(l31);
+  const int boff_r = l31 * RB;
+
+  f32x16 acc[NF][MF];
+  auto compute = [&](auto stage_tag) {  // compile-time stage: every LDS address is register + immediate
+    constexpr int STG = decltype(stage_tag)::value;
+    const char* sA = smem + STG * GEO::STAGE;
+    const char* sB = sA + GEO::A_BYTES;
+    constexpr int SLOTS = TAPS * KSTEPS;
+    // fragments are read PD slots ahead of the MFMAs that consume them (register ring of PD+1 slots), so that one wave
+    // alone keeps the matrix pipe fed while the other wave of its SIMD is in a memory phase
+    constexpr int RING = PD + 1;
+    bf16x8 wf[RING][NF], xf[RING][MF];
+    auto load_frags = [&](int slot, int buf) {
+      const int tap = slot / KSTEPS, ks = slot % KSTEPS;
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+        wf[buf][i] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + i * 32) * RB + boff_r + (((2 * ks + khalf) ^ bsw) << 4));
+#pragma unroll
+      for (int j = 0; j < MF; ++j)
+        xf[buf][j] = *reinterpret_cast<const bf16x8*>(sA + (aoff[j][tap] ^ (ks << 5)));
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < PD && s0 < SLOTS; ++s0) load_frags(s0, s0 % RING);
+    if (p.debug & 16) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+      const int cur = slot % RING;
+      if (slot + PD < SLOTS) load_frags(slot + PD, (slot + PD) % RING);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads in front of the MFMAs of this slot
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
+    }
+    if (p.debug & 16) __builtin_amdgcn_s_setprio(0);
+  };
+
+  float* sE = reinterpret_cast<float*>(smem + NST * GEO::STAGE + wave * GEO::EPI_WAVE);
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+  const bf16* res = reinterpret_cast<const bf16*>(p.res);
+
+  // the second workgroup of a CU starts late (see above); p.debug >> 8 overrides the skew (development)
+  if ((blockIdx.x / 256) & 1) {
+    const int skew = (p.debug >> 8) ? (p.debug >> 8) : (nk * 10 + 12);  // x128 clocks ~ half a unit
+    for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(2);
+  }
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  if (iu < total_units) issue_setup(iu);
+  issue_next(S0{});
+  for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
+    const Unit t = it;  // the issue cursor is still on this unit (it moves on during the last stage)
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int j = 0; j < MF; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // epilogue addressing: items of a 32 pixel x 32 channel patch are (pixel, 8-channel run); 128 items, 2 per lane
+    long eoff[MF][2];
+#pragma unroll
+    for (int j = 0; j < MF; ++j)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int idx = lane + 64 * tt;
+        const int ml = (wave * MF + j) * 32 + (idx >> 2);
+        const int th = (int)(((float)ml + 0.5f) * inv_TW);
+        const int tw = ml - th * TW;
+        const int h = t.h0 + th, w = t.w0 + tw;
+        const bool ok = h < p.H && w < p.W;
+        eoff[j][tt] = ok ? (long)((((size_t)t.b * p.H + h) * p.W + w) * p.Cout + (size_t)t.g * p.Ng + t.n0 + (idx & 3) * 8) : -1;
+      }
+    u32x4 rres[NF][MF][2];
+
+    // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
+    for (int q = 0; q < nk; q += 2) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // this stage landed for every wave; everyone is done reading the other one
+      issue_next(S1{});
+      if (!(p.debug & 8)) compute(S0{});
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      issue_next(S0{});
+      if (q + 2 == nk && p.epilogue == DDX_EPI_MPSUM) {  // residual rows ride along with the last matrix phase
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+          for (int j = 0; j < MF; ++j)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              const bool ok = eoff[j][tt] >= 0 && t.n0 + i * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+              rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
+            }
+      }
+      if (!(p.debug & 8)) compute(S1{});
+    }
+
+    // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
+    if (p.debug & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[NF - 1][1][3] + acc[0][1][2]; continue; }
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int j = 0; j < MF; ++j) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 y4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * qd + e];
+          *reinterpret_cast<f32x4*>(sE + l31 * 36 + 8 * qd + 4 * khalf) = y4;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave: only the compiler must not reorder
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int idx = lane + 64 * tt;
+          const int c8 = (idx & 3) * 8;
+          const float* srow = sE + (idx >> 2) * 36 + c8;
+          const f32x4 ya = *reinterpret_cast<const f32x4*>(srow);
+          const f32x4 yb = *reinterpret_cast<const f32x4*>(srow + 4);
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { y[e] = ya[e]; y[4 + e] = yb[e]; }
+          if (p.epilogue == DDX_EPI_MPSUM) {
+            Vec16<bf16> rv;
+            rv.v = __builtin_bit_cast(bf16x8, rres[i][j][tt]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = rv.get(e) * p.res_a + y[e] * p.res_b;
+          }
+          if (p.clip > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
+          }
+          const int nch = t.n0 + i * 32 + c8;  // channel inside the group
+          if (eoff[j][tt] < 0 || nch >= p.Ng) continue;
+          const long off = eoff[j][tt] + i * 32;
+          if (p.out2) {
+            Vec16<bf16> tv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + off) = tv.v;
+          }
+          if (p.out_act) {
+            if (p.out_cs) {
+              const float* csp = p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
+              const f32x4 ca = *reinterpret_cast<const f32x4*>(csp);
+              const f32x4 cb = *reinterpret_cast<const f32x4*>(csp + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { y[e] *= ca[e]; y[4 + e] *= cb[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = mp_silu_f(y[e]);
+          }
+          Vec16<bf16> ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov.set(e, y[e]);
+          *reinterpret_cast<bf16x8*>(out + off) = ov.v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
+      }
+  }
+}
+
+template <int KS, int SK, int NF, int PD = 1>
+int launch_dma_t(const ConvParams& p, hipStream_t s) {
+  using GEO = DmaGeom<KS, SK, NF>;
+  auto kern = conv_dma_kernel<KS, SK, NF, PD>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::SMEM) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_dma)");
+    attr_done = true;
+  }
+  const int ntile_n = ceil_div(p.Ng, GEO::BN);
+  const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
+  const int grid = (int)std::min<long>(total, 512);  // 2 workgroups on each of the 256 CUs
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEO::SMEM, s, p, (int)total, ntile_n);
+  return check_launch("conv_dma");
+}
+
+// TH x TW with TW a multiple of 32 (fragments never wrap tile rows) and TH*TW = 256
+bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util) {
+  const int pad = ksize / 2;
+  const int max_rows = ksize == 3 ? DmaGeom<3, 16, 2>::AROWS : kBM;
+  double best = -1;
+  const int tws[4] = {32, 64, 128, 256};
+  for (int tw : tws) {
+    const int th = kBM / tw;
+    if ((th + 2 * pad) * (tw + 2 * pad) > max_rows) continue;
+    const double u = (double)p.H * p.W / ((double)ceil_div(p.H, th) * ceil_div(p.W, tw) * kBM);
+    if (u > best + 1e-9) { best = u; *TH = th; *TW = tw; }
+  }
+  *util = best;
+  return best > 0;
+}
+
+}  // namespace
+
+bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size) {
+  if (dtype != DDX_BF16 || (ksize != 1 && ksize != 3)) return false;
+  if (p.prologue != DDX_PRO_NONE || p.scale0 != 1.0f || (p.src1 && p.scale1 != 1.0f)) return false;
+  if (p.resample == DDX_RESAMPLE_DOWN) return false;
+  const int SK = ksize == 3 ? 16 : 32;
+  if (p.Cg % (2 * SK) || p.C0 % SK || (p.src1 && p.C1 % 8)) return false;  // stages are processed in pairs
+  if (p.CK % SK) return false;
+  if (p.Ng % 8 || p.Cout % 8) return false;
+  if (p.epilogue == DDX_EPI_MPSUM && p.out_act && p.out_cs && (p.Cout % 4)) return false;
+  if ((size_t)p.B * p.sH * p.sW >= (size_t)1 << 31) return false;
+  int TH, TW; double util;
+  if (!dma_tile(p, ksize, &TH, &TW, &util)) return false;
+  const long wgs = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, p.Ng <= 32 ? 32 : 64) * p.G;
+  // small-M layers stay on the split-K kernel (conv_mfma.hip); poorly fitting tiles too
+  // automatic choice: 3x3 layers with enough units to fill the persistent grid; 1x1 layers and small-M layers stay on
+  // the register-staged kernel (split-K, wider K chunks) until the GEMM-shaped variant lands
+  return any_size || (ksize == 3 && wgs >= 512 && util >= 0.6);
+}
+
+int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
+  ConvParams p = p_in;
+  { const char* e = std::getenv("DDX_DMA_ABLATE"); p.debug = e ? atoi(e) : 0; }
+  int TH = 0, TW = 0; double util;
+  if (!dma_tile(p, ksize, &TH, &TW, &util)) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma: no tile");
+  const int pad = ksize / 2;
+  p.TH = TH; p.TW = TW;
+  p.tiles_h = ceil_div(p.H, TH); p.tiles_w = ceil_div(p.W, TW);
+  p.arows_alloc = (TH + 2 * pad) * (TW + 2 * pad);
+  p.inv_TWP = 1.0f / (float)(TW + 2 * pad);
+  const bool narrow = p.Ng <= 32;  // one 32-channel fragment column covers the group
+  if (ksize == 3 && (p.debug & 32)) return narrow ? launch_dma_t<3, 16, 1, 2>(p, s) : launch_dma_t<3, 16, 2, 2>(p, s);
+  if (ksize == 3) return narrow ? launch_dma_t<3, 16, 1>(p, s) : launch_dma_t<3, 16, 2>(p, s);
+  return narrow ? launch_dma_t<1, 32, 1>(p, s) : launch_dma_t<1, 32, 2>(p, s);
+}
+
+}  // namespace ddx

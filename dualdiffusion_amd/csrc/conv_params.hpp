@@ -28,6 +28,7 @@ struct ConvParams {
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;
   int group_smem;  // LDS bytes of one split-K group's staging region
+  int debug;       // ablation switches (development only)
 };
 
 // index into the prepared weight tensor wp[g][chunk][tap][NgP][CK]
@@ -39,5 +40,7 @@ int launch_conv_mfma(const ConvParams& p, int ksize, int dtype, hipStream_t s); 
 bool conv_mfma_supported(const ConvParams& p, int ksize, int dtype);
 void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype);
 int launch_conv_direct(const ConvParams& p, int ksize, int dtype, hipStream_t s);  // conv_direct.hip
+bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size);  // conv_dma.hip
+int launch_conv_dma(const ConvParams& p, int ksize, hipStream_t s);
 
 }  // namespace ddx

@@ -63,8 +63,10 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            scale0: float = 1.0, scale1: float = 1.0, resample: int = L.RESAMPLE_KEEP, prologue: int = L.PRO_NONE,
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
-           out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0) -> torch.Tensor:
+           out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
+           path: str = "auto") -> torch.Tensor:
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
+    path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)."""
     B, sH, sW, C0 = src0.shape
     if out_hw is None:
@@ -76,7 +78,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
                    B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
                    prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
-                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=int(force_direct),
+                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=1 if force_direct else {"auto": 0, "direct": 1, "mfma": 2, "dma": 3}[path],
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale))
     check(lib().ddx_mpconv2d_fwd(C.byref(d), current_stream()), "mpconv2d_fwd")
     return out

@@ -94,7 +94,7 @@ typedef struct {
   float res_t;              /* t of mp_sum(residual, y, t) */
   float clip;               /* <= 0: none */
   int32_t dtype;            /* activations and wp */
-  int32_t force_direct;     /* 1 = use the scalar reference kernel (testing / odd channel counts) */
+  int32_t force_direct;     /* kernel choice: 0 automatic, 1 scalar reference kernel, 2 register-staged MFMA, 3 LDS-DMA MFMA */
   /* producer-side activation (so that the CONSUMER conv needs no prologue and stages its operand untouched):
    *   out_act = 1: the stored output is mp_silu(y * out_scale[b][cout]) (out_scale NULL: mp_silu(y))  -- conv_res0 feeding
    *                conv_res1 (unet_edm2_b4.py:119-122);

@@ -289,3 +289,55 @@ def test_conv_producer_side_activation(dtype):
     qk_perm = qk.reshape(B, 1, 64, 2, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, 128, H, W)
     ao = ops.attention(to_nhwc(qk_perm, dtype), to_nhwc(v, dtype), 1, out_scale=cs.cuda())
     assert rel_l2(to_nchw(ao), O.silu_mp(O.attention_2d(qk, v, 1) * cs[:, :, None, None])) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+DMA_CASES = {
+    # name: (B, H, W, C0, C1, Cout, groups, ksize, resample, residual, clip, out_act, twin)
+    "k3_plain": (2, 16, 64, 64, 0, 128, 1, 3, "keep", False, 0.0, False, False),
+    "k3_edges": (3, 13, 45, 32, 0, 96, 1, 3, "keep", True, 1.5, True, True),     # ragged tiles, Ng not a multiple of 64
+    "k3_cat_up": (1, 16, 40, 64, 32, 64, 1, 3, "up", True, 0.0, False, True),    # two sources + nearest-up gather
+    "k3_groups": (2, 8, 32, 128, 0, 128, 2, 3, "keep", False, 0.0, True, False),
+    "k3_long_k": (1, 8, 32, 512, 256, 64, 1, 3, "keep", True, 256.0, False, False),
+    "k1_plain": (2, 16, 64, 128, 0, 256, 1, 1, "keep", False, 0.0, False, False),
+    "k1_cat": (2, 9, 37, 64, 192, 72, 1, 1, "keep", True, 2.0, True, True),
+    "k1_long_k": (1, 4, 64, 1024, 0, 64, 1, 1, "up", False, 0.0, False, False),
+}
+
+
+@pytest.mark.parametrize("name", list(DMA_CASES))
+def test_conv_dma(name):
+    """LDS-DMA staged conv kernel (bf16, untouched operands) against the oracle and the register-staged kernel."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dtype = torch.bfloat16
+    B, H, W, C0, C1, Cout, groups, ks, resample, has_res, clip, out_act, twin = DMA_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    sh, sw = (H // 2, W // 2) if resample == "up" else (H, W)
+    a = _round(torch.randn(B, C0, sh, sw, generator=g) * 1.3, dtype)
+    b = _round(torch.randn(B, C1, sh, sw, generator=g), dtype) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // groups, ks, ks, generator=g)
+    cs = torch.rand(B, Cout, generator=g) + 0.5
+    res = _round(torch.randn(B, Cout, H, W, generator=g), dtype) if has_res else None
+    x = O.resample2x(torch.cat([a, b], 1) if C1 else a, resample)
+    y = torch.nn.functional.conv2d(x, _round(O.prepared_weight(w), dtype), padding=ks // 2, groups=groups)
+    if has_res:
+        y = O.sum_mp(res, y, 0.3)
+    if clip > 0:
+        y = y.clamp(-clip, clip)
+    ref = O.silu_mp(y * cs[:, :, None, None]) if out_act else y
+    pw = ops.wprep(w.cuda(), groups, dtype)
+    outs = {}
+    for path in ("dma", "mfma"):
+        tw_buf = torch.zeros(B, H, W, Cout, device="cuda", dtype=dtype) if twin else None
+        out = ops.conv2d(to_nhwc(a, dtype), pw, out_hw=(H, W), src1=to_nhwc(b, dtype) if C1 else None,
+                         resample=L.RESAMPLE_UP if resample == "up" else L.RESAMPLE_KEEP,
+                         residual=to_nhwc(res, dtype) if has_res else None, res_t=0.3, clip=clip, out_act=out_act,
+                         out_scale=cs.cuda() if out_act else None, out2=tw_buf, out2_scale=0.8, path=path)
+        torch.cuda.synchronize()
+        outs[path] = (out, tw_buf)
+    e = rel_l2(to_nchw(outs["dma"][0]), ref)
+    print(f"conv_dma {name}: rel-L2 vs oracle {e:.3e}")
+    assert e < TOL[dtype], (name, e)
+    assert rel_l2(outs["dma"][0].float(), outs["mfma"][0].float()) < 3e-3   # same math, different K order: bf16 rounding flips only
+    if twin:
+        assert rel_l2(to_nchw(outs["dma"][1]), O.silu_mp(0.8 * y)) < TOL[dtype]

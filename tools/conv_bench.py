@@ -24,6 +24,16 @@ CASES = {
     "L0_up_res1_raw": (4, 32, 688, 1024, 0, 512, 8, 3, 0, L.PRO_NONE, True),
     "L0_res0_enc_raw": (4, 32, 688, 256, 0, 512, 8, 3, 0, L.PRO_NONE, False),
     "L1_res1_raw": (4, 16, 344, 1024, 0, 512, 8, 3, 0, L.PRO_NONE, True),
+    "L0_res1_enc_raw": (4, 32, 688, 512, 0, 256, 8, 3, 0, L.PRO_NONE, True),
+    "L0_dec_res0_raw": (4, 32, 688, 512, 256, 512, 8, 3, 0, L.PRO_NONE, False),
+    "L0_up_res0_raw": (4, 32, 688, 512, 0, 1024, 8, 3, 1, L.PRO_NONE, False),
+    "L1_dec_res0_raw": (4, 16, 344, 768, 512, 1024, 8, 3, 0, L.PRO_NONE, False),
+    "L2_res0_raw": (4, 8, 172, 768, 0, 1536, 8, 3, 0, L.PRO_NONE, False),
+    "L2_res1_raw": (4, 8, 172, 1536, 0, 768, 8, 3, 0, L.PRO_NONE, True),
+    "L3_res0_raw": (4, 4, 86, 1024, 0, 2048, 8, 3, 0, L.PRO_NONE, False),
+    "L0_skip_cat_raw": (4, 32, 688, 512, 256, 256, 1, 1, 0, L.PRO_NONE, False),
+    "L1_skip_cat_raw": (4, 16, 344, 768, 512, 512, 1, 1, 0, L.PRO_NONE, False),
+    "L2_skip_cat_raw": (4, 8, 172, 1024, 768, 768, 1, 1, 0, L.PRO_NONE, False),
     "L0_skip_512_raw": (4, 32, 688, 512, 0, 512, 1, 1, 0, L.PRO_NONE, False),
     "L0_skip_512": (4, 32, 688, 512, 0, 512, 1, 1, 1, L.PRO_NONE, False),
     "L0_skip_cat": (4, 32, 688, 512, 256, 256, 1, 1, 0, L.PRO_NONE, False),
@@ -43,6 +53,7 @@ def main():
     ap.add_argument("--cases", default=",".join(CASES))
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--path", default="auto", help="auto | mfma | dma | both")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
@@ -59,19 +70,25 @@ def main():
         raw = name.endswith('_raw')
         kw = dict(out_hw=(H, W), src1=a1, scale0=1.0 if raw else 0.8, scale1=1.0 if raw else 1.1, resample=rs, prologue=pro,
                   chan_scale=cs if pro & L.PRO_SCALE else None, residual=res, res_t=0.3, clip=256.0, out=out)
-        for _ in range(3):
-            ops.conv2d(a0, pw, **kw)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            ops.conv2d(a0, pw, **kw)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / a.iters * 1e3
-        fl = 2.0 * B * H * W * Cout * ((C0 + C1) // G) * ks * ks
-        by = (a0.numel() + (a1.numel() if C1 else 0) + out.numel() * (2 if has_res else 1)) * a0.element_size()
-        print(f"{name:14s} {us:9.1f} us  {fl / 1e9:8.2f} GFLOP  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:8.1f} GB/s (algorithmic)")
+        for path in (["mfma", "dma"] if a.path == "both" else [a.path]):
+            kw["path"] = path
+            try:
+                for _ in range(3):
+                    ops.conv2d(a0, pw, **kw)
+            except RuntimeError as e:
+                print(f"{name:16s} {path:5s} unsupported ({e})")
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                ops.conv2d(a0, pw, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / a.iters * 1e3
+            fl = 2.0 * B * H * W * Cout * ((C0 + C1) // G) * ks * ks
+            by = (a0.numel() + (a1.numel() if C1 else 0) + out.numel() * (2 if has_res else 1)) * a0.element_size()
+            print(f"{name:16s} {path:5s} {us:9.1f} us  {fl / 1e9:8.2f} GFLOP  {fl / us / 1e6:8.1f} TFLOP/s  {by / us / 1e3:8.1f} GB/s (algorithmic)")
 
 
 if __name__ == "__main__":
