@@ -45,9 +45,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 constexpr int kBM = 256;
 
-template <int KS, int SK, int NF> struct DmaGeom {
+template <int KS, int SK, int NF, int WN> struct DmaGeom {
   static constexpr int TAPS = KS * KS, PAD = KS / 2;
-  static constexpr int BN = 32 * NF;
+  static constexpr int NW = 4 * WN;          // waves: 4 along the pixels x WN along the output channels
+  static constexpr int BN = 32 * NF * WN;
   static constexpr int RB = SK * 2;          // bytes per LDS row
   static constexpr int LPR = RB / 16;        // lanes (16-byte slots) per row
   static constexpr int RPW = 1024 / RB;      // rows per DMA wave-instruction
@@ -56,10 +57,10 @@ template <int KS, int SK, int NF> struct DmaGeom {
   static constexpr int BPIECES = (TAPS * BN + RPW - 1) / RPW;
   static constexpr int A_BYTES = APIECES * 1024, B_BYTES = BPIECES * 1024;
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int NST = 2;
-  static constexpr int AI = (APIECES + 3) / 4, BI = (BPIECES + 3) / 4;
+  static constexpr int NST = 2;  // (a 3-stage ring with counted vmcnt was measured on the 1x1 variant: no gain)
+  static constexpr int AI = (APIECES + NW - 1) / NW, BI = (BPIECES + NW - 1) / NW;
   static constexpr int EPI_WAVE = 32 * 36 * 4;  // one 32 pixel x 32 channel fp32 patch, rows padded to 36 floats
-  static constexpr int SMEM = NST * STAGE + 4 * EPI_WAVE;
+  static constexpr int SMEM = NST * STAGE + NW * EPI_WAVE;
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
   static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
 };
@@ -69,9 +70,10 @@ template <int KS, int SK, int NF> struct DmaGeom {
 // while the last stage of the current one is multiplied and its epilogue runs), and the second workgroup of every CU
 // starts half a unit late so that one workgroup's memory phases (epilogue stores, first-stage latency) fall into the
 // other's matrix phase instead of both doing the same thing at the same time.
-template <int KS, int SK, int NF, int PD>
-__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n) {
-  using GEO = DmaGeom<KS, SK, NF>;
+template <int KS, int SK, int NF, int WN, int PD>
+__global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n) {
+  using GEO = DmaGeom<KS, SK, NF, WN>;
+  constexpr int NW = GEO::NW;
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
   constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
   constexpr int KSTEPS = SK / 16;
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;  // this wave's 64-pixel slab and (32*NF)-channel slab of the unit
   const int khalf = lane >> 5, l31 = lane & 31;
   const int TW = p.TW, TWP = TW + 2 * PAD;
   const int R = (p.TH + 2 * PAD) * TWP;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
   int ahh[AI], aww[AI], aslot[AI];  // tile-independent halo coordinates of this lane's rows
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int r = (wave + 4 * i) * RPW + lrow;
+    const int r = (wave + NW * i) * RPW + lrow;
     const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
     ahh[i] = r < R ? hh - PAD : -(1 << 20);
     aww[i] = r - hh * TWP - PAD;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
   int btap[BI], bn[BI], bslot[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int r = min((wave + 4 * i) * RPW + lrow, TAPS * BN - 1);
+    const int r = min((wave + NW * i) * RPW + lrow, TAPS * BN - 1);
     btap[i] = r / BN;
     bn[i] = r - btap[i] * BN;
     bslot[i] = (lslot ^ GEO::swz(r)) * 8;
@@ -148,9 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
       bvoff[i] = (((btap[i] * p.NgP + n) << ck_shift) + bslot[i]) * 2;
     }
   };
-  auto issue_next = [&](auto stage_tag) {
+  auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
     if (iu >= total_units) return;
-    char* sbase = smem + decltype(stage_tag)::value * GEO::STAGE;
+    char* sbase = smem + (int)stage * GEO::STAGE;
     const int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
     const int src_id = cabs >= p.C0 ? 1 : 0;
     if (src_id != isrc) {  // (re)compute the per-lane row offsets for this source's channel stride
@@ -163,14 +166,14 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
     const rsrc_t rsa = src_id ? rs1 : rs0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int piece = wave + 4 * i;
+      const int piece = wave + NW * i;
       if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
     }
     const int k0 = iq * SK;
     const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int piece = wave + 4 * i;
+      const int piece = wave + NW * i;
       if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, sbase + GEO::A_BYTES + piece * 1024);
     }
     if (++iq == nk) {
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
   int aoff[MF][TAPS];
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
-    const int ml = (wave * MF + j) * 32 + l31;
+    const int ml = (wm * MF + j) * 32 + l31;
     const int th = (int)(((float)ml + 0.5f) * inv_TW);
     const int tw = ml - th * TW;
     const int base = th * TWP + tw;
@@ -199,9 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
   const int boff_r = l31 * RB;
 
   f32x16 acc[NF][MF];
-  auto compute = [&](auto stage_tag) {  // compile-time stage: every LDS address is register + immediate
-    constexpr int STG = decltype(stage_tag)::value;
-    const char* sA = smem + STG * GEO::STAGE;
+  auto compute = [&](auto stage) {  // compile-time stage: every LDS address is register + immediate
+    const char* sA = smem + (int)stage * GEO::STAGE;
     const char* sB = sA + GEO::A_BYTES;
     constexpr int SLOTS = TAPS * KSTEPS;
     // fragments are read PD slots ahead of the MFMAs that consume them (register ring of PD+1 slots), so that one wave
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
       const int tap = slot / KSTEPS, ks = slot % KSTEPS;
 #pragma unroll
       for (int i = 0; i < NF; ++i)
-        wf[buf][i] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + i * 32) * RB + boff_r + (((2 * ks + khalf) ^ bsw) << 4));
+        wf[buf][i] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + (wn * NF + i) * 32) * RB + boff_r + (((2 * ks + khalf) ^ bsw) << 4));
 #pragma unroll
       for (int j = 0; j < MF; ++j)
         xf[buf][j] = *reinterpret_cast<const bf16x8*>(sA + (aoff[j][tap] ^ (ks << 5)));
@@ -237,12 +239,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
-  // the second workgroup of a CU starts late (see above); p.debug >> 8 overrides the skew (development)
-  if ((blockIdx.x / 256) & 1) {
-    const int skew = (p.debug >> 8) ? (p.debug >> 8) : (nk * 10 + 12);  // x128 clocks ~ half a unit
-    for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(2);
-  }
-
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   if (iu < total_units) issue_setup(iu);
@@ -263,42 +259,53 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int idx = lane + 64 * tt;
-        const int ml = (wave * MF + j) * 32 + (idx >> 2);
+        const int ml = (wm * MF + j) * 32 + (idx >> 2);
         const int th = (int)(((float)ml + 0.5f) * inv_TW);
         const int tw = ml - th * TW;
         const int h = t.h0 + th, w = t.w0 + tw;
         const bool ok = h < p.H && w < p.W;
-        eoff[j][tt] = ok ? (long)((((size_t)t.b * p.H + h) * p.W + w) * p.Cout + (size_t)t.g * p.Ng + t.n0 + (idx & 3) * 8) : -1;
+        eoff[j][tt] = ok ? (long)((((size_t)t.b * p.H + h) * p.W + w) * p.Cout + (size_t)t.g * p.Ng + t.n0 + wn * (NF * 32) + (idx & 3) * 8) : -1;
       }
-    u32x4 rres[NF][MF][2];
+    u32x4 rres[NF > 2 ? 2 : NF][MF][2];
 
-    // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
-    for (int q = 0; q < nk; q += 2) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();  // this stage landed for every wave; everyone is done reading the other one
-      issue_next(S1{});
-      if (!(p.debug & 8)) compute(S0{});
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      issue_next(S0{});
-      if (q + 2 == nk && p.epilogue == DDX_EPI_MPSUM) {  // residual rows ride along with the last matrix phase
+    {
+      // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
+      for (int q = 0; q < nk; q += 2) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // this stage landed for every wave; everyone is done reading the other one
+        issue_next(S1{});
+        if (!(p.debug & 8)) compute(S0{});
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        issue_next(S0{});
+        if (NF <= 2 && q + 2 == nk && p.epilogue == DDX_EPI_MPSUM) {  // residual rows ride along with the last matrix phase
 #pragma unroll
-        for (int i = 0; i < NF; ++i)
+          for (int i = 0; i < NF; ++i)
 #pragma unroll
-          for (int j = 0; j < MF; ++j)
+            for (int j = 0; j < MF; ++j)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-              const bool ok = eoff[j][tt] >= 0 && t.n0 + i * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
-              rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
-            }
+              for (int tt = 0; tt < 2; ++tt) {
+                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
+              }
+        }
+        if (!(p.debug & 8)) compute(S1{});
       }
-      if (!(p.debug & 8)) compute(S1{});
     }
 
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
     if (p.debug & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[NF - 1][1][3] + acc[0][1][2]; continue; }
 #pragma unroll
-    for (int i = 0; i < NF; ++i)
+    for (int i = 0; i < NF; ++i) {
+      if (NF > 2 && p.epilogue == DDX_EPI_MPSUM) {  // wide tiles: no registers to prefetch all residual rows, load per column
+#pragma unroll
+        for (int j = 0; j < MF; ++j)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+            rres[i & 1][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
+          }
+      }
 #pragma unroll
       for (int j = 0; j < MF; ++j) {
 #pragma unroll
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
           for (int e = 0; e < 4; ++e) { y[e] = ya[e]; y[4 + e] = yb[e]; }
           if (p.epilogue == DDX_EPI_MPSUM) {
             Vec16<bf16> rv;
-            rv.v = __builtin_bit_cast(bf16x8, rres[i][j][tt]);
+            rv.v = __builtin_bit_cast(bf16x8, rres[NF > 2 ? (i & 1) : i][j][tt]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = rv.get(e) * p.res_a + y[e] * p.res_b;
           }
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
           }
-          const int nch = t.n0 + i * 32 + c8;  // channel inside the group
+          const int nch = t.n0 + (wn * NF + i) * 32 + c8;  // channel inside the group
           if (eoff[j][tt] < 0 || nch >= p.Ng) continue;
           const long off = eoff[j][tt] + i * 32;
           if (p.out2) {
@@ -356,13 +363,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvParams p, co
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
       }
+    }
   }
 }
 
-template <int KS, int SK, int NF, int PD = 1>
+template <int KS, int SK, int NF, int WN>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
-  using GEO = DmaGeom<KS, SK, NF>;
-  auto kern = conv_dma_kernel<KS, SK, NF, PD>;
+  using GEO = DmaGeom<KS, SK, NF, WN>;
+  static_assert(GEO::SMEM <= (WN == 1 ? 80 : 160) * 1024, "LDS budget");
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, 1>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::SMEM) != hipSuccess)
@@ -371,15 +380,19 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   }
   const int ntile_n = ceil_div(p.Ng, GEO::BN);
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
-  const int grid = (int)std::min<long>(total, 512);  // 2 workgroups on each of the 256 CUs
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), GEO::SMEM, s, p, (int)total, ntile_n);
+  const int grid = (int)std::min<long>(total, WN == 1 ? 512 : 256);  // persistent: every CU holds 8 waves
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WN), GEO::SMEM, s, p, (int)total, ntile_n);
   return check_launch("conv_dma");
 }
+
+// 1x1 layers with >= 192 output channels per group run as 256 x 256 GEMM tiles (8 waves) when that still leaves
+// enough units for the 256 CUs
+bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) { return p.Ng >= 192 && pixel_tiles * ceil_div(p.Ng, 256) >= 128; }
 
 // TH x TW with TW a multiple of 32 (fragments never wrap tile rows) and TH*TW = 256
 bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util) {
   const int pad = ksize / 2;
-  const int max_rows = ksize == 3 ? DmaGeom<3, 16, 2>::AROWS : kBM;
+  const int max_rows = ksize == 3 ? DmaGeom<3, 16, 2, 1>::AROWS : kBM;
   double best = -1;
   const int tws[4] = {32, 64, 128, 256};
   for (int tw : tws) {
@@ -406,11 +419,13 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   if ((size_t)p.B * p.sH * p.sW >= (size_t)1 << 31) return false;
   int TH, TW; double util;
   if (!dma_tile(p, ksize, &TH, &TW, &util)) return false;
-  const long wgs = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, p.Ng <= 32 ? 32 : 64) * p.G;
-  // small-M layers stay on the split-K kernel (conv_mfma.hip); poorly fitting tiles too
-  // automatic choice: 3x3 layers with enough units to fill the persistent grid; 1x1 layers and small-M layers stay on
-  // the register-staged kernel (split-K, wider K chunks) until the GEMM-shaped variant lands
-  return any_size || (ksize == 3 && wgs >= 512 && util >= 0.6);
+  if (any_size) return true;
+  // automatic choice: layers with enough units to fill the persistent grid; small-M layers stay on the register-staged
+  // kernel (split-K, wider K chunks)
+  const long tiles = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * p.G;
+  if (util < 0.6) return false;
+  if (ksize == 1 && dma_wide_1x1(p, tiles)) return true;
+  return tiles * ceil_div(p.Ng, p.Ng <= 32 ? 32 : 64) >= 512;
 }
 
 int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
@@ -423,10 +438,12 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   p.tiles_h = ceil_div(p.H, TH); p.tiles_w = ceil_div(p.W, TW);
   p.arows_alloc = (TH + 2 * pad) * (TW + 2 * pad);
   p.inv_TWP = 1.0f / (float)(TW + 2 * pad);
-  const bool narrow = p.Ng <= 32;  // one 32-channel fragment column covers the group
-  if (ksize == 3 && (p.debug & 32)) return narrow ? launch_dma_t<3, 16, 1, 2>(p, s) : launch_dma_t<3, 16, 2, 2>(p, s);
-  if (ksize == 3) return narrow ? launch_dma_t<3, 16, 1>(p, s) : launch_dma_t<3, 16, 2>(p, s);
-  return narrow ? launch_dma_t<1, 32, 1>(p, s) : launch_dma_t<1, 32, 2>(p, s);
+  // channel tile: 32 (one fragment column) or 64 with 4 waves and 2 workgroups per CU; 256 for wide 1x1 layers (8 waves).
+  // (A 128-channel 8-wave 3x3 variant measured within 3% of the 64-channel one and loses on ragged groups: not built.)
+  if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
+  if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
+  const bool wide = !(p.debug & 64) && dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);
+  return wide ? launch_dma_t<1, 32, 4, 2>(p, s) : launch_dma_t<1, 32, 2, 1>(p, s);
 }
 
 }  // namespace ddx

@@ -104,7 +104,14 @@ class PlanBuilder:
         if blk.flavor == "enc":
             pw_skip = self.prep(blk.conv_skip, npix=npix) if blk.conv_skip is not None else None
             x1, x1a = self.act(h, w, cout), self.act(h, w, cout)
-            if pw_skip is not None:
+            if pw_skip is not None and rs == RESAMPLE_DOWN:
+                # avg-pool once (memory-bound) and run the skip conv on the pooled tensor: the in-conv 2x2 gather costs
+                # four strided loads per staged vector and serialises the small-M layers
+                xd = self.act(h, w, src0.shape[3])
+                S(lambda: ops.resample2d(src0, xd, rs))
+                S(lambda: ops.conv2d(xd, pw_skip, out=x1))
+                S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
+            elif pw_skip is not None:
                 S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), resample=rs, out=x1))
                 S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
             elif rs != RESAMPLE_KEEP:

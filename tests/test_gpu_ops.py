@@ -301,6 +301,8 @@ DMA_CASES = {
     "k1_plain": (2, 16, 64, 128, 0, 256, 1, 1, "keep", False, 0.0, False, False),
     "k1_cat": (2, 9, 37, 64, 192, 72, 1, 1, "keep", True, 2.0, True, True),
     "k1_long_k": (1, 4, 64, 1024, 0, 64, 1, 1, "up", False, 0.0, False, False),
+    "k1_wide_res": (2, 8, 32, 128, 0, 320, 1, 1, "keep", True, 1.5, True, True),      # 256-channel tiles, second one ragged
+    "k3_wide_ragged": (1, 16, 32, 64, 0, 192, 1, 3, "keep", True, 0.0, False, True),  # 128-channel tiles, second one ragged
 }
 
 
