@@ -49,6 +49,13 @@ class MelStftDesc(C.Structure):
                 ("n_mel", C.c_int32), ("band_stride", C.c_int32), ("exponent", C.c_float), ("mean", C.c_float), ("scale", C.c_float)]
 
 
+class MssDesc(C.Structure):
+    _fields_ = [("sample", C.c_void_p), ("target", C.c_void_p), ("window", C.c_void_p), ("weight", C.c_void_p),
+                ("twiddle", C.c_void_p), ("loss", C.c_void_p), ("grad", C.c_void_p),
+                ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("block_width", C.c_int32),
+                ("step", C.c_int32), ("midside", C.c_int32), ("use_mse", C.c_int32), ("loss_scale", C.c_float)]
+
+
 class LinearJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("gain_ptr", C.c_void_p), ("out", C.c_void_p), ("gain", C.c_float),
                 ("add_const", C.c_float), ("O", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
@@ -88,6 +95,7 @@ PROTOTYPES = {
     "ddx_fgla_ola": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_fgla_analysis": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_void_p]),
+    "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddx_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

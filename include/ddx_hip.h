@@ -229,6 +229,31 @@ int ddx_fgla_analysis(const float* audio, const float* window, const float* twid
                       int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-scale 2-D spectral loss, one block width per call  (training/loss/multiscale_spectral.py:213-294 `MSSLoss2D.stft2d`
+ * + `mss_loss`, static frequency weighting, phase_loss_scale = 0) -- value AND gradient in one pass:
+ *   loss[b] += loss_scale * mean_{c,blocks,kh,kw} weight[kh][kw] * | |S| - |T| |   (use_mse: squared)
+ *   grad    += d(sum_b loss[b]) / d(sample)            (grad NULL: value only)
+ *   S, T = rfft2(window * block, ortho) of the reflect-padded (w/2) sample / target, blocks every `step` pixels,
+ *   midside 1: channels (L+R, L-R) (`use_midside_transform="stack"`), 0: (L, R).
+ * sample, target, grad: [B][2][H][W] fp32; window [w][w]; weight [w][w/2+1]; twiddle [w] = (cos, -sin)(2 pi k / w);
+ * loss [B] fp32.  loss and grad are ACCUMULATED: zero them before the first block width.  w in {8, 16, 32, 64}.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* sample;
+  const float* target;
+  const float* window;
+  const float* weight;
+  const float* twiddle;
+  float* loss;
+  float* grad;
+  int32_t B, C, H, W;
+  int32_t block_width, step, midside, use_mse;
+  float loss_scale;
+} ddx_mss_desc;
+
+int ddx_mss_loss_scale(const ddx_mss_desc* d, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Launch plans: a recorded sequence of the calls above, replayed with one FFI call and optionally
  * as a hipGraph (the MI355X replacement for the reference's torch.compile, modules/module.py:145-149).
  * Recording: between ddx_plan_begin() and ddx_plan_end() every entry point above is recorded into

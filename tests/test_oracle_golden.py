@@ -137,3 +137,17 @@ def test_mel_golden_and_band_edges():
     host = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
     assert torch.equal(host.band_edges(), t["band_edges"])          # product-side table == reference non-zero support
     assert torch.equal(host.filters, fb)
+
+
+def test_mss_loss_golden():
+    """MSS loss oracle (value and gradient) against fixtures produced by the reference's MSSLoss2D."""
+    from oracle import mss_oracle as M
+    t, m = load_golden("mss_loss")
+    for name, kw in m.items():
+        if not isinstance(kw, dict):
+            continue                      # provenance entries (torch version, thread count)
+        kw = dict(kw)
+        kw["block_widths"] = tuple(kw["block_widths"])
+        loss, grad = M.mss_loss_and_grad(t[f"{name}.sample"], t[f"{name}.target"], **kw)
+        assert rel_l2(loss, t[f"{name}.loss"]) < 1e-6, name
+        assert rel_l2(grad, t[f"{name}.grad"]) < 1e-5, name

@@ -450,6 +450,40 @@ def gen_sigma() -> None:
                                                         "scale_invariant": dict(dist_scale=0.7), "linear": dict(dist_scale=2.0)}))
 
 
+def gen_mss() -> None:
+    """MSSLoss2D (training/loss/multiscale_spectral.py:136-296): per-sample loss and d(sum loss)/d(sample)."""
+    print("mss")
+    from training.loss.multiscale_spectral import MSSLoss2D, MSSLoss2DConfig
+    sys.path.insert(0, ROOT)
+    from oracle import mss_oracle as M
+    t, meta = {}, {}
+    cases = {
+        "default": (dict(), (2, 2, 64, 96)),
+        "hann_f2_mse": (dict(block_window_fn="hann", frequency_weighting="f^2", use_mse_loss=True, use_midside_transform="none",
+                             block_widths=(8, 32), frequency_weight_exponent=0.5, block_width_weight_exponent=0.25), (1, 2, 48, 40)),
+        "ragged": (dict(block_widths=(16, 64), block_overlap=4, block_window_fn="none"), (1, 2, 70, 50)),   # 64 > W: skipped
+    }
+    for name, (kw, shape) in cases.items():
+        g = torch.Generator().manual_seed(sum(map(ord, name)))
+        sample = torch.randn(*shape, generator=g)
+        target = sample * 0.7 + 0.5 * torch.randn(*shape, generator=g)
+        ref = MSSLoss2D(MSSLoss2DConfig(**kw), torch.device("cpu"))
+        s = sample.clone().requires_grad_(True)
+        loss = ref.mss_loss(s, target)
+        loss.sum().backward()
+        okw = dict(block_widths=kw.get("block_widths", (8, 16, 32, 64)), block_overlap=kw.get("block_overlap", 8),
+                   window_fn=kw.get("block_window_fn", "flat_top"), weighting=kw.get("frequency_weighting", "product"),
+                   weight_exponent=kw.get("frequency_weight_exponent", 1.0), width_weight_exponent=kw.get("block_width_weight_exponent", 0.0),
+                   midside=kw.get("use_midside_transform", "stack"), use_mse=kw.get("use_mse_loss", False))
+        ol, og = M.mss_loss_and_grad(sample, target, **okw)
+        check(f"mss {name} loss", ol, loss.detach(), 1e-6)
+        check(f"mss {name} grad", og, s.grad, 1e-5)
+        t[f"{name}.sample"], t[f"{name}.target"] = sample, target
+        t[f"{name}.loss"], t[f"{name}.grad"] = loss.detach(), s.grad.detach()
+        meta[name] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in okw.items()}
+    save("mss_loss", t, meta)
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -460,7 +494,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
