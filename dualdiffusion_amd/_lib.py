@@ -28,7 +28,8 @@ class WPrepDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("gain_ptr", C.c_void_p), ("gain", C.c_float),
                 ("w_dtype", C.c_int32), ("wp_dtype", C.c_int32), ("Cout", C.c_int32), ("Cg", C.c_int32),
                 ("ksize", C.c_int32), ("groups", C.c_int32), ("CK", C.c_int32), ("normalize", C.c_int32),
-                ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float)]
+                ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float),
+                ("transpose", C.c_int32), ("row_scale", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):

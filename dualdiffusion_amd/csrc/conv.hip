@@ -45,6 +45,46 @@ __global__ __launch_bounds__(256) void wprep_kernel(const TW_* __restrict__ w, T
   }
 }
 
+// ---- data-gradient (transposed) preparation: per-row scale first, then one workgroup per destination row (g, c)
+template <typename TW_>
+__global__ __launch_bounds__(256) void wprep_rowscale_kernel(const TW_* __restrict__ w, float* __restrict__ row_scale, const float* gain_ptr,
+                                                             float gain, int fan, int normalize, float eps) {
+  __shared__ float scratch[4];
+  const TW_* wr = w + (size_t)blockIdx.x * fan;
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
+    ss = block_sum_256(ss, scratch);
+    inv = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  }
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  if (threadIdx.x == 0) row_scale[blockIdx.x] = gn / sqrtf((float)fan) / inv;
+}
+
+template <typename TW_, typename TP>
+__global__ __launch_bounds__(256) void wprep_transposed_kernel(const TW_* __restrict__ w, TP* __restrict__ wp, const float* __restrict__ row_scale,
+                                                               int Cout, int Cg, int taps, int G, int CK, int qk_d, int in_split,
+                                                               float in_s0, float in_s1) {
+  const int ci = blockIdx.x;  // destination row = input channel of the forward conv
+  const int Ng = Cout / G, CgP = (Cg + 31) / 32 * 32, nchunk = (Ng + CK - 1) / CK;
+  const int g = ci / Cg, c = ci - g * Cg;
+  const float cscale = in_split > 0 ? (ci < in_split ? in_s0 : in_s1) : 1.0f;
+  for (int i = threadIdx.x; i < Ng * taps; i += 256) {
+    const int n = i / taps, tap = i - n * taps;
+    const int od = g * Ng + n;
+    int os = od;
+    if (qk_d > 0) {
+      const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
+      const int s = rem / qk_d, dd = rem - s * qk_d;
+      os = head * 2 * qk_d + dd * 2 + s;
+    }
+    const float x = to_f32<TW_>(w[((size_t)os * Cg + c) * taps + tap]) * row_scale[os] * cscale;
+    wp[wp_index(g, c, taps - 1 - tap, n, nchunk, taps, CgP, CK)] = from_f32<TP>(x);
+  }
+}
+
 template <typename TW_>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(TW_* w, int64_t fan, float eps) {
   __shared__ float scratch[4];
@@ -80,6 +120,31 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
   if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 32 && d.CK != 64 && d.CK != 128))
     return set_error(DDX_ERR_ARG, "wprep: bad shape");
   if (d.qk_head_dim > 0 && (d.groups != 1 || d.Cout % (2 * d.qk_head_dim))) return set_error(DDX_ERR_ARG, "wprep: bad qk_head_dim");
+  if (d.transpose) {
+    if (!d.row_scale) return set_error(DDX_ERR_ARG, "wprep: transpose needs the row_scale workspace");
+    return dispatch([d](hipStream_t s) -> int {
+      const int taps = d.ksize * d.ksize, Ng = d.Cout / d.groups, Cin = d.Cg * d.groups, fan = d.Cg * taps;
+      const size_t bytes = ddx_wprep_bytes(Cin, Ng, d.ksize, d.groups, d.CK, d.wp_dtype);
+      if (round_up(d.Cg, 32) != d.Cg || Ng % d.CK) {
+        if (hipMemsetAsync(d.wp, 0, bytes, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "wprep: memset");
+      }
+#define DDX_WPREP_T(TWT, TPT)                                                                                              \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL((wprep_rowscale_kernel<TWT>), dim3(d.Cout), dim3(256), 0, s, (const TWT*)d.w, d.row_scale, d.gain_ptr, \
+                       d.gain, fan, d.normalize, 1e-4f);                                                                   \
+    hipLaunchKernelGGL((wprep_transposed_kernel<TWT, TPT>), dim3(Cin), dim3(256), 0, s, (const TWT*)d.w, (TPT*)d.wp,        \
+                       (const float*)d.row_scale, d.Cout, d.Cg, taps, d.groups, d.CK, d.qk_head_dim, d.in_split, d.in_scale0, \
+                       d.in_scale1);                                                                                       \
+  } while (0)
+      if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_F32) DDX_WPREP_T(float, float);
+      else if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_BF16) DDX_WPREP_T(float, bf16);
+      else if (d.w_dtype == DDX_BF16 && d.wp_dtype == DDX_BF16) DDX_WPREP_T(bf16, bf16);
+      else if (d.w_dtype == DDX_BF16 && d.wp_dtype == DDX_F32) DDX_WPREP_T(bf16, float);
+      else return set_error(DDX_ERR_ARG, "wprep: dtype");
+#undef DDX_WPREP_T
+      return check_launch("wprep(transpose)");
+    }, stream, "wprep");
+  }
   return dispatch([d](hipStream_t s) -> int {
     const int taps = d.ksize * d.ksize;
     const int Ng = d.Cout / d.groups;

@@ -18,7 +18,7 @@ from ._lib import check, current_stream, dtype_code, lib, ptr
 class PreparedWeight:
     """Output of weight preparation (mp_tools.py:359-364) in the implicit-GEMM layout."""
 
-    __slots__ = ("wp", "Cout", "Cg", "ksize", "groups", "CK", "dtype", "desc")
+    __slots__ = ("wp", "Cout", "Cg", "ksize", "groups", "CK", "dtype", "desc", "workspace")
 
     def __init__(self, wp, Cout, Cg, ksize, groups, CK, dtype, desc):
         self.wp, self.Cout, self.Cg, self.ksize, self.groups, self.CK, self.dtype, self.desc = wp, Cout, Cg, ksize, groups, CK, dtype, desc
@@ -31,12 +31,15 @@ def pick_ck(Cg: int, ksize: int, dtype: torch.dtype, npix: int = 0) -> int:
 def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float = 1.0, gain_ptr: Optional[torch.Tensor] = None,
           normalize: bool = False, qk_head_dim: int = 0, CK: Optional[int] = None, cg_pad: Optional[int] = None,
           out: Optional[torch.Tensor] = None, npix: int = 0, in_split: int = 0, in_scale0: float = 1.0,
-          in_scale1: float = 1.0) -> PreparedWeight:
+          in_scale1: float = 1.0, transpose: bool = False) -> PreparedWeight:
     """Prepare MPConv weights `[Cout, Cg, k, k]` for ddx_mpconv2d_fwd.  `cg_pad`: channel count of the activation
-    tensor per group when it is zero-padded beyond the weight's Cg (conv_in: 6 -> 8)."""
+    tensor per group when it is zero-padded beyond the weight's Cg (conv_in: 6 -> 8).
+    transpose: prepare the data-gradient conv instead (dX = conv2d(dY, wprep(w, transpose=True)))."""
     assert weight.is_contiguous()
     Cout, Cg = weight.shape[0], weight.shape[1]
     ksize = weight.shape[2] if weight.ndim == 4 else 1
+    if transpose:
+        return _wprep_transposed(weight, groups, dtype, gain, gain_ptr, normalize, qk_head_dim, CK, out, npix, in_split, in_scale0, in_scale1)
     if CK is None:
         CK = pick_ck(cg_pad or Cg, ksize, dtype, npix)
     nbytes = lib().ddx_wprep_bytes(Cout, Cg, ksize, groups, CK, dtype_code(dtype))
@@ -50,6 +53,26 @@ def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float 
                     normalize=int(normalize), qk_head_dim=qk_head_dim, in_split=in_split, in_scale0=in_scale0, in_scale1=in_scale1)
     check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep")
     return PreparedWeight(out, Cout, Cg, ksize, groups, CK, dtype, d)
+
+
+def _wprep_transposed(weight, groups, dtype, gain, gain_ptr, normalize, qk_head_dim, CK, out, npix, in_split, in_scale0, in_scale1):
+    Cout, Cg = weight.shape[0], weight.shape[1]
+    ksize = weight.shape[2] if weight.ndim == 4 else 1
+    Ng, Cin = Cout // groups, Cg * groups
+    if CK is None:
+        CK = pick_ck(Ng, ksize, dtype, npix)
+    nbytes = lib().ddx_wprep_bytes(Cin, Ng, ksize, groups, CK, dtype_code(dtype))
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    assert out.numel() >= nbytes
+    ws = torch.empty(Cout, dtype=torch.float32, device=weight.device)
+    d = L.WPrepDesc(w=ptr(weight), wp=ptr(out), gain_ptr=ptr(gain_ptr), gain=float(gain), w_dtype=dtype_code(weight.dtype),
+                    wp_dtype=dtype_code(dtype), Cout=Cout, Cg=Cg, ksize=ksize, groups=groups, CK=CK, normalize=int(normalize),
+                    qk_head_dim=qk_head_dim, in_split=in_split, in_scale0=in_scale0, in_scale1=in_scale1, transpose=1, row_scale=ptr(ws))
+    check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep(transpose)")
+    pw = PreparedWeight(out, Cin, Ng, ksize, groups, CK, dtype, d)
+    pw.workspace = ws      # keeps the row-scale workspace alive as long as the prepared weight
+    return pw
 
 
 def normalize_weights_(weight: torch.Tensor) -> None:

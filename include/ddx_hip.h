@@ -59,6 +59,12 @@ typedef struct {
    * decoder blocks): input channels < in_split are scaled by in_scale0, the rest by in_scale1.  in_split <= 0: none. */
   int32_t in_split;
   float in_scale0, in_scale1;
+  /* transpose = 1: emit the weights of the DATA-GRADIENT conv instead (backward of F.conv2d w.r.t. its input):
+   *   dX = conv(dY, wp_t) with wp_t[g][c][n][tap] = w'[g*Ng+n][c][flipped tap], i.e. a conv with Cout' = groups*Cg output
+   *   channels and Cg' = Ng input channels per group, consumed by ddx_mpconv2d_fwd like any other prepared weight
+   *   (size ddx_wprep_bytes(groups*Cg, Ng, ksize, groups, CK, dtype)).  row_scale: [Cout] fp32 workspace (caller-owned). */
+  int32_t transpose;
+  float* row_scale;
 } ddx_wprep_desc;
 
 size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32_t groups, int32_t CK, int32_t dtype);

@@ -343,3 +343,37 @@ def test_conv_dma(name):
     assert rel_l2(outs["dma"][0].float(), outs["mfma"][0].float()) < 3e-3   # same math, different K order: bf16 rounding flips only
     if twin:
         assert rel_l2(to_nchw(outs["dma"][1]), O.silu_mp(0.8 * y)) < TOL[dtype]
+
+
+DGRAD_CASES = {
+    # name: (B, H, W, Cin, Cout, groups, ksize, normalize)
+    "k3_grouped": (2, 16, 32, 128, 256, 8, 3, True),
+    "k3_dense_odd": (1, 9, 21, 64, 96, 1, 3, False),
+    "k1": (2, 8, 24, 192, 128, 1, 1, True),
+    "k3_big_dma": (2, 32, 64, 256, 512, 8, 3, False),     # large enough for the LDS-DMA kernel in bf16
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", list(DGRAD_CASES))
+def test_conv_dgrad(name, dtype):
+    """Data gradient of MPConv = the forward kernels run on transposed/flipped prepared weights (wprep(transpose=True)),
+    against torch autograd through the oracle's weight path."""
+    ops = _ops()
+    B, H, W, Cin, Cout, groups, ks, normalize = DGRAD_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin // groups, ks, ks, generator=g)
+    gain = torch.tensor(0.8)
+    dy = _round(torch.randn(B, Cout, H, W, generator=g), dtype)
+    wp_ref = O.prepared_weight(w, gain, training=normalize)
+    if dtype == torch.bfloat16:
+        wp_ref = _round(wp_ref, dtype)
+    y = torch.nn.functional.conv2d(x, wp_ref, padding=ks // 2, groups=groups)
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    pw_t = ops.wprep(w.cuda(), groups, dtype, gain_ptr=gain.cuda().reshape(1), normalize=normalize, transpose=True)
+    dx = ops.conv2d(to_nhwc(dy, dtype), pw_t)
+    torch.cuda.synchronize()
+    e = rel_l2(to_nchw(dx), dx_ref)
+    print(f"dgrad {name} {dtype}: rel-L2 {e:.3e}")
+    assert dx.shape == (B, H, W, Cin) and e < TOL[dtype], (name, e)
