@@ -50,6 +50,12 @@ class MelStftDesc(C.Structure):
                 ("n_mel", C.c_int32), ("band_stride", C.c_int32), ("exponent", C.c_float), ("mean", C.c_float), ("scale", C.c_float)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x0", C.c_void_p), ("x1", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32), ("Cout", C.c_int32),
+                ("groups", C.c_int32), ("ksize", C.c_int32), ("resample", C.c_int32), ("dtype", C.c_int32), ("accumulate", C.c_int32)]
+
+
 class MssDesc(C.Structure):
     _fields_ = [("sample", C.c_void_p), ("target", C.c_void_p), ("window", C.c_void_p), ("weight", C.c_void_p),
                 ("twiddle", C.c_void_p), ("loss", C.c_void_p), ("grad", C.c_void_p),
@@ -96,6 +102,8 @@ PROTOTYPES = {
     "ddx_fgla_ola": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_fgla_analysis": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_float, C.c_void_p]),
+    "ddx_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
+    "ddx_mpconv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

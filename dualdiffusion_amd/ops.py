@@ -107,6 +107,26 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     return out
 
 
+def conv2d_wgrad(dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, *, x1: Optional[torch.Tensor] = None,
+                 resample: int = L.RESAMPLE_KEEP, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """Weight gradient of the conv w.r.t. its prepared weight: dy `[B,H,W,Cout]`, operand x0 (| x1) NHWC bf16 ->
+    fp32 `[Cout, Cin/groups, k, k]` (see include/ddx_hip.h)."""
+    B, H, W, Cout = dy.shape
+    C0 = x0.shape[3]
+    C1 = x1.shape[3] if x1 is not None else 0
+    if out is None:
+        out = torch.empty(Cout, (C0 + C1) // groups, ksize, ksize, dtype=torch.float32, device=dy.device)
+    d = L.WgradDesc(dy=ptr(dy), x0=ptr(x0), x1=ptr(x1), dw=ptr(out), workspace=None, B=B, H=H, W=W, C0=C0, C1=C1, Cout=Cout,
+                    groups=groups, ksize=ksize, resample=resample, dtype=dtype_code(dy.dtype), accumulate=int(accumulate))
+    nbytes = lib().ddx_wgrad_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        check(-1, "mpconv2d_wgrad (workspace query)")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    d.workspace = ptr(ws)
+    check(lib().ddx_mpconv2d_wgrad(C.byref(d), current_stream()), "mpconv2d_wgrad")
+    return out
+
+
 def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4, out_act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RMS normalisation over the last (channel) axis of contiguous rows; `out_act` also receives mp_silu(result)."""
     Cn = x.shape[-1]

@@ -117,6 +117,32 @@ int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
 int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward of the conv (training, unet_trainer.py:246 `accelerator.backward`):
+ *   data gradient  : dX = ddx_mpconv2d_fwd(dY, wprep(..., transpose = 1))  -- the forward kernels on transposed weights;
+ *   weight gradient: ddx_mpconv2d_wgrad below, w.r.t. the PREPARED weight w' (natural layout [Cout][Cg][ks][ks], fp32):
+ *       dW'[o][c][kh][kw] = sum_{b,h,w} dY[b][h][w][o] * X[b][h+kh-p][w+kw-p][g*Cg+c]
+ *   X is the conv's operand exactly as the forward staged it (activated twin / raw tensor; two NHWC sources = mp_cat with
+ *   the scales folded into w'; resample UP = nearest-upsampled on the fly).  bf16 operands, fp32 accumulation and result.
+ *   workspace: ddx_wgrad_workspace_bytes() bytes (per-split partial sums, summed deterministically); accumulate = 1
+ *   adds to dw instead of overwriting it.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* dy;           /* NHWC [B][H][W][Cout] */
+  const void* x0;           /* NHWC [B][sH][sW][C0] */
+  const void* x1;           /* NHWC [B][sH][sW][C1] or NULL */
+  float* dw;                /* [Cout][(C0+C1)/groups][ks][ks] fp32 */
+  float* workspace;
+  int32_t B, H, W;          /* size of dY (= conv output) */
+  int32_t C0, C1, Cout, groups, ksize;
+  int32_t resample;         /* DDX_RESAMPLE_KEEP | DDX_RESAMPLE_UP */
+  int32_t dtype;            /* DDX_BF16 */
+  int32_t accumulate;
+} ddx_wgrad_desc;
+
+size_t ddx_wgrad_workspace_bytes(const ddx_wgrad_desc* d);
+int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* d, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RMS ("pixel") normalisation over the channel axis of NHWC rows  (mp_tools.py:42-49 with dim=1,
  * unet_edm2_b4.py:117): y = x / (eps + ||x||_2 / sqrt(C)).  rows = B*H*W.  In place allowed.
  * ------------------------------------------------------------------------------------------------ */

@@ -377,3 +377,42 @@ def test_conv_dgrad(name, dtype):
     e = rel_l2(to_nchw(dx), dx_ref)
     print(f"dgrad {name} {dtype}: rel-L2 {e:.3e}")
     assert dx.shape == (B, H, W, Cin) and e < TOL[dtype], (name, e)
+
+
+WGRAD_CASES = {
+    # name: (B, H, W, C0, C1, Cout, groups, ksize, resample)
+    "k3_grouped": (2, 16, 64, 256, 0, 512, 8, 3, "keep"),
+    "k3_narrow_n": (2, 13, 45, 512, 0, 256, 8, 3, "keep"),       # Ng = 32 < channel tile, ragged pixel tiles
+    "k3_dense": (1, 8, 40, 64, 0, 96, 1, 3, "keep"),             # Cg = 64: two input-channel tiles, Ng = 96 ragged
+    "k3_cat_up": (1, 16, 32, 128, 128, 256, 8, 3, "up"),         # two sources, nearest-up operand
+    "k1": (2, 8, 24, 192, 0, 128, 1, 1, "keep"),
+    "k1_cat": (1, 6, 50, 128, 64, 72, 1, 1, "keep"),
+}
+
+
+@pytest.mark.parametrize("name", list(WGRAD_CASES))
+def test_conv_wgrad(name):
+    """Weight gradient kernel (LDS-DMA + transpose reads) against torch autograd on the same bf16-rounded operands."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dtype = torch.bfloat16
+    B, H, W, C0, C1, Cout, groups, ks, resample = WGRAD_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    sh, sw = (H // 2, W // 2) if resample == "up" else (H, W)
+    a = _round(torch.randn(B, C0, sh, sw, generator=g), dtype)
+    b = _round(torch.randn(B, C1, sh, sw, generator=g), dtype) if C1 else None
+    dy = _round(torch.randn(B, Cout, H, W, generator=g), dtype)
+    w = torch.randn(Cout, (C0 + C1) // groups, ks, ks, generator=g, requires_grad=True)
+    x = O.resample2x(torch.cat([a, b], 1) if C1 else a, resample)
+    y = torch.nn.functional.conv2d(x, w, padding=ks // 2, groups=groups)
+    (dw_ref,) = torch.autograd.grad(y, w, dy)
+    dw = ops.conv2d_wgrad(to_nhwc(dy, dtype), to_nhwc(a, dtype), groups, ks, x1=to_nhwc(b, dtype) if C1 else None,
+                          resample=L.RESAMPLE_UP if resample == "up" else L.RESAMPLE_KEEP)
+    torch.cuda.synchronize()
+    e = rel_l2(dw, dw_ref)
+    print(f"wgrad {name}: rel-L2 {e:.3e}")
+    assert dw.shape == w.shape and e < 2e-5, (name, e)       # exact bf16 products, fp32 accumulation
+    # accumulate = 1 adds to the existing gradient
+    dw2 = ops.conv2d_wgrad(to_nhwc(dy, dtype), to_nhwc(a, dtype), groups, ks, x1=to_nhwc(b, dtype) if C1 else None,
+                           resample=L.RESAMPLE_UP if resample == "up" else L.RESAMPLE_KEEP, out=dw.clone(), accumulate=True)
+    assert rel_l2(dw2, 2 * dw_ref) < 2e-5
