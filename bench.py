@@ -142,6 +142,8 @@ def main() -> None:
         prof = eng.fplan.profile(reps=3)
         fam = {}
         for tag, fl, by, ms in prof:
+            if tag in ("fork", "join"):
+                continue                      # lane markers of the plan, not launches
             f = fam.setdefault(tag, [0, 0.0, 0.0, 0.0])
             f[0] += 1; f[1] += fl; f[2] += by; f[3] += ms
         dom = max(fam.items(), key=lambda kv: kv[1][3])

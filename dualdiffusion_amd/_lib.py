@@ -111,6 +111,9 @@ PROTOTYPES = {
     "ddx_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_plan_begin": (C.c_void_p, []),
     "ddx_plan_end": (C.c_int, [C.c_void_p]),
+    "ddx_plan_fork": (C.c_int, []),
+    "ddx_plan_main": (C.c_int, []),
+    "ddx_plan_join": (C.c_int, []),
     "ddx_plan_num_ops": (C.c_int, [C.c_void_p]),
     "ddx_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddx_plan_graph_build": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -4,6 +4,7 @@
 // either eagerly or as a hipGraph captured from that replay -- the MI355X stand-in for the reference's
 // torch.compile(fullgraph=True) of UNet.forward (reference src/modules/module.py:145-149): shapes are static, so the
 // whole forward is one graph launch with no per-kernel host work.
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -11,12 +12,22 @@
 
 struct ddx_op_meta { const char* tag; double flops, bytes; };
 
+// Two lanes: ops recorded between ddx_plan_fork() and ddx_plan_main() run on a side stream that first waits for
+// everything recorded before the fork; ddx_plan_join() makes the main stream wait for the side stream.  Under graph capture
+// this produces parallel branches (independent small kernels of one block overlap instead of queueing).
+enum { DDX_LANE_MAIN = 0, DDX_LANE_SIDE = 1, DDX_MARK_FORK = 2, DDX_MARK_JOIN = 3 };
+
 struct ddx_plan {
   std::vector<ddx::LaunchFn> ops;
   std::vector<ddx_op_meta> meta;
+  std::vector<int> kind;  // per op: lane of a launch, or a fork / join marker (ops[i] is empty for markers)
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool recording = false;
+  int lane = DDX_LANE_MAIN;
+  bool forked = false;
 };
 
 namespace ddx {
@@ -42,6 +53,7 @@ int dispatch(LaunchFn&& fn, ddx_stream stream, const char* tag, double flops, do
   if (g_recording) {
     g_recording->ops.emplace_back(std::move(fn));
     g_recording->meta.push_back(ddx_op_meta{tag, flops, bytes});
+    g_recording->kind.push_back(g_recording->lane);
     return DDX_OK;
   }
   return fn(reinterpret_cast<hipStream_t>(stream));
@@ -60,8 +72,72 @@ extern "C" ddx_plan* ddx_plan_begin(void) {
   return p;
 }
 
+static void plan_mark(ddx_plan* p, int kind) {
+  p->ops.emplace_back(ddx::LaunchFn());
+  p->meta.push_back(ddx_op_meta{kind == DDX_MARK_FORK ? "fork" : "join", 0.0, 0.0});
+  p->kind.push_back(kind);
+}
+
+extern "C" int ddx_plan_fork(void) {
+  ddx_plan* p = ddx::g_recording;
+  if (!p) return DDX_OK;  // not recording: everything runs in issue order on the caller's stream
+  if (p->forked) return ddx::set_error(DDX_ERR_ARG, "plan_fork: already forked (join first)");
+  plan_mark(p, DDX_MARK_FORK);
+  p->forked = true;
+  p->lane = DDX_LANE_SIDE;
+  return DDX_OK;
+}
+
+extern "C" int ddx_plan_main(void) {
+  if (ddx::g_recording) ddx::g_recording->lane = DDX_LANE_MAIN;
+  return DDX_OK;
+}
+
+extern "C" int ddx_plan_join(void) {
+  ddx_plan* p = ddx::g_recording;
+  if (!p) return DDX_OK;
+  if (!p->forked) return DDX_OK;
+  plan_mark(p, DDX_MARK_JOIN);
+  p->forked = false;
+  p->lane = DDX_LANE_MAIN;
+  return DDX_OK;
+}
+
+// replay every op in order; launches of the side lane go to the plan's side stream, markers become event edges
+static int plan_replay(ddx_plan* p, hipStream_t s, bool lanes) {
+  static const bool lanes_enabled = []() { const char* e = std::getenv("DDX_PLAN_LANES"); return !e || e[0] != '0'; }();
+  lanes = lanes && lanes_enabled;
+  if (lanes && !p->side) {
+    bool any = false;
+    for (int k : p->kind) any = any || k == DDX_MARK_FORK;
+    if (any) {
+      if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess)
+        return ddx::set_error(DDX_ERR_LAUNCH, "plan: side stream / events");
+    }
+  }
+  for (size_t i = 0; i < p->ops.size(); ++i) {
+    const int k = p->kind[i];
+    if (k == DDX_MARK_FORK) {
+      if (lanes && (hipEventRecord(p->ev_fork, s) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess))
+        return ddx::set_error(DDX_ERR_LAUNCH, "plan: fork");
+      continue;
+    }
+    if (k == DDX_MARK_JOIN) {
+      if (lanes && (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess))
+        return ddx::set_error(DDX_ERR_LAUNCH, "plan: join");
+      continue;
+    }
+    const int rc = p->ops[i]((lanes && k == DDX_LANE_SIDE) ? p->side : s);
+    if (rc != DDX_OK) return rc;
+  }
+  return DDX_OK;
+}
+
 extern "C" int ddx_plan_end(ddx_plan* p) {
   if (!p || ddx::g_recording != p) return ddx::set_error(DDX_ERR_ARG, "plan_end: not the recording plan");
+  if (p->forked) { plan_mark(p, DDX_MARK_JOIN); p->forked = false; p->lane = DDX_LANE_MAIN; }
   p->recording = false;
   ddx::g_recording = nullptr;
   return DDX_OK;
@@ -71,12 +147,7 @@ extern "C" int ddx_plan_num_ops(const ddx_plan* p) { return p ? (int)p->ops.size
 
 extern "C" int ddx_plan_run(ddx_plan* p, ddx_stream stream) {
   if (!p || p->recording) return ddx::set_error(DDX_ERR_ARG, "plan_run: bad plan");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  for (auto& op : p->ops) {
-    const int rc = op(s);
-    if (rc != DDX_OK) return rc;
-  }
-  return DDX_OK;
+  return plan_replay(p, reinterpret_cast<hipStream_t>(stream), true);
 }
 
 extern "C" int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream) {
@@ -86,11 +157,7 @@ extern "C" int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream) {
   if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
     return ddx::set_error(DDX_ERR_LAUNCH, "plan_graph_build: hipStreamBeginCapture");
-  int rc = DDX_OK;
-  for (auto& op : p->ops) {
-    rc = op(s);
-    if (rc != DDX_OK) break;
-  }
+  const int rc = plan_replay(p, s, true);
   hipGraph_t g = nullptr;
   const hipError_t e = hipStreamEndCapture(s, &g);
   if (rc != DDX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -132,8 +199,8 @@ extern "C" int ddx_plan_profile(ddx_plan* p, ddx_stream stream, int reps, float*
   int rc = DDX_OK;
   for (int r = 0; r < reps && rc == DDX_OK; ++r) {
     (void)hipEventRecord(ev[0], s);
-    for (size_t i = 0; i < n; ++i) {
-      rc = p->ops[i](s);
+    for (size_t i = 0; i < n; ++i) {  // lanes serialised: per-op durations, not the overlapped schedule
+      if (p->ops[i]) rc = p->ops[i](s);
       if (rc != DDX_OK) break;
       (void)hipEventRecord(ev[i + 1], s);
     }
@@ -154,5 +221,8 @@ extern "C" void ddx_plan_destroy(ddx_plan* p) {
   if (ddx::g_recording == p) ddx::g_recording = nullptr;
   if (p->exec) (void)hipGraphExecDestroy(p->exec);
   if (p->graph) (void)hipGraphDestroy(p->graph);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  if (p->side) (void)hipStreamDestroy(p->side);
   delete p;
 }

@@ -16,7 +16,7 @@ from typing import Callable, Optional
 import torch
 
 from . import ops
-from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan
+from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan, check, lib
 
 _RESAMPLE = {"keep": RESAMPLE_KEEP, "up": RESAMPLE_UP, "down": RESAMPLE_DOWN}
 
@@ -128,9 +128,17 @@ class PlanBuilder:
                 S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU,
                                      out_act=True, out_scale=c_emb, out=y0))
             if blk.conv_skip is not None:
+                # the skip conv only depends on the block input: it runs on the plan's side lane, next to conv_res0
                 pw_skip = self.prep(blk.conv_skip, npix=npix, in_split=src0.shape[3] if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
                 sk = self.act(h, w, cout)
-                S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, resample=rs, out=sk))
+                # (only where the kernels leave CUs idle: large layers fill the chip on their own and lose from sharing it)
+                two_lanes = npix <= self.LANE_MAX_PIXELS
+                if two_lanes:
+                    self.steps.insert(len(self.steps) - 1, self._fork)
+                self.steps.insert(len(self.steps) - 1, lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, resample=rs, out=sk))
+                if two_lanes:
+                    self.steps.insert(len(self.steps) - 1, self._main)
+                    S(self._join)
             elif rs != RESAMPLE_KEEP:
                 sk = self.act(h, w, cout)      # no skip conv: the residual is the (resampled) block input itself
                 S(lambda: ops.resample2d(src0, sk, rs))
@@ -146,11 +154,36 @@ class PlanBuilder:
         pw_v, pw_proj = self.prep(blk.attn_v, npix=npix), self.prep(blk.attn_proj, npix=npix)
         qk, vv, ao, xa = self.act(h, w, 2 * cout), self.act(h, w, cout), self.act(h, w, cout), self.act(h, w, cout)
         tw_proj = dict(out2=twin, out2_scale=twin_scale) if twin is not None else {}
-        S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
+        two_lanes = npix <= self.LANE_MAX_PIXELS
+        if two_lanes:
+            S(self._fork)                                       # attn_v next to attn_qk (both read the block output)
         S(lambda: ops.conv2d(xo, pw_v, out=vv))
+        if two_lanes:
+            S(self._main)
+        S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
+        if two_lanes:
+            S(self._join)
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
+
+    # B*H*W up to which independent convs of a block (skip conv || conv_res0, attn_v || attn_qk) are put on two lanes of
+    # the plan.  Measured on MI355X (hipGraph): every fork/join pair costs more cross-queue synchronisation than the
+    # overlapped 15-20 us kernels save (5.30 vs 5.16 ms per step with 30 forks at L3/L4) -> off by default.
+    LANE_MAX_PIXELS = 0
+
+    # two-lane plan markers (no-ops outside a recording)
+    @staticmethod
+    def _fork() -> None:
+        check(lib().ddx_plan_fork(), "plan_fork")
+
+    @staticmethod
+    def _main() -> None:
+        check(lib().ddx_plan_main(), "plan_main")
+
+    @staticmethod
+    def _join() -> None:
+        check(lib().ddx_plan_join(), "plan_join")
 
     # ------------------------------------------------------------------------------------------ finalize / run
     def gain_ptr(self, slot: Optional[int]):

@@ -294,6 +294,12 @@ int ddx_mss_loss_scale(const ddx_mss_desc* d, ddx_stream stream);
 typedef struct ddx_plan ddx_plan;
 ddx_plan* ddx_plan_begin(void);
 int ddx_plan_end(ddx_plan* p);
+/* Two-lane recording: ops recorded after ddx_plan_fork() run on a side stream that waits for everything recorded before the
+ * fork; ddx_plan_main() switches back to the main lane without synchronising; ddx_plan_join() makes the main lane wait for
+ * the side lane.  Outside a recording the three calls are no-ops (everything runs in issue order). */
+int ddx_plan_fork(void);
+int ddx_plan_main(void);
+int ddx_plan_join(void);
 int ddx_plan_num_ops(const ddx_plan* p);
 int ddx_plan_run(ddx_plan* p, ddx_stream stream);            /* eager replay */
 int ddx_plan_graph_build(ddx_plan* p, ddx_stream stream);    /* capture into a hipGraphExec */

@@ -145,3 +145,32 @@ def test_resample2d():
         assert torch.equal(to_nchw(up), O.resample2x(xr, "up"))
         dn = ops.resample2d(to_nhwc(xr, dt), torch.empty(2, 3, 5, 16, device="cuda", dtype=dt), L.RESAMPLE_DOWN)
         assert rel_l2(to_nchw(dn), O.resample2x(xr, "down")) < (1e-6 if dt == torch.float32 else 4e-3)
+
+
+def test_plan_two_lanes_match_single_lane():
+    """ddx_plan_fork/main/join: ops recorded on the side lane give the same results eagerly and under graph capture."""
+    import ctypes as C
+    from dualdiffusion_amd import _lib as L, ops
+    a = torch.randn(1 << 16, device="cuda")
+    b = torch.randn(1 << 16, device="cuda")
+    o1, o2, o3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    plan = L.Plan()
+    with plan.record():
+        ops.lincomb3(o1, a, 2.0, b, 1.0)                             # main
+        L.check(L.lib().ddx_plan_fork(), "fork")
+        ops.lincomb3(o2, o1, 1.0, a, -1.0)                           # side: needs o1
+        L.check(L.lib().ddx_plan_main(), "main")
+        ops.lincomb3(o3, o1, 0.5, b, 3.0)                            # main, concurrent with the side op
+        L.check(L.lib().ddx_plan_join(), "join")
+        ops.lincomb3(o1, o2, 1.0, o3, 1.0)                           # needs both
+    ref = (a + b) + (0.5 * (2 * a + b) + 3 * b)
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.allclose(o1, ref, atol=1e-5)
+    o1.zero_()
+    cap = torch.cuda.Stream()
+    plan.graph_build(cap.cuda_stream)
+    cap.synchronize()
+    plan.graph_launch()
+    torch.cuda.synchronize()
+    assert torch.allclose(o1, ref, atol=1e-5)
