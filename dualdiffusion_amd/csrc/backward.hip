@@ -1,0 +1,229 @@
+// Element-wise / row-wise backward kernels of the EDM2 block (the pieces autograd runs between the conv gradients of
+// reference src/modules/unets/unet_edm2_b4.py:110-158 and src/modules/mp_tools.py:42-49,268-279,359-364).  All HBM-bound:
+// each reads its operands once in 16-byte lanes and writes the gradient(s) once.
+//   silu_scale_bwd  : a = mp_silu(y * c[b][ch] * s)           -> dy, dc          (conv_res1 / attn_proj operands, block inputs)
+//   mpsum_clip_bwd  : out = clip(a*res + b*y)                 -> dres, dy        (mp_sum + clip_ at the end of a block)
+//   pixelnorm_bwd   : y = x / (eps + |x| / sqrt(C))           -> dx              (normalize(x, dim=1) of encoder blocks)
+//   wprep_bwd       : w' = normalize(w) * gain / sqrt(fan)    -> dw, dgain       (MPConv weight path, fp32 master weights)
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace ddx {
+namespace {
+
+__device__ __forceinline__ float mp_silu_grad_f(float z) {
+  // d/dz [ z * sigmoid(z) / 0.596 ] = sigmoid(z) * (1 + z * (1 - sigmoid(z))) / 0.596
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+  return sg * (1.0f + z * (1.0f - sg)) * kMpSiluInv;
+}
+
+// one workgroup = RPW rows-per-pass x nvec 16-byte vectors; each thread keeps the dc partial sums of its vector
+template <typename T>
+__global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ cs,
+                                                             float scale, T* __restrict__ dy, float* __restrict__ dc, int HW, int C,
+                                                             int rows_per_block) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int vbase = blockIdx.z * 256;                 // rows wider than 256 vectors are split over blockIdx.z
+  const int nvec = min(C / EV - vbase, 256);
+  const int b = blockIdx.y;
+  const int rsub = threadIdx.x / nvec, rstep = 256 / nvec;
+  const int v = vbase + threadIdx.x % nvec;
+  if (rsub >= rstep) return;  // (256 not a multiple of nvec: idle tail threads)
+  float cv[EV], acc[EV];
+#pragma unroll
+  for (int e = 0; e < EV; ++e) { cv[e] = (cs ? cs[(size_t)b * C + v * EV + e] : 1.0f) * scale; acc[e] = 0.f; }
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+  for (int r = r0 + rsub; r < r1; r += rstep) {
+    const size_t o = ((size_t)b * HW + r) * C + (size_t)v * EV;
+    Vec16<T> g, yy, out;
+    g.v = *reinterpret_cast<const decltype(g.v)*>(da + o);
+    yy.v = *reinterpret_cast<const decltype(g.v)*>(y + o);
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const float yv = yy.get(e);
+      const float dz = g.get(e) * mp_silu_grad_f(yv * cv[e]);
+      out.set(e, dz * cv[e]);
+      acc[e] += dz * yv;
+    }
+    *reinterpret_cast<decltype(g.v)*>(dy + o) = out.v;
+  }
+  if (dc) {
+#pragma unroll
+    for (int e = 0; e < EV; ++e) atomicAdd(dc + (size_t)b * C + v * EV + e, acc[e] * scale);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mpsum_clip_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ dres,
+                                                             T* __restrict__ dy, float a, float b, float clip, size_t nvec) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    Vec16<T> g, o, r, yv;
+    g.v = *reinterpret_cast<const decltype(g.v)*>(dout + i * EV);
+    if (clip > 0.f) o.v = *reinterpret_cast<const decltype(g.v)*>(out + i * EV);
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const float m = (clip > 0.f && fabsf(o.get(e)) >= clip) ? 0.f : g.get(e);
+      r.set(e, a * m);
+      yv.set(e, b * m);
+    }
+    if (dres) *reinterpret_cast<decltype(g.v)*>(dres + i * EV) = r.v;
+    *reinterpret_cast<decltype(g.v)*>(dy + i * EV) = yv.v;
+  }
+}
+
+// one wave per row (as pixelnorm_kernel); C <= 64 * 4 * EV cached in registers, larger rows re-read
+template <typename T>
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int64_t rows,
+                                                            int C, float eps) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float inv_sqrt_c = rsqrtf((float)C);
+  const int nvec = C / EV;
+  for (int64_t r = wave_id; r < rows; r += nwaves) {
+    const T* xr = x + r * C; const T* gr = dy + r * C; T* or_ = dx + r * C;
+    float ss = 0.f, sd = 0.f;
+    for (int vi = lane; vi < nvec; vi += 64) {
+      Vec16<T> xv, gv;
+      xv.v = *reinterpret_cast<const decltype(xv.v)*>(xr + (size_t)vi * EV);
+      gv.v = *reinterpret_cast<const decltype(xv.v)*>(gr + (size_t)vi * EV);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) { const float f = xv.get(e); ss += f * f; sd += f * gv.get(e); }
+    }
+    ss = wave_sum(ss); sd = wave_sum(sd);
+    const float n = sqrtf(ss);
+    const float nu = eps + n * inv_sqrt_c;
+    const float k = n > 0.f ? sd * inv_sqrt_c / (nu * nu * n) : 0.f;
+    const float inv_nu = 1.0f / nu;
+    for (int vi = lane; vi < nvec; vi += 64) {
+      Vec16<T> xv, gv, o;
+      xv.v = *reinterpret_cast<const decltype(xv.v)*>(xr + (size_t)vi * EV);
+      gv.v = *reinterpret_cast<const decltype(xv.v)*>(gr + (size_t)vi * EV);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) o.set(e, gv.get(e) * inv_nu - xv.get(e) * k);
+      *reinterpret_cast<decltype(xv.v)*>(or_ + (size_t)vi * EV) = o.v;
+    }
+  }
+}
+
+// one workgroup per DESTINATION row of the prepared weight (same row mapping as wprep_kernel)
+template <typename TW_>
+__global__ __launch_bounds__(256) void wprep_bwd_kernel(const float* __restrict__ dwp, const TW_* __restrict__ w, const float* gain_ptr, float gain,
+                                                        float* __restrict__ dw, float* __restrict__ dgain, int Cout, int Cg, int taps, int G,
+                                                        int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1,
+                                                        int accumulate) {
+  __shared__ float scratch[4];
+  const int od = blockIdx.x;
+  const int Ng = Cout / G;
+  const int g = od / Ng;
+  int os = od;
+  if (qk_d > 0) {
+    const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
+    const int s = rem / qk_d, dd = rem - s * qk_d;
+    os = head * 2 * qk_d + dd * 2 + s;
+  }
+  const int fan = Cg * taps;
+  const TW_* wr = w + (size_t)os * fan;
+  const float* gr = dwp + (size_t)od * fan;
+  float ss = 0.f, su = 0.f;
+  for (int i = threadIdx.x; i < fan; i += 256) {
+    const float x = to_f32<TW_>(wr[i]);
+    const int c = i / taps;
+    const float sc = in_split > 0 ? ((g * Cg + c < in_split) ? in_s0 : in_s1) : 1.0f;
+    ss += x * x;
+    su += gr[i] * sc * x;
+  }
+  ss = block_sum_256(ss, scratch);
+  su = block_sum_256(su, scratch);
+  const float rfan = sqrtf(1.0f / (float)fan);
+  const float n = sqrtf(ss);
+  const float nu = normalize ? eps + n * rfan : 1.0f;
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float s = gn * rfan;
+  const float k = (normalize && n > 0.f) ? su * rfan / (nu * n) : 0.f;
+  for (int i = threadIdx.x; i < fan; i += 256) {
+    const float x = to_f32<TW_>(wr[i]);
+    const int c = i / taps;
+    const float sc = in_split > 0 ? ((g * Cg + c < in_split) ? in_s0 : in_s1) : 1.0f;
+    const float v = (s / nu) * (gr[i] * sc - x * k);
+    float* dst = dw + (size_t)os * fan + i;
+    *dst = accumulate ? *dst + v : v;
+  }
+  // d(loss)/d(gain parameter): g_eff = gain * (*gain_ptr)
+  if (dgain && threadIdx.x == 0) atomicAdd(dgain, gain * su * rfan / nu);
+}
+
+inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
+
+}  // namespace
+}  // namespace ddx
+
+using namespace ddx;
+
+extern "C" int ddx_silu_scale_bwd(const void* da, const void* y, const float* chan_scale, float scale, void* dy, float* dc, int32_t B,
+                                  int64_t HW, int32_t C, int32_t dtype, ddx_stream stream) {
+  if (!da || !y || !dy || B <= 0 || HW <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "silu_scale_bwd: bad args");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (C % ev) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C must be a multiple of the 16-byte vector");
+  if (dc && !chan_scale) return set_error(DDX_ERR_ARG, "silu_scale_bwd: dc without chan_scale");
+  return dispatch([=](hipStream_t s) -> int {
+    const int rows_per_block = 256;
+    dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)((C / ev + 255) / 256));
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (const bf16*)y, chan_scale, scale, (bf16*)dy, dc, (int)HW, C, rows_per_block);
+    else
+      hipLaunchKernelGGL(silu_scale_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)da, (const float*)y, chan_scale, scale, (float*)dy, dc, (int)HW, C, rows_per_block);
+    return check_launch("silu_scale_bwd");
+  }, stream, "silu_scale_bwd", 0.0, 3.0 * (double)B * HW * C * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_mpsum_clip_bwd(const void* dout, const void* out, void* dres, void* dy, float t, float clip, int64_t n, int32_t dtype,
+                                  ddx_stream stream) {
+  if (!dout || !dy || n <= 0 || (clip > 0.f && !out)) return set_error(DDX_ERR_ARG, "mpsum_clip_bwd: bad args");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (n % ev) return set_error(DDX_ERR_UNSUPPORTED, "mpsum_clip_bwd: n must be a multiple of the 16-byte vector");
+  const float nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
+  const float a = (1.f - t) / nrm, b = t / nrm;
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t nvec = (size_t)n / ev;
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(mpsum_clip_bwd_kernel<bf16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)dout, (const bf16*)out, (bf16*)dres, (bf16*)dy, a, b, clip, nvec);
+    else
+      hipLaunchKernelGGL(mpsum_clip_bwd_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)dout, (const float*)out, (float*)dres, (float*)dy, a, b, clip, nvec);
+    return check_launch("mpsum_clip_bwd");
+  }, stream, "mpsum_clip_bwd", 0.0, 4.0 * (double)n * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_pixelnorm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream) {
+  if (!dy || !x || !dx || rows <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "pixelnorm_bwd: bad args");
+  if (C % (dtype == DDX_BF16 ? 8 : 4)) return set_error(DDX_ERR_UNSUPPORTED, "pixelnorm_bwd: C must be a multiple of the 16-byte vector");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = (int)std::min<int64_t>((rows + 3) / 4, 16384);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(pixelnorm_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, rows, C, eps);
+    else
+      hipLaunchKernelGGL(pixelnorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, (float*)dx, rows, C, eps);
+    return check_launch("pixelnorm_bwd");
+  }, stream, "pixelnorm_bwd", 0.0, 3.0 * (double)rows * C * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* dp, const float* dwp, float* dw, float* dgain, int32_t accumulate, ddx_stream stream) {
+  if (!dp || !dp->w || !dwp || !dw) return set_error(DDX_ERR_ARG, "wprep_bwd: null");
+  const ddx_wprep_desc d = *dp;
+  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3)) return set_error(DDX_ERR_ARG, "wprep_bwd: bad shape");
+  if (d.transpose) return set_error(DDX_ERR_ARG, "wprep_bwd: describe the forward preparation (transpose = 0)");
+  return dispatch([=](hipStream_t s) -> int {
+    const int taps = d.ksize * d.ksize;
+    if (d.w_dtype == DDX_F32)
+      hipLaunchKernelGGL(wprep_bwd_kernel<float>, dim3(d.Cout), dim3(256), 0, s, dwp, (const float*)d.w, d.gain_ptr, d.gain, dw, dgain, d.Cout, d.Cg,
+                         taps, d.groups, d.normalize, d.qk_head_dim, 1e-4f, d.in_split, d.in_scale0, d.in_scale1, accumulate);
+    else
+      hipLaunchKernelGGL(wprep_bwd_kernel<bf16>, dim3(d.Cout), dim3(256), 0, s, dwp, (const bf16*)d.w, d.gain_ptr, d.gain, dw, dgain, d.Cout, d.Cg,
+                         taps, d.groups, d.normalize, d.qk_head_dim, 1e-4f, d.in_split, d.in_scale0, d.in_scale1, accumulate);
+    return check_launch("wprep_bwd");
+  }, stream, "wprep_bwd");
+}

@@ -221,7 +221,6 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     };
 #pragma unroll
     for (int s0 = 0; s0 < PD && s0 < SLOTS; ++s0) load_frags(s0, s0 % RING);
-    if (p.debug & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int slot = 0; slot < SLOTS; ++slot) {
       const int cur = slot % RING;
@@ -232,7 +231,6 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
 #pragma unroll
         for (int j = 0; j < MF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
     }
-    if (p.debug & 16) __builtin_amdgcn_s_setprio(0);
   };
 
   float* sE = reinterpret_cast<float*>(smem + NST * GEO::STAGE + wave * GEO::EPI_WAVE);
@@ -274,7 +272,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // this stage landed for every wave; everyone is done reading the other one
         issue_next(S1{});
-        if (!(p.debug & 8)) compute(S0{});
+        compute(S0{});
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         issue_next(S0{});
@@ -289,12 +287,11 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
                 rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
               }
         }
-        if (!(p.debug & 8)) compute(S1{});
+        compute(S1{});
       }
     }
 
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
-    if (p.debug & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out)[0] = acc[NF - 1][1][3] + acc[0][1][2]; continue; }
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       if (NF > 2 && p.epilogue == DDX_EPI_MPSUM) {  // wide tiles: no registers to prefetch all residual rows, load per column
@@ -430,7 +427,6 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
 
 int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   ConvParams p = p_in;
-  { const char* e = std::getenv("DDX_DMA_ABLATE"); p.debug = e ? atoi(e) : 0; }
   int TH = 0, TW = 0; double util;
   if (!dma_tile(p, ksize, &TH, &TW, &util)) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma: no tile");
   const int pad = ksize / 2;
@@ -442,7 +438,7 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   // (A 128-channel 8-wave 3x3 variant measured within 3% of the 64-channel one and loses on ragged groups: not built.)
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
-  const bool wide = !(p.debug & 64) && dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);
+  const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);
   return wide ? launch_dma_t<1, 32, 4, 2>(p, s) : launch_dma_t<1, 32, 2, 1>(p, s);
 }
 

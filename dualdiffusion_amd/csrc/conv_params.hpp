@@ -28,7 +28,6 @@ struct ConvParams {
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;
   int group_smem;  // LDS bytes of one split-K group's staging region
-  int debug;       // ablation switches (development only)
 };
 
 // index into the prepared weight tensor wp[g][chunk][tap][NgP][CK]

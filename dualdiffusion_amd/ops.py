@@ -18,10 +18,11 @@ from ._lib import check, current_stream, dtype_code, lib, ptr
 class PreparedWeight:
     """Output of weight preparation (mp_tools.py:359-364) in the implicit-GEMM layout."""
 
-    __slots__ = ("wp", "Cout", "Cg", "ksize", "groups", "CK", "dtype", "desc", "workspace")
+    __slots__ = ("wp", "Cout", "Cg", "ksize", "groups", "CK", "dtype", "desc", "workspace", "refs")
 
     def __init__(self, wp, Cout, Cg, ksize, groups, CK, dtype, desc):
         self.wp, self.Cout, self.Cg, self.ksize, self.groups, self.CK, self.dtype, self.desc = wp, Cout, Cg, ksize, groups, CK, dtype, desc
+        self.workspace, self.refs = None, None   # tensors the descriptor points at (master weight, gain) are kept alive here
 
 
 def pick_ck(Cg: int, ksize: int, dtype: torch.dtype, npix: int = 0) -> int:
@@ -52,7 +53,9 @@ def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float 
                     wp_dtype=dtype_code(dtype), Cout=Cout, Cg=Cg, ksize=ksize, groups=groups, CK=CK,
                     normalize=int(normalize), qk_head_dim=qk_head_dim, in_split=in_split, in_scale0=in_scale0, in_scale1=in_scale1)
     check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep")
-    return PreparedWeight(out, Cout, Cg, ksize, groups, CK, dtype, d)
+    pw = PreparedWeight(out, Cout, Cg, ksize, groups, CK, dtype, d)
+    pw.refs = (weight, gain_ptr)
+    return pw
 
 
 def _wprep_transposed(weight, groups, dtype, gain, gain_ptr, normalize, qk_head_dim, CK, out, npix, in_split, in_scale0, in_scale1):
@@ -72,6 +75,7 @@ def _wprep_transposed(weight, groups, dtype, gain, gain_ptr, normalize, qk_head_
     check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep(transpose)")
     pw = PreparedWeight(out, Cin, Ng, ksize, groups, CK, dtype, d)
     pw.workspace = ws      # keeps the row-scale workspace alive as long as the prepared weight
+    pw.refs = (weight, gain_ptr)
     return pw
 
 
@@ -125,6 +129,43 @@ def conv2d_wgrad(dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, *,
     d.workspace = ptr(ws)
     check(lib().ddx_mpconv2d_wgrad(C.byref(d), current_stream()), "mpconv2d_wgrad")
     return out
+
+
+def silu_scale_bwd(da: torch.Tensor, y: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0,
+                   dc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Backward of a = mp_silu(y * chan_scale[b, c] * scale) on NHWC tensors: returns dy; accumulates into dc [B, C] fp32."""
+    B, Cn = y.shape[0], y.shape[-1]
+    dy = torch.empty_like(y)
+    check(lib().ddx_silu_scale_bwd(ptr(da), ptr(y), ptr(chan_scale), float(scale), ptr(dy), ptr(dc), B, y.numel() // (B * Cn), Cn,
+                                   dtype_code(y.dtype), current_stream()), "silu_scale_bwd")
+    return dy
+
+
+def mpsum_clip_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], t: float, clip: float = 0.0, want_dres: bool = True):
+    """Backward of out = clip(mp_sum(res, y, t)): returns (dres | None, dy)."""
+    dres = torch.empty_like(dout) if want_dres else None
+    dy = torch.empty_like(dout)
+    check(lib().ddx_mpsum_clip_bwd(ptr(dout), ptr(out), ptr(dres), ptr(dy), float(t), float(clip), dout.numel(), dtype_code(dout.dtype),
+                                   current_stream()), "mpsum_clip_bwd")
+    return dres, dy
+
+
+def pixelnorm_bwd(dy: torch.Tensor, x: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
+    Cn = x.shape[-1]
+    dx = torch.empty_like(x)
+    check(lib().ddx_pixelnorm_bwd(ptr(dy), ptr(x), ptr(dx), x.numel() // Cn, Cn, eps, dtype_code(x.dtype), current_stream()), "pixelnorm_bwd")
+    return dx
+
+
+def wprep_bwd(pw: PreparedWeight, dwp: torch.Tensor, dw: Optional[torch.Tensor] = None, dgain: Optional[torch.Tensor] = None,
+              accumulate: bool = False) -> torch.Tensor:
+    """Gradient w.r.t. the master weight (fp32, the weight's shape) from the gradient w.r.t. the prepared weight `dwp`
+    (fp32 natural layout, e.g. from conv2d_wgrad); `pw` is the forward preparation (ops.wprep) of that weight."""
+    assert dwp.dtype == torch.float32 and dwp.is_contiguous()
+    if dw is None:
+        dw = torch.empty_like(dwp)
+    check(lib().ddx_mpconv_wprep_bwd(C.byref(pw.desc), ptr(dwp), ptr(dw), ptr(dgain), int(accumulate), current_stream()), "wprep_bwd")
+    return dw
 
 
 def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4, out_act: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -143,6 +143,25 @@ size_t ddx_wgrad_workspace_bytes(const ddx_wgrad_desc* d);
 int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* d, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Element-wise backward pieces of Block.forward (what autograd runs between the conv gradients):
+ *   ddx_silu_scale_bwd : a = mp_silu(y * chan_scale[b][c] * scale)  ->  dy = da * a'(.) * chan_scale * scale,
+ *                        dc[b][c] += sum_pixels da * a'(.) * y * scale      (dc NULL or chan_scale NULL: no per-channel factor)
+ *   ddx_mpsum_clip_bwd : out = clip(mp_sum(res, y, t), +-clip)  ->  dres = a*m*dout (NULL: skipped), dy = b*m*dout,
+ *                        m = |out| < clip (clip <= 0: no mask, out unused)
+ *   ddx_pixelnorm_bwd  : y = x / (eps + |x|_2 / sqrt(C))  ->  dx
+ *   ddx_mpconv_wprep_bwd: gradient w.r.t. the master weight and the gain parameter from the gradient w.r.t. the prepared
+ *                        weight (dwp, natural layout [Cout][Cg][ks][ks] fp32 = output of ddx_mpconv2d_wgrad); `d` describes the
+ *                        FORWARD preparation (normalize, gain, in_split, qk_head_dim); dgain (scalar, may be NULL) is accumulated.
+ * NHWC tensors in `dtype`, dc / dw / dgain fp32.
+ * ------------------------------------------------------------------------------------------------ */
+int ddx_silu_scale_bwd(const void* da, const void* y, const float* chan_scale, float scale, void* dy, float* dc, int32_t B,
+                       int64_t HW, int32_t C, int32_t dtype, ddx_stream stream);
+int ddx_mpsum_clip_bwd(const void* dout, const void* out, void* dres, void* dy, float t, float clip, int64_t n, int32_t dtype,
+                       ddx_stream stream);
+int ddx_pixelnorm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
+int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* d, const float* dwp, float* dw, float* dgain, int32_t accumulate, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RMS ("pixel") normalisation over the channel axis of NHWC rows  (mp_tools.py:42-49 with dim=1,
  * unet_edm2_b4.py:117): y = x / (eps + ||x||_2 / sqrt(C)).  rows = B*H*W.  In place allowed.
  * ------------------------------------------------------------------------------------------------ */

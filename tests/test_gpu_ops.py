@@ -416,3 +416,67 @@ def test_conv_wgrad(name):
     dw2 = ops.conv2d_wgrad(to_nhwc(dy, dtype), to_nhwc(a, dtype), groups, ks, x1=to_nhwc(b, dtype) if C1 else None,
                            resample=L.RESAMPLE_UP if resample == "up" else L.RESAMPLE_KEEP, out=dw.clone(), accumulate=True)
     assert rel_l2(dw2, 2 * dw_ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_elementwise_backward_kernels(dtype):
+    """silu_scale_bwd, mpsum_clip_bwd, pixelnorm_bwd against torch autograd through the oracle's forward definitions."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(123)
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    for (B, H, W, Cn) in ((2, 5, 7, 64), (1, 3, 9, 2560)):
+        # a = mp_silu(y * c * s)
+        y = _round(torch.randn(B, Cn, H, W, generator=g), dtype).requires_grad_(True)
+        c = (torch.rand(B, Cn, generator=g) + 0.5).requires_grad_(True)
+        da = _round(torch.randn(B, Cn, H, W, generator=g), dtype)
+        a = O.silu_mp(y * c[:, :, None, None] * 0.8)
+        dy_ref, dc_ref = torch.autograd.grad(a, (y, c), da)
+        dc = torch.zeros(B, Cn, device="cuda")
+        dy = ops.silu_scale_bwd(to_nhwc(da, dtype), to_nhwc(y.detach(), dtype), c.detach().cuda(), 0.8, dc)
+        assert rel_l2(to_nchw(dy), dy_ref) < tol and rel_l2(dc, dc_ref) < (2e-5 if dtype == torch.float32 else 2e-3), (Cn, rel_l2(dc, dc_ref))
+        # no per-channel factor (block input activation)
+        a2 = O.silu_mp(y * 1.3)
+        (dy2_ref,) = torch.autograd.grad(a2, y, da)
+        assert rel_l2(to_nchw(ops.silu_scale_bwd(to_nhwc(da, dtype), to_nhwc(y.detach(), dtype), None, 1.3)), dy2_ref) < tol
+        # out = clip(mp_sum(res, y2, t))
+        res = (_round(torch.randn(B, Cn, H, W, generator=g), dtype) * 2).requires_grad_(True)
+        y2 = (_round(torch.randn(B, Cn, H, W, generator=g), dtype) * 2).requires_grad_(True)
+        out = O.sum_mp(res, y2, 0.3).clamp(-1.5, 1.5)
+        dres_ref, dy2_ref = torch.autograd.grad(out, (res, y2), da)
+        out_st = _round(out.detach(), dtype)                      # the stored (possibly bf16) block output carries the clip mask
+        if dtype == torch.bfloat16:                               # mask from the stored values: rounding moves elements onto the clip edge
+            m = (out_st.abs() < 1.5).float()
+            nrm = math.sqrt(0.7 ** 2 + 0.3 ** 2)
+            dres_ref, dy2_ref = 0.7 / nrm * m * da, 0.3 / nrm * m * da
+        dres, dy2 = ops.mpsum_clip_bwd(to_nhwc(da, dtype), to_nhwc(out_st, dtype), 0.3, 1.5)
+        assert rel_l2(to_nchw(dres), dres_ref) < tol and rel_l2(to_nchw(dy2), dy2_ref) < tol
+        # pixel norm
+        x = _round(torch.randn(B, Cn, H, W, generator=g), dtype).requires_grad_(True)
+        (dx_ref,) = torch.autograd.grad(O.rms_normalize(x, [1]), x, da)
+        dx = ops.pixelnorm_bwd(to_nhwc(da, dtype), to_nhwc(x.detach(), dtype))
+        assert rel_l2(to_nchw(dx), dx_ref) < tol
+
+
+def test_wprep_backward():
+    """Weight-path backward (forced weight norm, gain, folded mp_cat scales, qk row permutation) against autograd."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(321)
+    for (Cout, Cg, ks, groups, normalize, in_split, qk) in ((64, 16, 3, 4, True, 0, 0), (96, 48, 1, 1, False, 32, 0), (128, 64, 1, 1, True, 0, 32),
+                                                            (32, 8, 3, 2, True, 8, 0)):
+        w = torch.randn(Cout, Cg, ks, ks, generator=g).requires_grad_(True)
+        gain = torch.tensor(0.7, requires_grad=True)
+        dwp = torch.randn(Cout, Cg, ks, ks, generator=g)
+        wp = O.prepared_weight(w, gain, training=normalize)
+        if in_split:
+            cabs = (torch.arange(Cout) // (Cout // groups))[:, None] * Cg + torch.arange(Cg)[None, :]
+            wp = wp * torch.where(cabs < in_split, 0.6, 1.4)[:, :, None, None]
+        if qk:   # destination rows (head, s, d) <- source rows (head, d, s)
+            heads = Cout // (2 * qk)
+            wp = wp.reshape(heads, qk, 2, Cg, ks, ks).permute(0, 2, 1, 3, 4, 5).reshape(Cout, Cg, ks, ks)
+        dw_ref, dgain_ref = torch.autograd.grad(wp, (w, gain), dwp)
+        pw = ops.wprep(w.detach().cuda(), groups, torch.float32, gain_ptr=gain.detach().cuda().reshape(1), normalize=normalize,
+                       in_split=in_split, in_scale0=0.6, in_scale1=1.4, qk_head_dim=qk)
+        dgain = torch.zeros(1, device="cuda")
+        dw = ops.wprep_bwd(pw, dwp.cuda(), dgain=dgain)
+        assert rel_l2(dw, dw_ref) < 2e-5, (Cout, rel_l2(dw, dw_ref))
+        assert abs(float(dgain) - float(dgain_ref)) < 2e-5 * max(1.0, abs(float(dgain_ref)))
