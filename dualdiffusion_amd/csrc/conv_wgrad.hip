@@ -221,10 +221,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[i] = s;
 }
 
+// split-K factor: enough units to fill the chip (512 workgroup slots), but never more partial-sum traffic than ~4x the
+// gradient itself (small-M layers have large weights and few pixel tiles: they run unsplit and write dW directly)
 int wgrad_ksplit(int G, int Ng, int Cg, int ks, int ntile_px) {
   const int bcw = ks == 3 ? 32 : 64;
   const long base = (long)G * ceil_div(Ng, 64) * ceil_div(Cg, bcw);
-  const long want = std::max<long>(1, 1024 / base);
+  long want = std::max<long>(1, 768 / base);
+  const double dw_mb = (double)G * Ng * Cg * ks * ks * 4.0 / 1e6;
+  if (dw_mb * want > 48.0) want = std::max<long>(1, (long)(48.0 / dw_mb));
   return (int)std::min<long>(want, ntile_px);
 }
 
@@ -303,6 +307,11 @@ extern "C" int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* dp, ddx_stream stream) {
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double bytes = 2.0 * ((double)p.B * p.H * p.W * p.Cout + (double)p.B * p.sH * p.sW * p.Cin) + 4.0 * n;
   return dispatch([p, ks, n, dw, accumulate](hipStream_t s) -> int {
+    if (p.ksplit == 1 && !accumulate) {  // unsplit: the kernel writes the gradient itself
+      WgradParams q = p;
+      q.ws = dw;
+      return ks == 3 ? launch_wgrad<3>(q, s) : launch_wgrad<1>(q, s);
+    }
     const int rc = ks == 3 ? launch_wgrad<3>(p, s) : launch_wgrad<1>(p, s);
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)p.ws, dw, n, p.ksplit, accumulate);
