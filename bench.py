@@ -150,8 +150,18 @@ def main() -> None:
         n, fl, by, ms = dom[1]
         total_ms = sum(v[3] for v in fam.values())
         achieved = fl / (ms * 1e-3) / 1e12
+        # HBM-side traffic per launch of the same kernel family: PMC counters cannot be read from inside the process, so
+        # the number comes from the committed rocprofv3 --pmc run of this very command (tools/profile_round.sh)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if os.path.isfile(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("family") == dom[0]:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": int(by / n),
                     "kernel": dom[0], "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms / total_ms, 3),
                     "step_tflops": round(B * FLOP_PER_SAMPLE / (elapsed / a.steps) / 1e12, 1),

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round profile on the GPU box: bench JSON, rocprofv3 kernel stats of the same command, and the HBM-side PMC counters
+# (separate --pmc passes, as the MI355X guide prescribes).  usage: tools/profile_round.sh r01     (outputs under gpurun_out/<tag>_*)
+tag=${1:-r01}
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out
+mkdir -p $out
+cd $root
+python bench.py --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $out/${tag}_stats -o x --output-format csv -- python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $out/${tag}_pmc_$c -o x --output-format csv -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $out/${tag}_pmc_$c.log 2>&1
+done
+cd $root
+python tools/pmc_summary.py $out/${tag}_pmc_FETCH_SIZE conv_ > $out/${tag}_pmc_summary.txt
+python tools/pmc_summary.py $out/${tag}_pmc_WRITE_SIZE conv_ >> $out/${tag}_pmc_summary.txt
+find $out/${tag}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats.csv
+cat $out/${tag}_bench.json
+head -12 $out/${tag}_kernel_stats.csv
+cat $out/${tag}_pmc_summary.txt | head -40
