@@ -20,9 +20,9 @@ __device__ __forceinline__ float mp_silu_grad_f(float z) {
 
 // one workgroup = RPW rows-per-pass x nvec 16-byte vectors; each thread keeps the dc partial sums of its vector
 template <typename T>
-__global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict__ da, const T* __restrict__ y, const float* __restrict__ cs,
-                                                             float scale, T* __restrict__ dy, float* __restrict__ dc, int HW, int C,
-                                                             int rows_per_block) {
+__global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict__ da, int da_ld, const T* __restrict__ y, const float* __restrict__ cs,
+                                                             float scale, const T* __restrict__ add, int add_ld, T* __restrict__ dy,
+                                                             float* __restrict__ dc, int HW, int C, int rows_per_block) {
   constexpr int EV = 16 / (int)sizeof(T);
   const int vbase = blockIdx.z * 256;                 // rows wider than 256 vectors are split over blockIdx.z
   const int nvec = min(C / EV - vbase, 256);
@@ -35,15 +35,17 @@ __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict
   for (int e = 0; e < EV; ++e) { cv[e] = (cs ? cs[(size_t)b * C + v * EV + e] : 1.0f) * scale; acc[e] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
   for (int r = r0 + rsub; r < r1; r += rstep) {
-    const size_t o = ((size_t)b * HW + r) * C + (size_t)v * EV;
-    Vec16<T> g, yy, out;
-    g.v = *reinterpret_cast<const decltype(g.v)*>(da + o);
+    const size_t row = (size_t)b * HW + r;
+    const size_t o = row * C + (size_t)v * EV;
+    Vec16<T> g, yy, out, ad;
+    g.v = *reinterpret_cast<const decltype(g.v)*>(da + row * da_ld + (size_t)v * EV);
     yy.v = *reinterpret_cast<const decltype(g.v)*>(y + o);
+    if (add) ad.v = *reinterpret_cast<const decltype(g.v)*>(add + row * add_ld + (size_t)v * EV);
 #pragma unroll
     for (int e = 0; e < EV; ++e) {
       const float yv = yy.get(e);
       const float dz = g.get(e) * mp_silu_grad_f(yv * cv[e]);
-      out.set(e, dz * cv[e]);
+      out.set(e, dz * cv[e] + (add ? ad.get(e) : 0.f));
       acc[e] += dz * yv;
     }
     *reinterpret_cast<decltype(g.v)*>(dy + o) = out.v;
@@ -51,6 +53,23 @@ __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict
   if (dc) {
 #pragma unroll
     for (int e = 0; e < EV; ++e) atomicAdd(dc + (size_t)b * C + v * EV + e, acc[e] * scale);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void silu_scale_fwd_kernel(const T* __restrict__ x, const float* __restrict__ cs, float scale, T* __restrict__ out,
+                                                             size_t rows_per_b, int C, size_t nvec_total) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int nvec = C / EV;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec_total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / nvec;
+    const int v = (int)(i - row * nvec);
+    const size_t b = row / rows_per_b;
+    Vec16<T> xv, o;
+    xv.v = *reinterpret_cast<const decltype(xv.v)*>(x + i * EV);
+#pragma unroll
+    for (int e = 0; e < EV; ++e) o.set(e, mp_silu_f(xv.get(e) * (cs ? cs[b * C + v * EV + e] : 1.0f) * scale));
+    *reinterpret_cast<decltype(xv.v)*>(out + i * EV) = o.v;
   }
 }
 
@@ -164,21 +183,43 @@ inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 81
 
 using namespace ddx;
 
-extern "C" int ddx_silu_scale_bwd(const void* da, const void* y, const float* chan_scale, float scale, void* dy, float* dc, int32_t B,
-                                  int64_t HW, int32_t C, int32_t dtype, ddx_stream stream) {
+extern "C" int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* y, const float* chan_scale, float scale, const void* add,
+                                     int64_t add_ld, void* dy, float* dc, int32_t B, int64_t HW, int32_t C, int32_t dtype, ddx_stream stream) {
   if (!da || !y || !dy || B <= 0 || HW <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "silu_scale_bwd: bad args");
   const int ev = dtype == DDX_BF16 ? 8 : 4;
-  if (C % ev) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C must be a multiple of the 16-byte vector");
+  if (C % ev || da_ld % ev || (add && add_ld % ev)) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C and the row strides must be multiples of the 16-byte vector");
   if (dc && !chan_scale) return set_error(DDX_ERR_ARG, "silu_scale_bwd: dc without chan_scale");
   return dispatch([=](hipStream_t s) -> int {
     const int rows_per_block = 256;
     dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)((C / ev + 255) / 256));
     if (dtype == DDX_BF16)
-      hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (const bf16*)y, chan_scale, scale, (bf16*)dy, dc, (int)HW, C, rows_per_block);
+      hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (int)da_ld, (const bf16*)y, chan_scale, scale,
+                         (const bf16*)add, (int)add_ld, (bf16*)dy, dc, (int)HW, C, rows_per_block);
     else
-      hipLaunchKernelGGL(silu_scale_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)da, (const float*)y, chan_scale, scale, (float*)dy, dc, (int)HW, C, rows_per_block);
+      hipLaunchKernelGGL(silu_scale_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)da, (int)da_ld, (const float*)y, chan_scale, scale,
+                         (const float*)add, (int)add_ld, (float*)dy, dc, (int)HW, C, rows_per_block);
     return check_launch("silu_scale_bwd");
-  }, stream, "silu_scale_bwd", 0.0, 3.0 * (double)B * HW * C * (double)dtype_size(dtype));
+  }, stream, "silu_scale_bwd", 0.0, (add ? 4.0 : 3.0) * (double)B * HW * C * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_silu_scale_bwd(const void* da, const void* y, const float* chan_scale, float scale, void* dy, float* dc, int32_t B,
+                                  int64_t HW, int32_t C, int32_t dtype, ddx_stream stream) {
+  return ddx_silu_scale_bwd_ex(da, C, y, chan_scale, scale, nullptr, 0, dy, dc, B, HW, C, dtype, stream);
+}
+
+extern "C" int ddx_silu_scale_fwd(const void* x, const float* chan_scale, float scale, void* out, int32_t B, int64_t HW, int32_t C,
+                                  int32_t dtype, ddx_stream stream) {
+  if (!x || !out || B <= 0 || HW <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "silu_scale_fwd: bad args");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (C % ev) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_fwd: C must be a multiple of the 16-byte vector");
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t nvt = (size_t)B * HW * (C / ev);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(silu_scale_fwd_kernel<bf16>, dim3(grid_for(nvt)), dim3(256), 0, s, (const bf16*)x, chan_scale, scale, (bf16*)out, (size_t)HW, C, nvt);
+    else
+      hipLaunchKernelGGL(silu_scale_fwd_kernel<float>, dim3(grid_for(nvt)), dim3(256), 0, s, (const float*)x, chan_scale, scale, (float*)out, (size_t)HW, C, nvt);
+    return check_launch("silu_scale_fwd");
+  }, stream, "silu_scale_fwd", 0.0, 2.0 * (double)B * HW * C * (double)dtype_size(dtype));
 }
 
 extern "C" int ddx_mpsum_clip_bwd(const void* dout, const void* out, void* dres, void* dy, float t, float clip, int64_t n, int32_t dtype,

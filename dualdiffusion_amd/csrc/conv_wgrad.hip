@@ -263,7 +263,8 @@ static int wgrad_fill(const ddx_wgrad_desc& d, WgradParams* pp) {
   const int bcw = d.ksize == 3 ? 32 : 64;
   if (d.C0 % 8 || (d.x1 && d.C1 % 8) || d.Cout % 8 || (Cin / d.groups) % 8 || (d.Cout / d.groups) % 8)
     return set_error(DDX_ERR_UNSUPPORTED, "wgrad: channel counts (per group) must be multiples of 8");
-  if (d.x1 && (d.C0 % bcw)) return set_error(DDX_ERR_UNSUPPORTED, "wgrad: the source split must fall on an input-channel tile");
+  // an input-channel tile (bcw channels from g*Cg + k*bcw) must lie inside ONE source
+  if (d.x1 && ((d.C0 % (Cin / d.groups)) % bcw)) return set_error(DDX_ERR_UNSUPPORTED, "wgrad: the source split must fall on an input-channel tile");
   if (d.resample == DDX_RESAMPLE_DOWN) return set_error(DDX_ERR_UNSUPPORTED, "wgrad: avg-pool gather not built");
   if (d.resample == DDX_RESAMPLE_UP && ((d.H | d.W) & 1)) return set_error(DDX_ERR_ARG, "wgrad: upsampled size must be even");
   WgradParams p{};

@@ -131,14 +131,34 @@ def conv2d_wgrad(dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, *,
     return out
 
 
+def _chan_view(t: torch.Tensor, Cn: int):
+    """(data pointer, row stride) of an NHWC tensor or of a channel slice `t[..., c0:c0+Cn]` of one."""
+    assert t.shape[-1] == Cn and t.stride(-1) == 1
+    ld = t.stride(-2)
+    assert all(t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2)), "rows must be evenly strided"
+    return t.data_ptr(), ld
+
+
 def silu_scale_bwd(da: torch.Tensor, y: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0,
-                   dc: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Backward of a = mp_silu(y * chan_scale[b, c] * scale) on NHWC tensors: returns dy; accumulates into dc [B, C] fp32."""
+                   dc: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Backward of a = mp_silu(y * chan_scale[b, c] * scale) on NHWC tensors: returns dy (+ add); accumulates into dc [B, C]
+    fp32.  `da` and `add` may be channel slices of wider NHWC tensors (one source of an mp_cat)."""
     B, Cn = y.shape[0], y.shape[-1]
     dy = torch.empty_like(y)
-    check(lib().ddx_silu_scale_bwd(ptr(da), ptr(y), ptr(chan_scale), float(scale), ptr(dy), ptr(dc), B, y.numel() // (B * Cn), Cn,
-                                   dtype_code(y.dtype), current_stream()), "silu_scale_bwd")
+    da_p, da_ld = _chan_view(da, Cn)
+    add_p, add_ld = _chan_view(add, Cn) if add is not None else (None, 0)
+    check(lib().ddx_silu_scale_bwd_ex(da_p, da_ld, ptr(y), ptr(chan_scale), float(scale), add_p, add_ld, ptr(dy), ptr(dc), B,
+                                      y.numel() // (B * Cn), Cn, dtype_code(y.dtype), current_stream()), "silu_scale_bwd")
     return dy
+
+
+def silu_scale_fwd(x: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+    """mp_silu(x * chan_scale[b, c] * scale) on an NHWC tensor (recomputed conv operand of the backward pass)."""
+    B, Cn = x.shape[0], x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib().ddx_silu_scale_fwd(ptr(x), ptr(chan_scale), float(scale), ptr(out), B, x.numel() // (B * Cn), Cn, dtype_code(x.dtype),
+                                   current_stream()), "silu_scale_fwd")
+    return out
 
 
 def mpsum_clip_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], t: float, clip: float = 0.0, want_dres: bool = True):
