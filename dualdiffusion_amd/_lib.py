@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libddx_hip.so")
 
 DDX_F32, DDX_BF16 = 0, 1
 RESAMPLE_KEEP, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
+RESAMPLE_UP_BWD, RESAMPLE_DOWN_BWD = 3, 4
 PRO_NONE, PRO_SILU, PRO_SCALE, PRO_SCALE_SILU = 0, 1, 2, 3
 EPI_STORE, EPI_MPSUM = 0, 1
 
@@ -112,6 +113,9 @@ PROTOTYPES = {
     "ddx_mpsum_clip_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_int32, C.c_void_p]),
     "ddx_pixelnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_mpconv_wprep_bwd": (C.c_int, [C.POINTER(WPrepDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ddx_wprep_rowscale": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "ddx_linear_small_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -176,6 +176,27 @@ __global__ __launch_bounds__(256) void wprep_bwd_kernel(const float* __restrict_
   if (dgain && threadIdx.x == 0) atomicAdd(dgain, gain * su * rfan / nu);
 }
 
+// Backward of the small-M linear layers (emb_linear*: c = 1 + x @ w'^T at M = batch, reference unet_edm2_b4.py:121 through
+// mp_tools.py:366-367): one workgroup per output row o; dwp[o][k] = sum_m dc[m][o] x[m][g*Kg+k]; dx[m][g*Kg+k] += dc[m][o] w'[o][k]
+template <typename TW_>
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ dc, const float* __restrict__ x, const TW_* __restrict__ w,
+                                                               const float* __restrict__ row_scale, float* __restrict__ dwp, float* __restrict__ dx,
+                                                               int M, int O, int Kg, int groups, int x_stride) {
+  const int o = blockIdx.x;
+  const int g = o / (O / groups);
+  const float rs = row_scale[o];
+  for (int k = threadIdx.x; k < Kg; k += 256) {
+    const float wv = to_f32<TW_>(w[(size_t)o * Kg + k]) * rs;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float d = dc[(size_t)m * O + o];
+      acc += d * x[(size_t)m * x_stride + g * Kg + k];
+      if (dx) atomicAdd(dx + (size_t)m * x_stride + g * Kg + k, d * wv);
+    }
+    dwp[(size_t)o * Kg + k] = acc;
+  }
+}
+
 inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
 
 }  // namespace
@@ -267,4 +288,17 @@ extern "C" int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* dp, const float* dwp, 
                          taps, d.groups, d.normalize, d.qk_head_dim, 1e-4f, d.in_split, d.in_scale0, d.in_scale1, accumulate);
     return check_launch("wprep_bwd");
   }, stream, "wprep_bwd");
+}
+
+extern "C" int ddx_linear_small_bwd(const float* dc, const float* x, int32_t x_stride, const void* w, int32_t w_dtype, const float* row_scale,
+                                    float* dwp, float* dx, int32_t M, int32_t O, int32_t K, int32_t groups, ddx_stream stream) {
+  if (!dc || !x || !w || !row_scale || !dwp || M <= 0 || O <= 0 || K <= 0 || groups <= 0 || O % groups || K % groups)
+    return set_error(DDX_ERR_ARG, "linear_small_bwd: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    if (w_dtype == DDX_F32)
+      hipLaunchKernelGGL(linear_small_bwd_kernel<float>, dim3(O), dim3(256), 0, s, dc, x, (const float*)w, row_scale, dwp, dx, M, O, K / groups, groups, x_stride);
+    else
+      hipLaunchKernelGGL(linear_small_bwd_kernel<bf16>, dim3(O), dim3(256), 0, s, dc, x, (const bf16*)w, row_scale, dwp, dx, M, O, K / groups, groups, x_stride);
+    return check_launch("linear_small_bwd");
+  }, stream, "linear_small_bwd");
 }

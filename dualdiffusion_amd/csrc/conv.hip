@@ -166,6 +166,18 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
   }, stream, "wprep");
 }
 
+extern "C" int ddx_wprep_rowscale(const void* w, int32_t w_dtype, float* row_scale, const float* gain_ptr, float gain, int64_t rows,
+                                  int64_t fan_in, int32_t normalize, ddx_stream stream) {
+  if (!w || !row_scale || rows <= 0 || fan_in <= 0) return set_error(DDX_ERR_ARG, "wprep_rowscale: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    if (w_dtype == DDX_F32)
+      hipLaunchKernelGGL(wprep_rowscale_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, (const float*)w, row_scale, gain_ptr, gain, (int)fan_in, normalize, 1e-4f);
+    else
+      hipLaunchKernelGGL(wprep_rowscale_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, s, (const bf16*)w, row_scale, gain_ptr, gain, (int)fan_in, normalize, 1e-4f);
+    return check_launch("wprep_rowscale");
+  }, stream);
+}
+
 extern "C" int ddx_normalize_weights(void* w, int32_t w_dtype, int64_t rows, int64_t fan_in, ddx_stream stream) {
   if (!w || rows <= 0 || fan_in <= 0) return set_error(DDX_ERR_ARG, "normalize_weights: bad args");
   return dispatch([=](hipStream_t s) -> int {

@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void resample2d_kernel(const T* __restrict__ x
   constexpr int EV = 16 / (int)sizeof(T);
   const int nvec = C / EV;  // host guarantees C % EV == 0
   const size_t total = (size_t)B * H * W * nvec;
-  const int sH = mode == DDX_RESAMPLE_UP ? H / 2 : H * 2, sW = mode == DDX_RESAMPLE_UP ? W / 2 : W * 2;
+  const bool nearest = mode == DDX_RESAMPLE_UP || mode == DDX_RESAMPLE_DOWN_BWD;   // read one source pixel of the half-size image
+  const float gain = mode == DDX_RESAMPLE_UP ? 1.0f : (mode == DDX_RESAMPLE_UP_BWD ? 1.0f : 0.25f);
+  const int sH = nearest ? H / 2 : H * 2, sW = nearest ? W / 2 : W * 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int v = (int)(i % nvec);
     size_t pix = i / nvec;
@@ -251,8 +253,12 @@ __global__ __launch_bounds__(256) void resample2d_kernel(const T* __restrict__ x
     const int h = (int)(pix % H);
     const int b = (int)(pix / H);
     Vec16<T> o;
-    if (mode == DDX_RESAMPLE_UP) {
+    if (nearest) {
       o.v = *reinterpret_cast<const decltype(o.v)*>(x + (((size_t)b * sH + (h >> 1)) * sW + (w >> 1)) * C + v * EV);
+      if (mode == DDX_RESAMPLE_DOWN_BWD) {
+#pragma unroll
+        for (int e = 0; e < EV; ++e) o.set(e, gain * o.get(e));
+      }
     } else {
       const T* sp = x + (((size_t)b * sH + 2 * h) * sW + 2 * w) * C + v * EV;
       Vec16<T> a0, a1, a2, a3;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void resample2d_kernel(const T* __restrict__ x
       a2.v = *reinterpret_cast<const decltype(o.v)*>(sp + (size_t)sW * C);
       a3.v = *reinterpret_cast<const decltype(o.v)*>(sp + (size_t)sW * C + C);
 #pragma unroll
-      for (int e = 0; e < EV; ++e) o.set(e, 0.25f * ((a0.get(e) + a1.get(e)) + (a2.get(e) + a3.get(e))));
+      for (int e = 0; e < EV; ++e) o.set(e, gain * ((a0.get(e) + a1.get(e)) + (a2.get(e) + a3.get(e))));
     }
     *reinterpret_cast<decltype(o.v)*>(y + i * EV) = o.v;
   }
@@ -371,8 +377,8 @@ extern "C" int ddx_mpsum_rows(const float* a, int32_t a_rows, const float* b, co
 extern "C" int ddx_resample2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode, int32_t dtype,
                               ddx_stream stream) {
   if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "resample2d: bad args");
-  if (mode != DDX_RESAMPLE_UP && mode != DDX_RESAMPLE_DOWN) return set_error(DDX_ERR_ARG, "resample2d: mode must be UP or DOWN");
-  if (mode == DDX_RESAMPLE_UP && ((H | W) & 1)) return set_error(DDX_ERR_ARG, "resample2d: upsampled size must be even");
+  if (mode < DDX_RESAMPLE_UP || mode > DDX_RESAMPLE_DOWN_BWD) return set_error(DDX_ERR_ARG, "resample2d: bad mode");
+  if ((mode == DDX_RESAMPLE_UP || mode == DDX_RESAMPLE_DOWN_BWD) && ((H | W) & 1)) return set_error(DDX_ERR_ARG, "resample2d: upsampled size must be even");
   if (C % (dtype == DDX_BF16 ? 8 : 4)) return set_error(DDX_ERR_UNSUPPORTED, "resample2d: channels must fill 16-byte vectors");
   return dispatch([=](hipStream_t s) -> int {
     const size_t total = (size_t)B * H * W * (C / (dtype == DDX_BF16 ? 8 : 4));
@@ -381,7 +387,7 @@ extern "C" int ddx_resample2d(const void* x, void* y, int32_t B, int32_t H, int3
     else
       hipLaunchKernelGGL(resample2d_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, mode);
     return check_launch("resample2d");
-  }, stream, "resample2d", 0.0, (double)dtype_size(dtype) * B * H * W * C * (mode == DDX_RESAMPLE_UP ? 1.25 : 5.0));
+  }, stream, "resample2d", 0.0, (double)dtype_size(dtype) * B * H * W * C * ((mode == DDX_RESAMPLE_UP || mode == DDX_RESAMPLE_DOWN_BWD) ? 1.25 : 5.0));
 }
 
 extern "C" int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* z, float c, float* out, int64_t n,

@@ -188,6 +188,28 @@ def wprep_bwd(pw: PreparedWeight, dwp: torch.Tensor, dw: Optional[torch.Tensor] 
     return dw
 
 
+def linear_small_bwd(dc: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, groups: int = 1, gain_ptr: Optional[torch.Tensor] = None,
+                     normalize: bool = False, dx: Optional[torch.Tensor] = None):
+    """Backward of c = const + x @ w'^T (w' = weight path of `weight` [O, K/groups]): returns (dw, dgain) for the master weight
+    and the gain parameter; accumulates the input gradient into dx [M, K] (fp32) when given."""
+    M, O = dc.shape
+    K = x.shape[1]
+    w2 = weight.reshape(O, -1)
+    rs = torch.empty(O, dtype=torch.float32, device=dc.device)
+    check(lib().ddx_wprep_rowscale(ptr(w2), dtype_code(w2.dtype), ptr(rs), ptr(gain_ptr), 1.0, O, w2.shape[1], int(normalize), current_stream()),
+          "wprep_rowscale")
+    dwp = torch.empty(O, w2.shape[1], dtype=torch.float32, device=dc.device)
+    check(lib().ddx_linear_small_bwd(ptr(dc), ptr(x), x.stride(0), ptr(w2), dtype_code(w2.dtype), ptr(rs), ptr(dwp), ptr(dx), M, O, K, groups,
+                                     current_stream()), "linear_small_bwd")
+    d = L.WPrepDesc(w=ptr(w2), wp=None, gain_ptr=ptr(gain_ptr), gain=1.0, w_dtype=dtype_code(w2.dtype), wp_dtype=L.DDX_F32, Cout=O, Cg=w2.shape[1],
+                    ksize=1, groups=groups, CK=32, normalize=int(normalize), qk_head_dim=0, in_split=0, in_scale0=1.0, in_scale1=1.0, transpose=0,
+                    row_scale=None)
+    dw = torch.empty_like(dwp)
+    dgain = torch.zeros(1, dtype=torch.float32, device=dc.device) if gain_ptr is not None else None
+    check(lib().ddx_mpconv_wprep_bwd(C.byref(d), ptr(dwp), ptr(dw), ptr(dgain), 0, current_stream()), "wprep_bwd(linear)")
+    return dw.reshape(weight.shape), dgain
+
+
 def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4, out_act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RMS normalisation over the last (channel) axis of contiguous rows; `out_act` also receives mp_silu(result)."""
     Cn = x.shape[-1]

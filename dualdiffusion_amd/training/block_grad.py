@@ -1,92 +1,161 @@
-"""Forward-with-tape and backward of one EDM2 decoder-style block on the HIP kernels (training building block).
+"""Forward-with-tape and backward of one EDM2 block (without attention) on the HIP kernels — the unit the whole-UNet
+backward plan is made of.
 
-Mirrors the non-attention path of reference src/modules/unets/unet_edm2_b4.py:110-135,153-158 under autograd:
-    x   = mp_cat(src0, src1)                      (scales s0, s1; src1 optional)
-    y0  = conv_res0(mp_silu(x))
-    y1  = conv_res1(mp_silu(y0 * c))              c = emb_linear(emb) * gain + 1, given here as a [B, Cmid] tensor
-    out = clip(mp_sum(conv_skip(x) | x, y1, t))
-with forced weight normalisation inside the forward (module.training, mp_tools.py:360-361).  The training forward keeps the
-RAW tensors (x sources, y0, out); the backward recomputes the activated conv operands (HBM-bound) and runs
-    mp_sum/clip backward -> conv_res1 wgrad + dgrad -> mp_silu(y0*c) backward (dy0, dc) -> conv_res0 wgrad + dgrad ->
-    conv_skip wgrad + dgrad -> mp_silu(x) backward per source (+ skip gradient) -> weight-path backward.
-This is host orchestration over `dualdiffusion_amd.ops`; it is the unit the whole-UNet backward plan will be made of.
+Mirrors reference src/modules/unets/unet_edm2_b4.py:110-135,153-158 under autograd, forced weight normalisation inside the
+forward (module.training, mp_tools.py:360-361):
+    x   = resample(mp_cat(src0, src1))                              (scales s0, s1; src1 optional)
+    enc: x = normalize(conv_skip(x) | x, dim=channels)
+    y0  = conv_res0(mp_silu(x));   c = emb_linear(emb) * emb_gain + 1
+    y1  = conv_res1(mp_silu(y0 * c))
+    dec: x = conv_skip(x) | x
+    out = clip(mp_sum(x, y1, t))
+The training forward keeps the RAW tensors (block input, pre-norm skip output, y0, out); the backward recomputes the
+activated conv operands (HBM-bound element-wise kernels) and chains
+    mp_sum/clip backward -> conv_res1 wgrad + dgrad -> mp_silu(y0*c) backward (dy0, dc) -> emb_linear backward ->
+    conv_res0 wgrad + dgrad -> mp_silu backward per source (+ residual / skip gradient) -> [pixel-norm backward ->]
+    conv_skip wgrad + dgrad -> resample adjoint -> weight-path backward (weight norm, gains, folded mp_cat scales).
+Host orchestration over `dualdiffusion_amd.ops` only; activations NHWC bf16, master weights fp32.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Optional
 
 import torch
 
 from .. import ops
-from .._lib import PRO_SCALE_SILU, PRO_SILU
+from .._lib import PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_DOWN_BWD, RESAMPLE_UP, RESAMPLE_UP_BWD
+
+
+@dataclass
+class BlockWeightsT:
+    """fp32 master weights of one block (reference state-dict entries `<block>.<name>.weight`, `<block>.emb_gain`)."""
+    conv_res0: torch.Tensor
+    conv_res1: torch.Tensor
+    emb_linear: torch.Tensor
+    emb_gain: torch.Tensor            # 0-d / [1] parameter
+    conv_skip: Optional[torch.Tensor] = None
+    groups: int = 8
 
 
 @dataclass
 class BlockTape:
-    src0: torch.Tensor
+    w: BlockWeightsT
+    flavor: str
+    resample: str
+    in0: torch.Tensor                 # block inputs as given (before resampling)
+    in1: Optional[torch.Tensor]
+    src0: torch.Tensor                # resampled inputs
     src1: Optional[torch.Tensor]
     s0: float
     s1: float
+    emb: torch.Tensor
     c: torch.Tensor
+    xs: Optional[torch.Tensor]        # enc: conv_skip output / resampled input before the pixel norm
+    x1: Optional[torch.Tensor]        # enc: normalised x
     y0: torch.Tensor
     out: torch.Tensor
-    groups: int
     res_t: float
     clip: float
-    pw_res0: ops.PreparedWeight
-    pw_res1: ops.PreparedWeight
-    pw_skip: Optional[ops.PreparedWeight]
-    w_res0: torch.Tensor
-    w_res1: torch.Tensor
-    w_skip: Optional[torch.Tensor]
+    pw: dict = field(default_factory=dict)
 
 
-def block_forward_train(src0: torch.Tensor, src1: Optional[torch.Tensor], s0: float, s1: float, c: torch.Tensor, w_res0: torch.Tensor,
-                        w_res1: torch.Tensor, w_skip: Optional[torch.Tensor], groups: int, res_t: float = 0.3, clip: float = 256.0):
-    """NHWC activations (bf16), fp32 master weights.  Returns (out, tape)."""
-    dt = src0.dtype
+def _resample(x: torch.Tensor, mode: str) -> torch.Tensor:
+    if mode == "keep":
+        return x
+    B, H, W, Cn = x.shape
+    out = torch.empty((B, H * 2, W * 2, Cn) if mode == "up" else (B, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device)
+    return ops.resample2d(x, out, RESAMPLE_UP if mode == "up" else RESAMPLE_DOWN)
+
+
+def _resample_bwd(dx: torch.Tensor, mode: str) -> torch.Tensor:
+    if mode == "keep":
+        return dx
+    B, H, W, Cn = dx.shape
+    out = torch.empty((B, H // 2, W // 2, Cn) if mode == "up" else (B, H * 2, W * 2, Cn), dtype=dx.dtype, device=dx.device)
+    return ops.resample2d(dx, out, RESAMPLE_UP_BWD if mode == "up" else RESAMPLE_DOWN_BWD)
+
+
+def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: float, s1: float, emb: torch.Tensor, w: BlockWeightsT, *,
+                        flavor: str, resample: str = "keep", res_t: float = 0.3, clip: float = 256.0):
+    """in0 (| in1): NHWC bf16 block input(s) (mp_cat scales s0, s1); emb [B, Cemb] fp32.  Returns (out, tape)."""
+    dt, G = in0.dtype, w.groups
+    src0 = _resample(in0, resample)
+    src1 = _resample(in1, resample) if in1 is not None else None
     C0 = src0.shape[-1]
-    pw0 = ops.wprep(w_res0, groups, dt, normalize=True)
-    pw1 = ops.wprep(w_res1, groups, dt, normalize=True)
-    y0 = ops.conv2d(src0, pw0, src1=src1, scale0=s0, scale1=s1, prologue=PRO_SILU)
-    if w_skip is not None:
-        pws = ops.wprep(w_skip, 1, dt, normalize=True, in_split=C0 if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
-        sk = ops.conv2d(src0, pws, src1=src1)
-    else:
+    B = src0.shape[0]
+    gain_ptr = w.emb_gain.reshape(1)
+    Cmid = w.emb_linear.shape[0]
+    c = torch.empty(B, Cmid, dtype=torch.float32, device=in0.device)
+    table = ops.make_linear_jobs([(w.emb_linear, gain_ptr, c, 1.0, 1.0, G, True)], in0.device)
+    ops.linear_small(table, 1, Cmid, emb, B, w.emb_linear.dtype)
+    pw = {"res0": ops.wprep(w.conv_res0, G, dt, normalize=True), "res1": ops.wprep(w.conv_res1, G, dt, normalize=True)}
+    xs = x1 = None
+    if flavor == "enc":
         assert src1 is None and s0 == 1.0
-        pws, sk = None, src0
-    out = ops.conv2d(y0, pw1, prologue=PRO_SCALE_SILU, chan_scale=c, residual=sk, res_t=res_t, clip=clip)
-    return out, BlockTape(src0, src1, s0, s1, c, y0, out, groups, res_t, clip, pw0, pw1, pws, w_res0, w_res1, w_skip)
+        if w.conv_skip is not None:
+            pw["skip"] = ops.wprep(w.conv_skip, 1, dt, normalize=True)
+            xs = ops.conv2d(src0, pw["skip"])
+        else:
+            xs = src0
+        x1 = ops.pixelnorm(xs)
+        y0 = ops.conv2d(x1, pw["res0"], prologue=PRO_SILU)
+        sk = x1
+    else:
+        y0 = ops.conv2d(src0, pw["res0"], src1=src1, scale0=s0, scale1=s1, prologue=PRO_SILU)
+        if w.conv_skip is not None:
+            pw["skip"] = ops.wprep(w.conv_skip, 1, dt, normalize=True, in_split=C0 if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
+            sk = ops.conv2d(src0, pw["skip"], src1=src1)
+        else:
+            assert src1 is None and s0 == 1.0
+            sk = src0
+    out = ops.conv2d(y0, pw["res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=sk, res_t=res_t, clip=clip)
+    return out, BlockTape(w, flavor, resample, in0, in1, src0, src1, s0, s1, emb, c, xs, x1, y0, out, res_t, clip, pw)
 
 
-def block_backward(tape: BlockTape, dout: torch.Tensor):
-    """Gradients of one block: returns dict(dsrc0, dsrc1, dc, dw_res0, dw_res1, dw_skip) (weights fp32, activations NHWC)."""
-    t = tape
-    dt = t.src0.dtype
+def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor] = None) -> dict:
+    """Gradients of one block.  Returns din0, din1, dw_{conv_res0,conv_res1,conv_skip,emb_linear}, demb_gain; accumulates the
+    embedding gradient into `demb` [B, Cemb] fp32 when given."""
+    w, dt, G = t.w, t.src0.dtype, t.w.groups
     C0 = t.src0.shape[-1]
     C1 = t.src1.shape[-1] if t.src1 is not None else 0
-    G = t.groups
+    g: dict = {}
     # out = clip(mp_sum(sk, y1, t))
     dsk, dy1 = ops.mpsum_clip_bwd(dout, t.out, t.res_t, t.clip)
     # y1 = conv_res1(a1), a1 = mp_silu(y0 * c)
     a1 = ops.silu_scale_fwd(t.y0, t.c)
-    dwp1 = ops.conv2d_wgrad(dy1, a1, G, t.pw_res1.ksize)
-    da1 = ops.conv2d(dy1, ops.wprep(t.w_res1, G, dt, normalize=True, transpose=True))
+    g["dw_conv_res1"] = ops.wprep_bwd(t.pw["res1"], ops.conv2d_wgrad(dy1, a1, G, 3))
+    da1 = ops.conv2d(dy1, ops.wprep(w.conv_res1, G, dt, normalize=True, transpose=True))
     dc = torch.zeros_like(t.c)
     dy0 = ops.silu_scale_bwd(da1, t.y0, t.c, 1.0, dc)
-    # y0 = conv_res0(a0), a0 = mp_silu(cat(s0 * src0, s1 * src1))
-    a00 = ops.silu_scale_fwd(t.src0, None, t.s0)
-    a01 = ops.silu_scale_fwd(t.src1, None, t.s1) if t.src1 is not None else None
-    dwp0 = ops.conv2d_wgrad(dy0, a00, G, t.pw_res0.ksize, x1=a01)
-    da0 = ops.conv2d(dy0, ops.wprep(t.w_res0, G, dt, normalize=True, transpose=True))
-    # skip path: sk = conv_skip(cat) with the cat scales folded into the weights, or the input itself
-    if t.w_skip is not None:
-        dwps = ops.conv2d_wgrad(dsk, t.src0, 1, t.pw_skip.ksize, x1=t.src1)
-        dxs = ops.conv2d(dsk, ops.wprep(t.w_skip, 1, dt, normalize=True, transpose=True, in_split=C0 if C1 else 0, in_scale0=t.s0, in_scale1=t.s1))
-        dw_skip = ops.wprep_bwd(t.pw_skip, dwps)
+    # c = emb_linear(emb) * emb_gain + 1
+    g["dw_emb_linear"], g["demb_gain"] = ops.linear_small_bwd(dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), True, demb)
+    g["dc"] = dc
+    if t.flavor == "enc":
+        a0 = ops.silu_scale_fwd(t.x1)
+        g["dw_conv_res0"] = ops.wprep_bwd(t.pw["res0"], ops.conv2d_wgrad(dy0, a0, G, 3))
+        da0 = ops.conv2d(dy0, ops.wprep(w.conv_res0, G, dt, normalize=True, transpose=True))
+        dx1 = ops.silu_scale_bwd(da0, t.x1, None, 1.0, add=dsk)
+        dxs = ops.pixelnorm_bwd(dx1, t.xs)
+        if w.conv_skip is not None:
+            g["dw_conv_skip"] = ops.wprep_bwd(t.pw["skip"], ops.conv2d_wgrad(dxs, t.src0, 1, 1))
+            dsrc0 = ops.conv2d(dxs, ops.wprep(w.conv_skip, 1, dt, normalize=True, transpose=True))
+        else:
+            dsrc0 = dxs
+        dsrc1 = None
     else:
-        dxs, dw_skip = dsk, None
-    dsrc0 = ops.silu_scale_bwd(da0[..., :C0], t.src0, None, t.s0, add=dxs[..., :C0])
-    dsrc1 = ops.silu_scale_bwd(da0[..., C0:], t.src1, None, t.s1, add=dxs[..., C0:]) if C1 else None
-    return dict(dsrc0=dsrc0, dsrc1=dsrc1, dc=dc, dw_res0=ops.wprep_bwd(t.pw_res0, dwp0), dw_res1=ops.wprep_bwd(t.pw_res1, dwp1), dw_skip=dw_skip)
+        a00 = ops.silu_scale_fwd(t.src0, None, t.s0)
+        a01 = ops.silu_scale_fwd(t.src1, None, t.s1) if C1 else None
+        g["dw_conv_res0"] = ops.wprep_bwd(t.pw["res0"], ops.conv2d_wgrad(dy0, a00, G, 3, x1=a01))
+        da0 = ops.conv2d(dy0, ops.wprep(w.conv_res0, G, dt, normalize=True, transpose=True))
+        if w.conv_skip is not None:
+            g["dw_conv_skip"] = ops.wprep_bwd(t.pw["skip"], ops.conv2d_wgrad(dsk, t.src0, 1, 1, x1=t.src1))
+            dxs = ops.conv2d(dsk, ops.wprep(w.conv_skip, 1, dt, normalize=True, transpose=True, in_split=C0 if C1 else 0,
+                                            in_scale0=t.s0, in_scale1=t.s1))
+        else:
+            dxs = dsk
+        dsrc0 = ops.silu_scale_bwd(da0[..., :C0], t.src0, None, t.s0, add=dxs[..., :C0])
+        dsrc1 = ops.silu_scale_bwd(da0[..., C0:], t.src1, None, t.s1, add=dxs[..., C0:]) if C1 else None
+    g["din0"] = _resample_bwd(dsrc0, t.resample)
+    g["din1"] = _resample_bwd(dsrc1, t.resample) if dsrc1 is not None else None
+    return g

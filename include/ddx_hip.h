@@ -81,7 +81,9 @@ int ddx_normalize_weights(void* w, int32_t w_dtype, int64_t rows, int64_t fan_in
  *             (scale applied first, then silu)
  *   epilogue: 0 = store; 1 = mp_sum(residual, y, t) (mp_tools.py:274-279); then clip to +-clip if clip > 0
  * ------------------------------------------------------------------------------------------------ */
-enum { DDX_RESAMPLE_KEEP = 0, DDX_RESAMPLE_UP = 1, DDX_RESAMPLE_DOWN = 2 };
+enum { DDX_RESAMPLE_KEEP = 0, DDX_RESAMPLE_UP = 1, DDX_RESAMPLE_DOWN = 2,
+       /* adjoints, ddx_resample2d only: gradient of UP (2x2 sums) and of DOWN (nearest, x 1/4) */
+       DDX_RESAMPLE_UP_BWD = 3, DDX_RESAMPLE_DOWN_BWD = 4 };
 enum { DDX_PRO_NONE = 0, DDX_PRO_SILU = 1, DDX_PRO_SCALE = 2, DDX_PRO_SCALE_SILU = 3 };
 enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1 };
 
@@ -167,6 +169,15 @@ int ddx_mpsum_clip_bwd(const void* dout, const void* out, void* dres, void* dy, 
                        ddx_stream stream);
 int ddx_pixelnorm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
 int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* d, const float* dwp, float* dw, float* dgain, int32_t accumulate, ddx_stream stream);
+/* Per-row factor of the weight path: row_scale[o] = gain_eff / sqrt(fan_in) / (normalize ? eps + |w_o| / sqrt(fan_in) : 1), so that
+ * w' = w * row_scale[o]  (mp_tools.py:359-364). */
+int ddx_wprep_rowscale(const void* w, int32_t w_dtype, float* row_scale, const float* gain_ptr, float gain, int64_t rows,
+                       int64_t fan_in, int32_t normalize, ddx_stream stream);
+/* Backward of the small-M linear layers c = add_const + x @ w'^T (emb_linear*, unet_edm2_b4.py:121; grouped like the forward
+ * ddx_linear_small_batched): dwp[o][k] = sum_m dc[m][o] x[m][g*K/groups + k]  (gradient w.r.t. the PREPARED weight, feed it to
+ * ddx_mpconv_wprep_bwd), dx[m][.] += dc[m][o] * w[o][k] * row_scale[o]  (dx NULL: skipped; accumulated with atomics). */
+int ddx_linear_small_bwd(const float* dc, const float* x, int32_t x_stride, const void* w, int32_t w_dtype, const float* row_scale,
+                         float* dwp, float* dx, int32_t M, int32_t O, int32_t K, int32_t groups, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RMS ("pixel") normalisation over the channel axis of NHWC rows  (mp_tools.py:42-49 with dim=1,
@@ -230,7 +241,8 @@ int ddx_unet_output_combine(const void* y_nhwc, const float* x_in_nchw, const fl
                             ddx_stream stream);
 
 /* Stand-alone 2x nearest upsample / 2x2 average pool of an NHWC tensor (resample_2d, mp_tools.py:71-79) for the places
- * where it cannot ride in a conv's gather (blocks without a skip conv).  H, W = OUTPUT size; mode = DDX_RESAMPLE_UP|DOWN. */
+ * where it cannot ride in a conv's gather (blocks without a skip conv).  H, W = OUTPUT size; mode = DDX_RESAMPLE_UP|DOWN, or their
+ * adjoints DDX_RESAMPLE_UP_BWD (output = half size) | DDX_RESAMPLE_DOWN_BWD (output = double size) for the backward pass. */
 int ddx_resample2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode, int32_t dtype,
                    ddx_stream stream);
 

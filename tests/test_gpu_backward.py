@@ -1,5 +1,5 @@
 """One EDM2 block forward + backward on the HIP kernels (dualdiffusion_amd.training.block_grad) against torch autograd
-through the oracle's definitions (training mode: forced weight norm inside the forward)."""
+through the oracle's block (oracle.edm2_oracle.block_forward, training mode: forced weight norm inside the forward)."""
 import pytest
 import torch
 
@@ -13,42 +13,74 @@ def _r(x):
     return x.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("case", ["cat_skip", "plain"])
+CASES = {
+    # name: (flavor, resample, C0, C1, Cout, groups, skip conv)
+    "dec_cat_skip": ("dec", "keep", 128, 64, 128, 2, True),    # (128 + 64) / 2 = 96 channels per group: the source split is tile aligned
+    "dec_plain": ("dec", "keep", 128, 0, 128, 8, False),
+    "dec_up": ("dec", "up", 128, 0, 128, 8, False),
+    "enc_down_skip": ("enc", "down", 64, 0, 128, 8, True),
+    "enc_plain": ("enc", "keep", 128, 0, 128, 8, False),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
 def test_block_forward_backward(case):
-    from dualdiffusion_amd.training.block_grad import block_backward, block_forward_train
-    g = torch.Generator().manual_seed(7 if case == "plain" else 8)
-    B, H, W = 2, 12, 40
-    groups = 2 if case == "cat_skip" else 8      # (128 + 64) / 2 = 96 channels per group: the source split is tile aligned
-    C0, C1, Cout = (128, 64, 128) if case == "cat_skip" else (128, 0, 128)
+    from dualdiffusion_amd.training.block_grad import BlockWeightsT, block_backward, block_forward_train
+    flavor, resample, C0, C1, Cout, groups, has_skip = CASES[case]
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    B, H, W, Cemb = 2, 12, 40, 96
+    iH, iW = {"keep": (H, W), "up": (H // 2, W // 2), "down": (H * 2, W * 2)}[resample]
     Cmid = 2 * Cout
-    a = _r(torch.randn(B, C0, H, W, generator=g)).requires_grad_(True)
-    b = _r(torch.randn(B, C1, H, W, generator=g)).requires_grad_(True) if C1 else None
-    w0 = torch.randn(Cmid, (C0 + C1) // groups, 3, 3, generator=g, requires_grad=True)
-    w1 = torch.randn(Cout, Cmid // groups, 3, 3, generator=g, requires_grad=True)
-    ws = torch.randn(Cout, C0 + C1, 1, 1, generator=g, requires_grad=True) if C1 else None
-    c = (torch.rand(B, Cmid, generator=g) + 0.5).requires_grad_(True)
+    a = _r(torch.randn(B, C0, iH, iW, generator=g)).requires_grad_(True)
+    b = _r(torch.randn(B, C1, iH, iW, generator=g)).requires_grad_(True) if C1 else None
+    emb = torch.randn(B, Cemb, generator=g).requires_grad_(True)
+    Cx = Cout if (flavor == "enc" and has_skip) else C0 + C1      # channels seen by conv_res0
+    sd = {"blk.conv_res0.weight": torch.randn(Cmid, Cx // groups, 3, 3, generator=g),
+          "blk.conv_res1.weight": torch.randn(Cout, Cmid // groups, 3, 3, generator=g),
+          "blk.emb_linear.weight": torch.randn(Cmid, Cemb // groups, 1, 1, generator=g),
+          "blk.emb_gain": torch.tensor(0.6)}
+    if has_skip:
+        sd["blk.conv_skip.weight"] = torch.randn(Cout, C0 + C1, 1, 1, generator=g)
+    for v in sd.values():
+        v.requires_grad_(True)
     dout = _r(torch.randn(B, Cout, H, W, generator=g))
     s0, s1 = O.cat_mp_weights(C0, C1, 0.5) if C1 else (1.0, 1.0)
-    # ---- reference: fp32 autograd on the same (bf16-representable) inputs
-    x = torch.cat([s0 * a, s1 * b], 1) if C1 else a
-    y0 = O.conv_mp(O.silu_mp(x), w0, groups=groups, training=True)
-    y1 = O.conv_mp(O.silu_mp(y0 * c[:, :, None, None]), w1, groups=groups, training=True)
-    sk = O.conv_mp(x, ws, training=True) if C1 else x
-    out = O.sum_mp(sk, y1, 0.3).clamp(-256, 256)
-    leaves = [a, w0, w1, c] + ([b, ws] if C1 else [])
-    grads = torch.autograd.grad(out, leaves, dout)
-    ref = dict(zip(["dsrc0", "dw_res0", "dw_res1", "dc"] + (["dsrc1", "dw_skip"] if C1 else []), grads))
+    # ---- reference: fp32 autograd through the oracle's block on the same (bf16-representable) inputs
+    x = O.cat_mp(a, b, 0.5) if C1 else a
+    if has_skip:
+        out = O.block_forward(sd, "blk", x, emb[:, :, None, None], flavor=flavor, resample=resample, attention=False, heads=1, groups=groups,
+                              training=True)
+    else:   # the oracle indexes conv_skip unconditionally for its flavor: blocks without one are the identity there
+        xr = O.resample2x(x, resample)
+        if flavor == "enc":
+            xr = O.rms_normalize(xr, dims=[1])
+        y = O.conv_mp(O.silu_mp(xr), sd["blk.conv_res0.weight"], groups=groups, training=True)
+        c = O.conv_mp(emb[:, :, None, None], sd["blk.emb_linear.weight"], gain=sd["blk.emb_gain"], groups=groups, training=True) + 1.0
+        y = O.conv_mp(O.silu_mp(y * c), sd["blk.conv_res1.weight"], groups=groups, training=True)
+        out = O.sum_mp(xr, y, 0.3).clamp(-256, 256)
+    names = ["din0", "demb", "dw_conv_res0", "dw_conv_res1", "dw_emb_linear", "demb_gain"] + (["din1"] if C1 else []) + (["dw_conv_skip"] if has_skip else [])
+    leaves = [a, emb, sd["blk.conv_res0.weight"], sd["blk.conv_res1.weight"], sd["blk.emb_linear.weight"], sd["blk.emb_gain"]] + \
+             ([b] if C1 else []) + ([sd["blk.conv_skip.weight"]] if has_skip else [])
+    ref = dict(zip(names, torch.autograd.grad(out, leaves, dout)))
     # ---- HIP (bf16 activations, fp32 master weights)
     dt = torch.bfloat16
-    o, tape = block_forward_train(to_nhwc(a.detach(), dt), to_nhwc(b.detach(), dt) if C1 else None, s0, s1, c.detach().cuda(),
-                                  w0.detach().cuda(), w1.detach().cuda(), ws.detach().cuda() if C1 else None, groups, 0.3, 256.0)
-    e_fwd = rel_l2(to_nchw(o), out)
-    got = block_backward(tape, to_nhwc(dout, dt))
+    wts = BlockWeightsT(conv_res0=sd["blk.conv_res0.weight"].detach().cuda(), conv_res1=sd["blk.conv_res1.weight"].detach().cuda(),
+                        emb_linear=sd["blk.emb_linear.weight"].detach().cuda(), emb_gain=sd["blk.emb_gain"].detach().cuda().reshape(1),
+                        conv_skip=sd["blk.conv_skip.weight"].detach().cuda() if has_skip else None, groups=groups)
+    emb_d = emb.detach().cuda()
+    o, tape = block_forward_train(to_nhwc(a.detach(), dt), to_nhwc(b.detach(), dt) if C1 else None, s0, s1, emb_d, wts, flavor=flavor,
+                                  resample=resample, res_t=0.3, clip=256.0)
+    demb = torch.zeros_like(emb_d)
+    got = block_backward(tape, to_nhwc(dout, dt), demb)
+    got["demb"] = demb
     torch.cuda.synchronize()
-    errs = {"fwd": e_fwd}
+    errs = {"fwd": rel_l2(to_nchw(o), out)}
     for k, r in ref.items():
         v = got[k]
-        errs[k] = rel_l2(to_nchw(v) if v.dim() == 4 and k.startswith("dsrc") else v, r)
+        if k.startswith("din"):
+            v = to_nchw(v)
+        errs[k] = rel_l2(v.reshape(r.shape) if not k.startswith("din") else v, r)
     print(f"block {case}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     # bf16 storage of y0 / a1 / the gradients between the kernels: a few 1e-3 per hop
-    assert all(v < 2e-2 for v in errs.values()), errs
+    # (emb_gain's gradient is ONE scalar summed over signed per-channel terms: cancellation amplifies the relative error)
+    assert all(v < (8e-2 if k == "demb_gain" else 2e-2) for k, v in errs.items()), errs
