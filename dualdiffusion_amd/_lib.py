@@ -57,6 +57,13 @@ class WgradDesc(C.Structure):
                 ("groups", C.c_int32), ("ksize", C.c_int32), ("resample", C.c_int32), ("dtype", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class BgemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+                ("sA0", C.c_int64), ("sA1", C.c_int64), ("sB0", C.c_int64), ("sB1", C.c_int64), ("sC0", C.c_int64), ("sC1", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("nb0", C.c_int32), ("nb1", C.c_int32),
+                ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32), ("c_fp32", C.c_int32), ("alpha", C.c_float)]
+
+
 class MssDesc(C.Structure):
     _fields_ = [("sample", C.c_void_p), ("target", C.c_void_p), ("window", C.c_void_p), ("weight", C.c_void_p),
                 ("twiddle", C.c_void_p), ("loss", C.c_void_p), ("grad", C.c_void_p),
@@ -116,6 +123,9 @@ PROTOTYPES = {
     "ddx_wprep_rowscale": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "ddx_linear_small_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_bgemm_bf16": (C.c_int, [C.POINTER(BgemmDesc), C.c_void_p]),
+    "ddx_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
+    "ddx_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -299,6 +299,32 @@ int ddx_fgla_analysis(const float* audio, const float* window, const float* twid
                       int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Batched bf16 GEMM + row softmax: the pieces of the attention BACKWARD pass (unet_edm2_b4.py:137-148 under autograd;
+ * see dualdiffusion_amd/training/attention_grad.py for the composition).
+ *   C[b0][b1][m][n] = alpha * sum_k A(m,k) * B(k,n),  batch = nb0 x nb1 with element strides s?0 / s?1.
+ *   a_kmajor = 0: A(m,k) = A[m*lda + k]   (reduction index contiguous);  1: A(m,k) = A[k*lda + m]
+ *   b_kmajor = 0: B(k,n) = B[n*ldb + k]   (like a weight matrix);        1: B(k,n) = B[k*ldb + n]
+ *   C row-major [m][n] with ldc, bf16 or fp32 (c_fp32).  lda, ldb and the A/B batch strides: multiples of 8; the contiguous
+ *   axis of A and B must be readable (zero padded) up to the next multiple of 8.  Row kernels: rows of n values, stride ld.
+ *   ddx_softmax_rows     : P = softmax(S * scale) over rows of n   (S fp32, P bf16)
+ *   ddx_softmax_bwd_rows : dS = P o (dP - sum_j P dP) * scale        (P bf16, dP fp32, dS bf16)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* A;
+  const void* B;
+  void* C;
+  int64_t lda, ldb, ldc;
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+  int32_t M, N, K, nb0, nb1;
+  int32_t a_kmajor, b_kmajor, c_fp32;
+  float alpha;
+} ddx_bgemm_desc;
+
+int ddx_bgemm_bf16(const ddx_bgemm_desc* d, ddx_stream stream);
+int ddx_softmax_rows(const void* s, void* p, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream);
+int ddx_softmax_bwd_rows(const void* p, const void* dp, void* ds, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-scale 2-D spectral loss, one block width per call  (training/loss/multiscale_spectral.py:213-294 `MSSLoss2D.stft2d`
  * + `mss_loss`, static frequency weighting, phase_loss_scale = 0) -- value AND gradient in one pass:
  *   loss[b] += loss_scale * mean_{c,blocks,kh,kw} weight[kh][kw] * | |S| - |T| |   (use_mse: squared)

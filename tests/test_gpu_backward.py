@@ -84,3 +84,25 @@ def test_block_forward_backward(case):
     # bf16 storage of y0 / a1 / the gradients between the kernels: a few 1e-3 per hop
     # (emb_gain's gradient is ONE scalar summed over signed per-channel terms: cancellation amplifies the relative error)
     assert all(v < (8e-2 if k == "demb_gain" else 2e-2) for k, v in errs.items()), errs
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 86, 2, 64), (1, 2, 43, 3, 64)], ids=["T344", "T86"])
+def test_attention_backward(shape):
+    """Attention backward (batched MFMA GEMMs over materialised P / dS + row softmax + normalize backward) against autograd
+    through the oracle's attention_2d; T = 86 exercises the zero-padded (T -> 88) score matrices."""
+    from dualdiffusion_amd.training.attention_grad import attention_backward
+    B, H, W, heads, d = shape
+    Cn = heads * d
+    g = torch.Generator().manual_seed(B * 100 + W)
+    qk = _r(torch.randn(B, 2 * Cn, H, W, generator=g)).requires_grad_(True)       # oracle layout: (head, d, {q,k})
+    v = _r(torch.randn(B, Cn, H, W, generator=g)).requires_grad_(True)
+    do = _r(torch.randn(B, Cn, H, W, generator=g))
+    o = O.attention_2d(qk, v, heads)
+    dqk_ref, dv_ref = torch.autograd.grad(o, (qk, v), do)
+    perm = lambda t: t.reshape(B, heads, d, 2, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * Cn, H, W)   # -> (head, {q,k}, d)
+    dt = torch.bfloat16
+    dqk, dv = attention_backward(to_nhwc(perm(qk.detach()), dt), to_nhwc(v.detach(), dt), to_nhwc(do, dt), heads)
+    torch.cuda.synchronize()
+    e_qk, e_v = rel_l2(to_nchw(dqk), perm(dqk_ref)), rel_l2(to_nchw(dv), dv_ref)
+    print(f"attention backward {shape}: dqk {e_qk:.2e}, dv {e_v:.2e}")
+    assert e_qk < 2e-2 and e_v < 2e-2
