@@ -115,8 +115,9 @@ PROTOTYPES = {
     "ddx_silu_scale_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_void_p]),
     "ddx_silu_scale_bwd_ex": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                        C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
-    "ddx_silu_scale_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+                                        C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_silu_scale_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_add3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "ddx_mpsum_clip_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_int32, C.c_void_p]),
     "ddx_pixelnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_mpconv_wprep_bwd": (C.c_int, [C.POINTER(WPrepDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

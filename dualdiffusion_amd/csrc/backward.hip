@@ -22,7 +22,7 @@ __device__ __forceinline__ float mp_silu_grad_f(float z) {
 template <typename T>
 __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict__ da, int da_ld, const T* __restrict__ y, const float* __restrict__ cs,
                                                              float scale, const T* __restrict__ add, int add_ld, T* __restrict__ dy,
-                                                             float* __restrict__ dc, int HW, int C, int rows_per_block) {
+                                                             float* __restrict__ dc, int HW, int C, int rows_per_block, int act) {
   constexpr int EV = 16 / (int)sizeof(T);
   const int vbase = blockIdx.z * 256;                 // rows wider than 256 vectors are split over blockIdx.z
   const int nvec = min(C / EV - vbase, 256);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict
 #pragma unroll
     for (int e = 0; e < EV; ++e) {
       const float yv = yy.get(e);
-      const float dz = g.get(e) * mp_silu_grad_f(yv * cv[e]);
+      const float dz = act ? g.get(e) * mp_silu_grad_f(yv * cv[e]) : g.get(e);
       out.set(e, dz * cv[e] + (add ? ad.get(e) : 0.f));
       acc[e] += dz * yv;
     }
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict
 
 template <typename T>
 __global__ __launch_bounds__(256) void silu_scale_fwd_kernel(const T* __restrict__ x, const float* __restrict__ cs, float scale, T* __restrict__ out,
-                                                             size_t rows_per_b, int C, size_t nvec_total) {
+                                                             size_t rows_per_b, int C, size_t nvec_total, int act) {
   constexpr int EV = 16 / (int)sizeof(T);
   const int nvec = C / EV;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec_total; i += (size_t)gridDim.x * 256) {
@@ -68,8 +68,25 @@ __global__ __launch_bounds__(256) void silu_scale_fwd_kernel(const T* __restrict
     Vec16<T> xv, o;
     xv.v = *reinterpret_cast<const decltype(xv.v)*>(x + i * EV);
 #pragma unroll
-    for (int e = 0; e < EV; ++e) o.set(e, mp_silu_f(xv.get(e) * (cs ? cs[b * C + v * EV + e] : 1.0f) * scale));
+    for (int e = 0; e < EV; ++e) {
+      const float z = xv.get(e) * (cs ? cs[b * C + v * EV + e] : 1.0f) * scale;
+      o.set(e, act ? mp_silu_f(z) : z);
+    }
     *reinterpret_cast<decltype(xv.v)*>(out + i * EV) = o.v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ out, size_t nvec) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    Vec16<T> x, y, z, o;
+    x.v = *reinterpret_cast<const decltype(x.v)*>(a + i * EV);
+    y.v = *reinterpret_cast<const decltype(x.v)*>(b + i * EV);
+    if (c) z.v = *reinterpret_cast<const decltype(x.v)*>(c + i * EV);
+#pragma unroll
+    for (int e = 0; e < EV; ++e) o.set(e, x.get(e) + y.get(e) + (c ? z.get(e) : 0.f));
+    *reinterpret_cast<decltype(x.v)*>(out + i * EV) = o.v;
   }
 }
 
@@ -205,7 +222,8 @@ inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 81
 using namespace ddx;
 
 extern "C" int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* y, const float* chan_scale, float scale, const void* add,
-                                     int64_t add_ld, void* dy, float* dc, int32_t B, int64_t HW, int32_t C, int32_t dtype, ddx_stream stream) {
+                                     int64_t add_ld, void* dy, float* dc, int32_t B, int64_t HW, int32_t C, int32_t act, int32_t dtype,
+                                     ddx_stream stream) {
   if (!da || !y || !dy || B <= 0 || HW <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "silu_scale_bwd: bad args");
   const int ev = dtype == DDX_BF16 ? 8 : 4;
   if (C % ev || da_ld % ev || (add && add_ld % ev)) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C and the row strides must be multiples of the 16-byte vector");
@@ -215,30 +233,30 @@ extern "C" int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* 
     dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)((C / ev + 255) / 256));
     if (dtype == DDX_BF16)
       hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (int)da_ld, (const bf16*)y, chan_scale, scale,
-                         (const bf16*)add, (int)add_ld, (bf16*)dy, dc, (int)HW, C, rows_per_block);
+                         (const bf16*)add, (int)add_ld, (bf16*)dy, dc, (int)HW, C, rows_per_block, act);
     else
       hipLaunchKernelGGL(silu_scale_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)da, (int)da_ld, (const float*)y, chan_scale, scale,
-                         (const float*)add, (int)add_ld, (float*)dy, dc, (int)HW, C, rows_per_block);
+                         (const float*)add, (int)add_ld, (float*)dy, dc, (int)HW, C, rows_per_block, act);
     return check_launch("silu_scale_bwd");
   }, stream, "silu_scale_bwd", 0.0, (add ? 4.0 : 3.0) * (double)B * HW * C * (double)dtype_size(dtype));
 }
 
 extern "C" int ddx_silu_scale_bwd(const void* da, const void* y, const float* chan_scale, float scale, void* dy, float* dc, int32_t B,
                                   int64_t HW, int32_t C, int32_t dtype, ddx_stream stream) {
-  return ddx_silu_scale_bwd_ex(da, C, y, chan_scale, scale, nullptr, 0, dy, dc, B, HW, C, dtype, stream);
+  return ddx_silu_scale_bwd_ex(da, C, y, chan_scale, scale, nullptr, 0, dy, dc, B, HW, C, 1, dtype, stream);
 }
 
 extern "C" int ddx_silu_scale_fwd(const void* x, const float* chan_scale, float scale, void* out, int32_t B, int64_t HW, int32_t C,
-                                  int32_t dtype, ddx_stream stream) {
+                                  int32_t act, int32_t dtype, ddx_stream stream) {
   if (!x || !out || B <= 0 || HW <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "silu_scale_fwd: bad args");
   const int ev = dtype == DDX_BF16 ? 8 : 4;
   if (C % ev) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_fwd: C must be a multiple of the 16-byte vector");
   return dispatch([=](hipStream_t s) -> int {
     const size_t nvt = (size_t)B * HW * (C / ev);
     if (dtype == DDX_BF16)
-      hipLaunchKernelGGL(silu_scale_fwd_kernel<bf16>, dim3(grid_for(nvt)), dim3(256), 0, s, (const bf16*)x, chan_scale, scale, (bf16*)out, (size_t)HW, C, nvt);
+      hipLaunchKernelGGL(silu_scale_fwd_kernel<bf16>, dim3(grid_for(nvt)), dim3(256), 0, s, (const bf16*)x, chan_scale, scale, (bf16*)out, (size_t)HW, C, nvt, act);
     else
-      hipLaunchKernelGGL(silu_scale_fwd_kernel<float>, dim3(grid_for(nvt)), dim3(256), 0, s, (const float*)x, chan_scale, scale, (float*)out, (size_t)HW, C, nvt);
+      hipLaunchKernelGGL(silu_scale_fwd_kernel<float>, dim3(grid_for(nvt)), dim3(256), 0, s, (const float*)x, chan_scale, scale, (float*)out, (size_t)HW, C, nvt, act);
     return check_launch("silu_scale_fwd");
   }, stream, "silu_scale_fwd", 0.0, 2.0 * (double)B * HW * C * (double)dtype_size(dtype));
 }
@@ -301,4 +319,16 @@ extern "C" int ddx_linear_small_bwd(const float* dc, const float* x, int32_t x_s
       hipLaunchKernelGGL(linear_small_bwd_kernel<bf16>, dim3(O), dim3(256), 0, s, dc, x, (const bf16*)w, row_scale, dwp, dx, M, O, K / groups, groups, x_stride);
     return check_launch("linear_small_bwd");
   }, stream, "linear_small_bwd");
+}
+
+extern "C" int ddx_add3(const void* a, const void* b, const void* c, void* out, int64_t n, int32_t dtype, ddx_stream stream) {
+  if (!a || !b || !out || n <= 0) return set_error(DDX_ERR_ARG, "add3: bad args");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (n % ev) return set_error(DDX_ERR_UNSUPPORTED, "add3: n must be a multiple of the 16-byte vector");
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t nvec = (size_t)n / ev;
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(grid_for(nvec)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, (const bf16*)c, (bf16*)out, nvec);
+    else hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)a, (const float*)b, (const float*)c, (float*)out, nvec);
+    return check_launch("add3");
+  }, stream, "add3", 0.0, (c ? 4.0 : 3.0) * (double)n * (double)dtype_size(dtype));
 }

@@ -140,7 +140,7 @@ def _chan_view(t: torch.Tensor, Cn: int):
 
 
 def silu_scale_bwd(da: torch.Tensor, y: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0,
-                   dc: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   dc: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None, act: bool = True) -> torch.Tensor:
     """Backward of a = mp_silu(y * chan_scale[b, c] * scale) on NHWC tensors: returns dy (+ add); accumulates into dc [B, C]
     fp32.  `da` and `add` may be channel slices of wider NHWC tensors (one source of an mp_cat)."""
     B, Cn = y.shape[0], y.shape[-1]
@@ -148,15 +148,21 @@ def silu_scale_bwd(da: torch.Tensor, y: torch.Tensor, chan_scale: Optional[torch
     da_p, da_ld = _chan_view(da, Cn)
     add_p, add_ld = _chan_view(add, Cn) if add is not None else (None, 0)
     check(lib().ddx_silu_scale_bwd_ex(da_p, da_ld, ptr(y), ptr(chan_scale), float(scale), add_p, add_ld, ptr(dy), ptr(dc), B,
-                                      y.numel() // (B * Cn), Cn, dtype_code(y.dtype), current_stream()), "silu_scale_bwd")
+                                      y.numel() // (B * Cn), Cn, int(act), dtype_code(y.dtype), current_stream()), "silu_scale_bwd")
     return dy
 
 
-def silu_scale_fwd(x: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+def add3(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a)
+    check(lib().ddx_add3(ptr(a), ptr(b), ptr(c), ptr(out), a.numel(), dtype_code(a.dtype), current_stream()), "add3")
+    return out
+
+
+def silu_scale_fwd(x: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0, act: bool = True) -> torch.Tensor:
     """mp_silu(x * chan_scale[b, c] * scale) on an NHWC tensor (recomputed conv operand of the backward pass)."""
     B, Cn = x.shape[0], x.shape[-1]
     out = torch.empty_like(x)
-    check(lib().ddx_silu_scale_fwd(ptr(x), ptr(chan_scale), float(scale), ptr(out), B, x.numel() // (B * Cn), Cn, dtype_code(x.dtype),
+    check(lib().ddx_silu_scale_fwd(ptr(x), ptr(chan_scale), float(scale), ptr(out), B, x.numel() // (B * Cn), Cn, int(act), dtype_code(x.dtype),
                                    current_stream()), "silu_scale_fwd")
     return out
 

@@ -24,7 +24,8 @@ from typing import Optional
 import torch
 
 from .. import ops
-from .._lib import PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_DOWN_BWD, RESAMPLE_UP, RESAMPLE_UP_BWD
+from .._lib import PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_DOWN_BWD, RESAMPLE_UP, RESAMPLE_UP_BWD
+from .attention_grad import attention_backward
 
 
 @dataclass
@@ -36,6 +37,15 @@ class BlockWeightsT:
     emb_gain: torch.Tensor            # 0-d / [1] parameter
     conv_skip: Optional[torch.Tensor] = None
     groups: int = 8
+    # self-attention part (blocks of the attention levels; unet_edm2_b4.py:137-151)
+    attn_qk: Optional[torch.Tensor] = None
+    attn_v: Optional[torch.Tensor] = None
+    attn_proj: Optional[torch.Tensor] = None
+    emb_linear_qk: Optional[torch.Tensor] = None
+    emb_gain_qk: Optional[torch.Tensor] = None
+    emb_linear_v: Optional[torch.Tensor] = None
+    emb_gain_v: Optional[torch.Tensor] = None
+    heads: int = 0
 
 
 @dataclass
@@ -58,6 +68,7 @@ class BlockTape:
     res_t: float
     clip: float
     pw: dict = field(default_factory=dict)
+    attn: Optional[dict] = None       # c_qk, c_v, qk, v, ao, xa, attn_t
 
 
 def _resample(x: torch.Tensor, mode: str) -> torch.Tensor:
@@ -77,7 +88,7 @@ def _resample_bwd(dx: torch.Tensor, mode: str) -> torch.Tensor:
 
 
 def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: float, s1: float, emb: torch.Tensor, w: BlockWeightsT, *,
-                        flavor: str, resample: str = "keep", res_t: float = 0.3, clip: float = 256.0):
+                        flavor: str, resample: str = "keep", res_t: float = 0.3, clip: float = 256.0, attn_t: float = 0.3):
     """in0 (| in1): NHWC bf16 block input(s) (mp_cat scales s0, s1); emb [B, Cemb] fp32.  Returns (out, tape)."""
     dt, G = in0.dtype, w.groups
     src0 = _resample(in0, resample)
@@ -109,8 +120,27 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
         else:
             assert src1 is None and s0 == 1.0
             sk = src0
-    out = ops.conv2d(y0, pw["res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=sk, res_t=res_t, clip=clip)
-    return out, BlockTape(w, flavor, resample, in0, in1, src0, src1, s0, s1, emb, c, xs, x1, y0, out, res_t, clip, pw)
+    has_attn = w.attn_qk is not None
+    out = ops.conv2d(y0, pw["res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=sk, res_t=res_t, clip=0.0 if has_attn else clip)
+    tape = BlockTape(w, flavor, resample, in0, in1, src0, src1, s0, s1, emb, c, xs, x1, y0, out, res_t, 0.0 if has_attn else clip, pw)
+    if not has_attn:
+        return out, tape
+    # ---- self-attention: qk = attn_qk(x * c_qk), v = attn_v(x), y = attn_proj(mp_silu(attention * c_v)), x = mp_sum(x, y, t)
+    Cout = out.shape[-1]
+    c_qk = torch.empty(B, Cout, dtype=torch.float32, device=in0.device)
+    c_v = torch.empty(B, Cout, dtype=torch.float32, device=in0.device)
+    table = ops.make_linear_jobs([(w.emb_linear_qk, w.emb_gain_qk.reshape(1), c_qk, 1.0, 1.0, 1, True),
+                                  (w.emb_linear_v, w.emb_gain_v.reshape(1), c_v, 1.0, 1.0, 1, True)], in0.device)
+    ops.linear_small(table, 2, Cout, emb, B, w.emb_linear_qk.dtype)
+    pw["qk"] = ops.wprep(w.attn_qk, 1, dt, normalize=True, qk_head_dim=Cout // w.heads)
+    pw["v"] = ops.wprep(w.attn_v, 1, dt, normalize=True)
+    pw["proj"] = ops.wprep(w.attn_proj, 1, dt, normalize=True)
+    qk = ops.conv2d(out, pw["qk"], prologue=PRO_SCALE, chan_scale=c_qk)
+    vv = ops.conv2d(out, pw["v"])
+    ao = ops.attention(qk, vv, w.heads)
+    xa = ops.conv2d(ao, pw["proj"], prologue=PRO_SCALE_SILU, chan_scale=c_v, residual=out, res_t=attn_t, clip=clip)
+    tape.attn = dict(c_qk=c_qk, c_v=c_v, qk=qk, v=vv, ao=ao, xa=xa, attn_t=attn_t, clip=clip)
+    return xa, tape
 
 
 def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor] = None) -> dict:
@@ -120,6 +150,28 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     C0 = t.src0.shape[-1]
     C1 = t.src1.shape[-1] if t.src1 is not None else 0
     g: dict = {}
+    if t.attn is not None:
+        a = t.attn
+        one = w.emb_gain_qk.reshape(1)
+        # xa = clip(mp_sum(out, attn_proj(ap), t)), ap = mp_silu(ao * c_v)
+        dout_res, dyp = ops.mpsum_clip_bwd(dout, a["xa"], a["attn_t"], a["clip"])
+        ap = ops.silu_scale_fwd(a["ao"], a["c_v"])
+        g["dw_attn_proj"] = ops.wprep_bwd(t.pw["proj"], ops.conv2d_wgrad(dyp, ap, 1, 1))
+        dap = ops.conv2d(dyp, ops.wprep(w.attn_proj, 1, dt, normalize=True, transpose=True))
+        dc_v = torch.zeros_like(a["c_v"])
+        dao = ops.silu_scale_bwd(dap, a["ao"], a["c_v"], 1.0, dc_v)
+        g["dw_emb_linear_v"], g["demb_gain_v"] = ops.linear_small_bwd(dc_v, t.emb, w.emb_linear_v, 1, w.emb_gain_v.reshape(1), True, demb)
+        dqk, dv = attention_backward(a["qk"], a["v"], dao, w.heads)
+        # v = attn_v(out);  qk = attn_qk(out * c_qk) with the (head, {q,k}, d) row order of the forward preparation
+        g["dw_attn_v"] = ops.wprep_bwd(t.pw["v"], ops.conv2d_wgrad(dv, t.out, 1, 1))
+        dout_v = ops.conv2d(dv, ops.wprep(w.attn_v, 1, dt, normalize=True, transpose=True))
+        xs_qk = ops.silu_scale_fwd(t.out, a["c_qk"], 1.0, act=False)
+        g["dw_attn_qk"] = ops.wprep_bwd(t.pw["qk"], ops.conv2d_wgrad(dqk, xs_qk, 1, 1))
+        dxs = ops.conv2d(dqk, ops.wprep(w.attn_qk, 1, dt, normalize=True, transpose=True, qk_head_dim=t.out.shape[-1] // w.heads))
+        dc_qk = torch.zeros_like(a["c_qk"])
+        dout_qk = ops.silu_scale_bwd(dxs, t.out, a["c_qk"], 1.0, dc_qk, add=dout_v, act=False)
+        g["dw_emb_linear_qk"], g["demb_gain_qk"] = ops.linear_small_bwd(dc_qk, t.emb, w.emb_linear_qk, 1, one, True, demb)
+        dout = ops.add3(dout_res, dout_qk)
     # out = clip(mp_sum(sk, y1, t))
     dsk, dy1 = ops.mpsum_clip_bwd(dout, t.out, t.res_t, t.clip)
     # y1 = conv_res1(a1), a1 = mp_silu(y0 * c)

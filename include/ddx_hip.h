@@ -161,10 +161,14 @@ int ddx_silu_scale_bwd(const void* da, const void* y, const float* chan_scale, f
 /* Same with a row-strided da (da_ld elements between pixel rows: a channel slice of a wider NHWC tensor, i.e. one source of an
  * mp_cat) and an optional row-strided addend: dy = da * a'(.) * chan_scale * scale + add  (the skip conv's data gradient). */
 int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* y, const float* chan_scale, float scale, const void* add,
-                          int64_t add_ld, void* dy, float* dc, int32_t B, int64_t HW, int32_t C, int32_t dtype, ddx_stream stream);
-/* out = mp_silu(x * chan_scale[b][c] * scale): recomputes a conv operand in the backward pass (training keeps the raw tensors). */
+                          int64_t add_ld, void* dy, float* dc, int32_t B, int64_t HW, int32_t C, int32_t act, int32_t dtype,
+                          ddx_stream stream);
+/* out = mp_silu(x * chan_scale[b][c] * scale): recomputes a conv operand in the backward pass (training keeps the raw tensors).
+ * act = 0 (here and in ddx_silu_scale_bwd_ex) drops the mp_silu: the plain `x * c` operand of attn_qk (unet_edm2_b4.py:139). */
 int ddx_silu_scale_fwd(const void* x, const float* chan_scale, float scale, void* out, int32_t B, int64_t HW, int32_t C,
-                       int32_t dtype, ddx_stream stream);
+                       int32_t act, int32_t dtype, ddx_stream stream);
+/* out = a + b (+ c): gradient contributions of several consumers of one tensor (same shape, c may be NULL). */
+int ddx_add3(const void* a, const void* b, const void* c, void* out, int64_t n, int32_t dtype, ddx_stream stream);
 int ddx_mpsum_clip_bwd(const void* dout, const void* out, void* dres, void* dy, float t, float clip, int64_t n, int32_t dtype,
                        ddx_stream stream);
 int ddx_pixelnorm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
