@@ -1,0 +1,155 @@
+"""Training forward (with tape) and backward of the whole EDM2 UNet on the HIP kernels.
+
+Chains `block_grad.block_forward_train / block_backward` over the encoder / decoder of reference
+src/modules/unets/unet_edm2_b4.py:250-296 (module.training: forced weight norm inside the forward), with
+    * the front end  c_in * x, [x, 1, ln_freq] -> conv_in;   emb = mp_silu(mp_sum(emb_noise(fourier(c_noise)), embeddings, t))
+    * the skip stack (decoder `layer` blocks read mp_cat(x, skip)),
+    * the output     D = c_skip * x_in + c_out * conv_out(x) * out_gain.
+`backward(dD)` returns the gradient of every parameter that takes part in `forward` (keys = state-dict names) plus the
+gradient w.r.t. the label embeddings input.  Eager host orchestration over `dualdiffusion_amd.ops`; activations NHWC bf16,
+master weights fp32.  Not yet here: get_embeddings / logvar backward (tiny linear layers), the launch-plan / hipGraph form.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+from ..engine import mp_cat_weights
+from .._lib import DDXError
+from .block_grad import BlockWeightsT, block_backward, block_forward_train
+
+
+def _block_weights(blk, groups: int) -> BlockWeightsT:
+    w = BlockWeightsT(conv_res0=blk.conv_res0.weight.data, conv_res1=blk.conv_res1.weight.data, emb_linear=blk.emb_linear.weight.data,
+                      emb_gain=blk.emb_gain.data.reshape(1), conv_skip=blk.conv_skip.weight.data if blk.conv_skip is not None else None,
+                      groups=groups)
+    if blk.use_attention:
+        w.attn_qk, w.attn_v, w.attn_proj = blk.attn_qk.weight.data, blk.attn_v.weight.data, blk.attn_proj.weight.data
+        w.emb_linear_qk, w.emb_linear_v = blk.emb_linear_qk.weight.data, blk.emb_linear_v.weight.data
+        w.emb_gain_qk, w.emb_gain_v = blk.emb_gain_qk.data.reshape(1), blk.emb_gain_v.data.reshape(1)
+        w.heads = blk.num_heads
+    return w
+
+
+class UNetTrainer:
+    """forward(x_in, sigma, format, embeddings) -> D_x (NCHW fp32); backward(dD) -> {parameter name: gradient}."""
+
+    def __init__(self, unet) -> None:
+        # mixed precision as the reference trains (accelerate bf16 autocast over fp32 parameters, trainer.py:375): the module
+        # keeps fp32 master weights, every activation / prepared weight on the device is bf16
+        if unet.device.type != "cuda" or next(unet.parameters()).dtype != torch.float32:
+            raise DDXError("UNetTrainer: module must be on the ROCm device with float32 (master) parameters")
+        self.u = unet
+        self.tape: Optional[dict] = None
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor) -> torch.Tensor:
+        u, cfg, dev, dt = self.u, self.u.config, self.u.device, torch.bfloat16
+        B, _, H, W = x_in.shape
+        G = cfg.mlp_groups
+        x_in = x_in.to(dev, torch.float32).contiguous()
+        sig = sigma.flatten().to(dev, torch.float32).contiguous()
+        emb_in = embeddings.to(dev, torch.float32).contiguous()
+        lnf = u.get_ln_freqs_rows(format, B, H, W).to(dev)
+        # front end
+        x0 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
+        ops.unet_input_prep(x_in, sig, lnf, x0, cfg.sigma_data)
+        four = torch.empty(B, u.cnoise, dtype=torch.float32, device=dev)
+        ops.mpfourier(sig, u.emb_fourier.freqs.float().contiguous(), u.emb_fourier.phases.float().contiguous(), four, True)
+        e0 = torch.empty(B, u.cemb, dtype=torch.float32, device=dev)
+        w_noise = u.emb_noise.weight.data
+        ops.linear_small(ops.make_linear_jobs([(w_noise, None, e0, 1.0, 0.0, 1, True)], dev), 1, u.cemb, four, B, w_noise.dtype)
+        pre, emb = torch.empty_like(e0), torch.empty_like(e0)
+        ops.mpsum_rows(e0, emb_in, pre, t=cfg.label_balance, silu=False)
+        ops.mpsum_rows(e0, emb_in, emb, t=cfg.label_balance, silu=True)
+        # conv_in
+        w_in = u.enc["conv_in"].weight.data
+        pw_in = ops.wprep(w_in, 1, dt, normalize=True, cg_pad=8, npix=B * H * W)
+        x = ops.conv2d(x0, pw_in)
+        tapes, skips = [], [x]
+        kw = dict(res_t=cfg.res_balance, attn_t=cfg.attn_balance)
+        for name, blk in u.enc.items():
+            if name == "conv_in":
+                continue
+            x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G), flavor="enc", resample=blk.resample_mode, **kw)
+            tapes.append(("enc." + name, blk, t, None))
+            skips.append(x)
+        n_enc = len(skips)
+        stack = list(range(n_enc))
+        for name, blk in u.dec.items():
+            if "layer" in name:
+                si = stack.pop()
+                sk = skips[si]
+                s0, s1 = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
+                x, t = block_forward_train(x, sk, s0, s1, emb, _block_weights(blk, G), flavor="dec", resample=blk.resample_mode, **kw)
+                tapes.append(("dec." + name, blk, t, si))
+            else:
+                x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G), flavor="dec", resample=blk.resample_mode, **kw)
+                tapes.append(("dec." + name, blk, t, None))
+        # conv_out on an 8-row padded weight (4 output channels do not fill a 16-byte NHWC vector)
+        w_out = u.conv_out.weight.data
+        Co = w_out.shape[0]
+        w_out8 = torch.zeros(8, *w_out.shape[1:], dtype=w_out.dtype, device=dev)
+        w_out8[:Co] = w_out
+        gain = u.out_gain.data.reshape(1)
+        pw_out = ops.wprep(w_out8, 1, dt, gain_ptr=gain, normalize=True, npix=B * H * W)
+        y8 = ops.conv2d(x, pw_out)
+        y = y8[..., :Co].contiguous()
+        out = torch.empty(B, Co, H, W, dtype=torch.float32, device=dev)
+        ops.unet_output_combine(y, x_in, sig, None, out, cfg.sigma_data)
+        self.tape = dict(B=B, H=H, W=W, sig=sig, x0=x0, four=four, pre=pre, emb=emb, pw_in=pw_in, tapes=tapes, n_enc=n_enc, x_last=x,
+                         w_out8=w_out8, pw_out=pw_out, gain=gain, Co=Co)
+        return out
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def backward(self, dD: torch.Tensor) -> dict:
+        u, cfg, t, dev, dt = self.u, self.u.config, self.tape, self.u.device, torch.bfloat16
+        if t is None:
+            raise DDXError("UNetTrainer.backward before forward")
+        B, H, W, Co = t["B"], t["H"], t["W"], t["Co"]
+        grads: dict = {}
+        # D = c_skip * x_in + c_out * y  ->  dy = c_out[b] * dD   (tiny [B, 4, H, W] glue on the host side of the boundary)
+        sd = cfg.sigma_data
+        c_out = (t["sig"] * sd / torch.sqrt(t["sig"] ** 2 + sd ** 2)).view(B, 1, 1, 1)
+        dy8 = torch.zeros(B, H, W, 8, dtype=dt, device=dev)
+        dy8[..., :Co] = (dD.to(dev, torch.float32) * c_out).permute(0, 2, 3, 1).to(dt)
+        # conv_out (+ out_gain)
+        dwp8 = ops.conv2d_wgrad(dy8, t["x_last"], 1, 3)
+        dgain = torch.zeros(1, dtype=torch.float32, device=dev)
+        dw8 = ops.wprep_bwd(t["pw_out"], dwp8, dgain=dgain)
+        grads["conv_out.weight"], grads["out_gain"] = dw8[:Co].clone(), dgain.reshape(())
+        dx = ops.conv2d(dy8, ops.wprep(t["w_out8"], 1, dt, gain_ptr=t["gain"], normalize=True, transpose=True))
+        # decoder / encoder blocks in reverse; skip gradients wait for their encoder stage
+        demb = torch.zeros_like(t["emb"])
+        dskip: dict = {}
+        enc_index = t["n_enc"] - 1
+        for name, blk, tape, si in reversed(t["tapes"]):
+            if name.startswith("enc."):
+                if enc_index in dskip:
+                    dx = ops.add3(dx, dskip.pop(enc_index))
+                enc_index -= 1
+            g = block_backward(tape, dx, demb)
+            dx = g["din0"]
+            if si is not None:
+                dskip[si] = g["din1"]
+            for k, v in g.items():
+                if k.startswith("dw_"):
+                    grads[f"{name}.{k[3:]}.weight"] = v
+                elif k.startswith("demb_gain"):
+                    grads[f"{name}.emb_gain{k[len('demb_gain'):]}"] = v.reshape(())
+        # conv_in: its output is skip 0 and the first block's input
+        if 0 in dskip:
+            dx = ops.add3(dx, dskip.pop(0))
+        dwp_in = ops.conv2d_wgrad(dx, t["x0"], 1, 3)                       # [Cout, 8, 3, 3]; the weight has 6 input channels
+        cin = u.enc["conv_in"].weight.shape[1]
+        grads["enc.conv_in.weight"] = ops.wprep_bwd(t["pw_in"], dwp_in[:, :cin].contiguous())
+        # emb = mp_silu(pre), pre = mp_sum(emb_noise(four), embeddings, t)
+        dpre = ops.silu_scale_bwd(demb.view(B, 1, -1), t["pre"].view(B, 1, -1), None, 1.0).view(B, -1)
+        tb = cfg.label_balance
+        nrm = ((1 - tb) ** 2 + tb ** 2) ** 0.5
+        de0 = ops.lincomb3(torch.empty_like(dpre), dpre, (1 - tb) / nrm)
+        grads["embeddings"] = ops.lincomb3(torch.empty_like(dpre), dpre, tb / nrm)
+        grads["emb_noise.weight"], _ = ops.linear_small_bwd(de0, t["four"], u.emb_noise.weight.data, 1, None, True, None)
+        return grads

@@ -134,3 +134,62 @@ def test_attention_backward(shape):
     e_qk, e_v = rel_l2(to_nchw(dqk), perm(dqk_ref)), rel_l2(to_nchw(dv), dv_ref)
     print(f"attention backward {shape}: dqk {e_qk:.2e}, dv {e_v:.2e}")
     assert e_qk < 2e-2 and e_v < 2e-2
+
+
+class _Fmt:
+    def __init__(self, fmin=20.0, fmax=16000.0):
+        from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+        self.ms_freq_scale = FrequencyScale("mel", fmin, fmax, 32000, 3201, 256)
+
+
+def test_unet_training_forward_backward():
+    """Whole EDM2 UNet (2 levels, attention on level 1, every block flavour) forward + backward on the HIP kernels against
+    fp32 autograd through the oracle's unet_forward (training mode), for a random upstream gradient dD."""
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.training.unet_grad import UNetTrainer
+    # model_channels = 256 as in the default config: every mp_cat source split then falls on a 32-channel tile of a group
+    over = dict(model_channels=256, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=64, num_layers_per_block=1, in_channels_emb=64,
+                logvar_channels=32)
+    cfg = O.unet_cfg(**over)
+    sd = O.random_unet_state(cfg, seed=3, gain_value=0.6, normalized=False)
+    g = torch.Generator().manual_seed(17)
+    B, H, W = 2, 16, 32
+    x_in = torch.randn(B, 4, H, W, generator=g)
+    sigma = torch.tensor([0.4, 3.0])
+    emb_in = torch.randn(B, O.unet_topology(cfg)["cemb"], generator=g)
+    dD = torch.randn(B, 4, H, W, generator=g)
+    # ---- reference
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "fourier" not in k and not k.startswith("logvar")
+              and not k.startswith("emb_label")}
+    sd_ref = dict(sd); sd_ref.update(params)
+    emb_ref = emb_in.clone().requires_grad_(True)
+    out_ref = O.unet_forward(sd_ref, cfg, x_in, sigma, emb_ref, training=True)
+    names = list(params)
+    gref = dict(zip(names + ["embeddings"], torch.autograd.grad(out_ref, [params[k] for k in names] + [emb_ref], dD, allow_unused=True)))
+    # ---- HIP
+    unet = UNet(UNetConfig(**over)).requires_grad_(False)
+    unet.load_state_dict(sd, strict=True)
+    unet = unet.to(device="cuda", dtype=torch.float32).train(True)
+    tr = UNetTrainer(unet)
+    out = tr.forward(x_in, sigma, _Fmt(), emb_in)
+    grads = tr.backward(dD)
+    torch.cuda.synchronize()
+    e_fwd = rel_l2(out, out_ref)
+    errs = {}
+    for k, r in gref.items():
+        if r is None:
+            continue
+        assert k in grads, f"no gradient for {k}"
+        errs[k] = rel_l2(grads[k].reshape(r.shape), r)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print(f"unet train: fwd {e_fwd:.2e}; {len(errs)} gradients, worst: " + ", ".join(f"{k} {v:.2e}" for k, v in worst))
+    assert e_fwd < 2e-2
+    rest = {k: v for k, v in errs.items() if "gain" not in k}
+    assert all(v < 3e-2 for v in rest.values()), {k: v for k, v in rest.items() if v >= 3e-2}
+    # the 0-d gains: each gradient is ONE scalar summed over signed per-channel terms (cancellation), so they are judged
+    # together against the largest gain gradient of the model
+    gk = [k for k in errs if "gain" in k]
+    gmax = max(abs(float(gref[k])) for k in gk)
+    bad = {k: (float(grads[k]), float(gref[k])) for k in gk if abs(float(grads[k]) - float(gref[k])) > 3e-2 * abs(float(gref[k])) + 1e-2 * gmax}
+    print("gain gradients (hip, ref): " + ", ".join(f"{k.split('.')[-2]}.{k.split('.')[-1]} {float(grads[k]):+.3e}/{float(gref[k]):+.3e}" for k in gk[:8]))
+    assert not bad, bad
