@@ -127,6 +127,8 @@ PROTOTYPES = {
     "ddx_bgemm_bf16": (C.c_int, [C.POINTER(BgemmDesc), C.c_void_p]),
     "ddx_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "ddx_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
+    "ddx_edm2_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                C.c_int64, C.c_void_p]),
     "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

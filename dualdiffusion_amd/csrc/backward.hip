@@ -214,6 +214,38 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __re
   }
 }
 
+// EDM2 training loss (reference training/module_trainers/unet_trainer.py:271-282): per sample
+//   wl = mean_chw((D - x)^2) * (sigma^2 + sd^2) / (sigma * sd)^2,   loss = wl / exp(logvar) + logvar,
+// and the gradients of mean_b(loss): dD = (2 w / (N B exp(logvar))) (D - x), dlogvar = (1 - wl / exp(logvar)) / B.
+__global__ __launch_bounds__(256) void edm2_loss_grad_kernel(const float* __restrict__ d, const float* __restrict__ x, const float* __restrict__ sigma,
+                                                             const float* __restrict__ logvar, float sd, float* __restrict__ dd, float* __restrict__ ss,
+                                                             int B, size_t n) {
+  __shared__ float scratch[4];
+  const int b = blockIdx.y;
+  const float sg = sigma[b];
+  const float w = (sg * sg + sd * sd) / ((sg * sd) * (sg * sd));
+  const float k = 2.0f * w / ((float)n * (float)B * __expf(logvar ? logvar[b] : 0.f));
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float e = d[b * n + i] - x[b * n + i];
+    acc += e * e;
+    if (dd) dd[b * n + i] = k * e;
+  }
+  acc = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) atomicAdd(ss + b, acc);
+}
+__global__ void edm2_loss_finish_kernel(const float* __restrict__ ss, const float* __restrict__ sigma, const float* __restrict__ logvar, float sd,
+                                        float* __restrict__ loss, float* __restrict__ dlogvar, int B, size_t n) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float sg = sigma[b];
+  const float w = (sg * sg + sd * sd) / ((sg * sd) * (sg * sd));
+  const float wl = ss[b] / (float)n * w;
+  const float lv = logvar ? logvar[b] : 0.f;
+  loss[b] = logvar ? wl * __expf(-lv) + lv : wl;
+  if (dlogvar) dlogvar[b] = (1.0f - wl * __expf(-lv)) / (float)B;
+}
+
 inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
 
 }  // namespace
@@ -331,4 +363,17 @@ extern "C" int ddx_add3(const void* a, const void* b, const void* c, void* out, 
     else hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(nvec)), dim3(256), 0, s, (const float*)a, (const float*)b, (const float*)c, (float*)out, nvec);
     return check_launch("add3");
   }, stream, "add3", 0.0, (c ? 4.0 : 3.0) * (double)n * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data, float* loss,
+                             float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream) {
+  if (!denoised || !target || !sigma || !loss || !workspace || B <= 0 || n_per_sample <= 0) return set_error(DDX_ERR_ARG, "edm2_loss: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    if (hipMemsetAsync(workspace, 0, sizeof(float) * B, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "edm2_loss: memset");
+    dim3 grid((unsigned)std::min<int64_t>((n_per_sample + 255) / 256, 512), (unsigned)B);
+    hipLaunchKernelGGL(edm2_loss_grad_kernel, grid, dim3(256), 0, s, denoised, target, sigma, logvar, sigma_data, d_denoised, workspace, B, (size_t)n_per_sample);
+    hipLaunchKernelGGL(edm2_loss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)workspace, sigma, logvar, sigma_data, loss, d_logvar, B,
+                       (size_t)n_per_sample);
+    return check_launch("edm2_loss");
+  }, stream, "edm2_loss");
 }

@@ -216,6 +216,21 @@ def linear_small_bwd(dc: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, gr
     return dw.reshape(weight.shape), dgain
 
 
+def edm2_loss(denoised: torch.Tensor, target: torch.Tensor, sigma: torch.Tensor, logvar: Optional[torch.Tensor], sigma_data: float,
+              want_grad: bool = True):
+    """Per-sample EDM2 loss [B] (+ d mean(loss)/d denoised, d mean(loss)/d logvar) -- unet_trainer.py:271-282."""
+    B = denoised.shape[0]
+    n = denoised.numel() // B
+    dev = denoised.device
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    dd = torch.empty_like(denoised) if want_grad else None
+    dlv = torch.empty(B, dtype=torch.float32, device=dev) if (want_grad and logvar is not None) else None
+    ws = torch.empty(B, dtype=torch.float32, device=dev)
+    check(lib().ddx_edm2_loss(ptr(denoised), ptr(target), ptr(sigma), ptr(logvar), float(sigma_data), ptr(loss), ptr(dd), ptr(dlv), ptr(ws), B, n,
+                              current_stream()), "edm2_loss")
+    return loss, dd, dlv
+
+
 def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4, out_act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RMS normalisation over the last (channel) axis of contiguous rows; `out_act` also receives mp_silu(result)."""
     Cn = x.shape[-1]

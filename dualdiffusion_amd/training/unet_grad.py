@@ -45,17 +45,19 @@ class UNetTrainer:
         self.tape: Optional[dict] = None
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor) -> torch.Tensor:
+    def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor,
+                perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
         u, cfg, dev, dt = self.u, self.u.config, self.u.device, torch.bfloat16
         B, _, H, W = x_in.shape
         G = cfg.mlp_groups
         x_in = x_in.to(dev, torch.float32).contiguous()
+        x_pre = perturbed_input.to(dev, torch.float32).contiguous() if perturbed_input is not None else x_in
         sig = sigma.flatten().to(dev, torch.float32).contiguous()
         emb_in = embeddings.to(dev, torch.float32).contiguous()
         lnf = u.get_ln_freqs_rows(format, B, H, W).to(dev)
         # front end
         x0 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
-        ops.unet_input_prep(x_in, sig, lnf, x0, cfg.sigma_data)
+        ops.unet_input_prep(x_pre, sig, lnf, x0, cfg.sigma_data)
         four = torch.empty(B, u.cnoise, dtype=torch.float32, device=dev)
         ops.mpfourier(sig, u.emb_fourier.freqs.float().contiguous(), u.emb_fourier.phases.float().contiguous(), four, True)
         e0 = torch.empty(B, u.cemb, dtype=torch.float32, device=dev)
@@ -153,3 +155,49 @@ class UNetTrainer:
         grads["embeddings"] = ops.lincomb3(torch.empty_like(dpre), dpre, tb / nrm)
         grads["emb_noise.weight"], _ = ops.linear_small_bwd(de0, t["four"], u.emb_noise.weight.data, 1, None, True, None)
         return grads
+
+    # ------------------------------------------------------------------------------------------------ one training batch
+    def train_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
+                    conditioning_mask: torch.Tensor, format, input_perturbation: Optional[torch.Tensor] = None,
+                    input_perturbation_scale: float = 0.0):
+        """The device part of reference UNetTrainer.unet_train_batch (unet_trainer.py:222-296) with the random draws given:
+        noise / input_perturbation ~ N(0, 1) like `samples`, conditioning_mask [B] bool, sigma [B].
+        Returns (loss [B], grads) where grads holds d mean(loss) / d parameter for EVERY parameter of the module."""
+        u, cfg, dev = self.u, self.u.config, self.u.device
+        B = samples.shape[0]
+        samples = samples.to(dev, torch.float32).contiguous()
+        sig = sigma.flatten().to(dev, torch.float32).contiguous()
+        mask = conditioning_mask.to(dev, torch.float32).contiguous()
+        # get_embeddings (unet_edm2_b4.py:232-235) -- kept here with its intermediates for the backward
+        xn = ops.pixelnorm(audio_embeddings.to(dev, torch.float32).contiguous())
+        ones = torch.ones(1, 1, device=dev, dtype=torch.float32)
+        uemb = torch.empty(1, u.cemb, device=dev, dtype=torch.float32)
+        cemb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
+        w_u, w_c = u.emb_label_unconditional.weight.data, u.emb_label.weight.data
+        ops.linear_small(ops.make_linear_jobs([(w_u, None, uemb, 1.0, 0.0, 1, True)], dev), 1, u.cemb, ones, 1, w_u.dtype)
+        ops.linear_small(ops.make_linear_jobs([(w_c, None, cemb, 1.0, 0.0, 1, True)], dev), 1, u.cemb, xn, B, w_c.dtype)
+        emb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
+        ops.mpsum_rows(uemb, cemb, emb, t_rows=mask)
+        # model inputs (unet_trainer.py:249-259)
+        s4 = sig.view(-1, 1, 1, 1)
+        x_in = samples + noise.to(dev, torch.float32) * s4
+        pert = x_in + input_perturbation.to(dev, torch.float32) * s4 * input_perturbation_scale if input_perturbation is not None else None
+        denoised = self.forward(x_in, sig, format, emb, pert)
+        # learned per-sigma log-variance (unet_edm2_b4.py:237-238; no weight norm on logvar_linear)
+        f_lv = torch.empty(B, cfg.logvar_channels, device=dev, dtype=torch.float32)
+        ops.mpfourier(sig, u.logvar_fourier.freqs.float().contiguous(), u.logvar_fourier.phases.float().contiguous(), f_lv, True)
+        logvar = torch.empty(B, 1, device=dev, dtype=torch.float32)
+        w_lv = u.logvar_linear.weight.data
+        ops.linear_small(ops.make_linear_jobs([(w_lv, None, logvar, 1.0, 0.0, 1, False)], dev), 1, 1, f_lv, B, w_lv.dtype)
+        loss, dD, dlv = ops.edm2_loss(denoised, samples, sig, logvar.view(-1), cfg.sigma_data)
+        grads = self.backward(dD)
+        grads["logvar_linear.weight"], _ = ops.linear_small_bwd(dlv.view(B, 1), f_lv, w_lv, 1, None, False, None)
+        # embeddings = mp_sum(u, c, mask) row-wise with mask in {0, 1}: rows pick c (conditioned) or u (dropped)  -- [B, cemb] glue
+        dE = grads.pop("embeddings")
+        t = mask.view(-1, 1)
+        nrm = torch.sqrt((1 - t) ** 2 + t ** 2)
+        dc = (dE * t / nrm).contiguous()
+        du = (dE * (1 - t) / nrm).sum(dim=0, keepdim=True).contiguous()
+        grads["emb_label.weight"], _ = ops.linear_small_bwd(dc, xn, w_c, 1, None, True, None)
+        grads["emb_label_unconditional.weight"], _ = ops.linear_small_bwd(du, ones, w_u, 1, None, True, None)
+        return loss, grads

@@ -173,6 +173,12 @@ int ddx_mpsum_clip_bwd(const void* dout, const void* out, void* dres, void* dy, 
                        ddx_stream stream);
 int ddx_pixelnorm_bwd(const void* dy, const void* x, void* dx, int64_t rows, int32_t C, float eps, int32_t dtype, ddx_stream stream);
 int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* d, const float* dwp, float* dw, float* dgain, int32_t accumulate, ddx_stream stream);
+/* EDM2 training loss and its gradients (training/module_trainers/unet_trainer.py:271-282), fp32 NCHW:
+ *   wl[b] = mean((denoised - target)^2) * (sigma^2 + sd^2) / (sigma sd)^2;  loss[b] = wl / exp(logvar) + logvar  (logvar NULL: wl)
+ *   d_denoised = d mean_b(loss) / d denoised,  d_logvar[b] = d mean_b(loss) / d logvar[b]   (either may be NULL)
+ * workspace: B floats. */
+int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data, float* loss,
+                  float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream);
 /* Per-row factor of the weight path: row_scale[o] = gain_eff / sqrt(fan_in) / (normalize ? eps + |w_o| / sqrt(fan_in) : 1), so that
  * w' = w * row_scale[o]  (mp_tools.py:359-364). */
 int ddx_wprep_rowscale(const void* w, int32_t w_dtype, float* row_scale, const float* gain_ptr, float gain, int64_t rows,

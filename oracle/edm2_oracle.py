@@ -355,6 +355,24 @@ def unet_forward(sd: dict, cfg: dict, x_in: torch.Tensor, sigma: torch.Tensor, e
     return d_x
 
 
+def unet_train_loss(sd: dict, cfg: dict, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
+                    cond_mask: torch.Tensor, input_perturbation: Optional[torch.Tensor] = None, input_perturbation_scale: float = 0.0,
+                    freq_range: tuple[float, float] = (20.0, 16000.0)) -> torch.Tensor:
+    """Device part of training/module_trainers/unet_trainer.py:222-296 (`unet_train_batch`, train branch) with the random draws
+    given: get_embeddings :236, noised / perturbed input :249-259, UNet forward in training mode :261, loss weight and MSE
+    :271-276, Gaussian NLL with the learned per-sigma log-variance :280-282.  Returns the per-sample loss [B]."""
+    emb = unet_embeddings(sd, cfg, audio_embeddings, cond_mask, training=True)
+    s4 = sigma.float().view(-1, 1, 1, 1)
+    x_in = samples + noise * s4
+    pert = x_in + input_perturbation * s4 * input_perturbation_scale if input_perturbation is not None else None
+    denoised = unet_forward(sd, cfg, x_in, sigma, emb, freq_range, perturbed_input=pert, training=True)
+    sdata = cfg["sigma_data"]
+    w = (s4 ** 2 + sdata ** 2) / (s4 * sdata) ** 2
+    wl = (F.mse_loss(denoised, samples, reduction="none") * w).mean(dim=(1, 2, 3))
+    logvar = unet_sigma_logvar(sd, cfg, sigma).flatten()
+    return wl / logvar.exp() + logvar
+
+
 def unet_latent_shape(cfg: dict, shape: Sequence[int]) -> tuple:
     """unet_edm2_b4.py:240-242."""
     q = 2 ** (len(cfg["channel_mult"]) - 1)

@@ -193,3 +193,43 @@ def test_unet_training_forward_backward():
     bad = {k: (float(grads[k]), float(gref[k])) for k in gk if abs(float(grads[k]) - float(gref[k])) > 3e-2 * abs(float(gref[k])) + 1e-2 * gmax}
     print("gain gradients (hip, ref): " + ", ".join(f"{k.split('.')[-2]}.{k.split('.')[-1]} {float(grads[k]):+.3e}/{float(gref[k]):+.3e}" for k in gk[:8]))
     assert not bad, bad
+
+
+def test_unet_train_batch():
+    """One training batch (embeddings with conditioning dropout, noised + perturbed input, UNet forward/backward, EDM2 loss with
+    learned log-variance) against fp32 autograd through the oracle: loss per sample and the gradient of EVERY parameter."""
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.training.unet_grad import UNetTrainer
+    over = dict(model_channels=256, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=64, num_layers_per_block=1, in_channels_emb=64,
+                logvar_channels=32)
+    cfg = O.unet_cfg(**over)
+    sd = O.random_unet_state(cfg, seed=5, gain_value=0.5, normalized=False)
+    g = torch.Generator().manual_seed(23)
+    B, H, W = 2, 16, 32
+    samples = torch.randn(B, 4, H, W, generator=g)
+    noise, pert = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 4, H, W, generator=g)
+    sigma = torch.tensor([0.7, 5.0])
+    clap = torch.randn(B, 64, generator=g)
+    mask = torch.tensor([True, False])
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "fourier" not in k}
+    sd_ref = dict(sd); sd_ref.update(params)
+    loss_ref = O.unet_train_loss(sd_ref, cfg, samples, clap, sigma, noise, mask, pert, 1.0)
+    names = list(params)
+    gref = dict(zip(names, torch.autograd.grad(loss_ref.mean(), [params[k] for k in names])))
+    unet = UNet(UNetConfig(**over)).requires_grad_(False)
+    unet.load_state_dict(sd, strict=True)
+    unet = unet.to(device="cuda", dtype=torch.float32).train(True)
+    loss, grads = UNetTrainer(unet).train_batch(samples, clap, sigma, noise, mask, _Fmt(), pert, 1.0)
+    torch.cuda.synchronize()
+    e_loss = rel_l2(loss, loss_ref)
+    missing = [k for k in names if k not in grads]
+    assert not missing, f"parameters without a gradient: {missing}"
+    errs = {k: rel_l2(grads[k].reshape(gref[k].shape), gref[k]) for k in names}
+    worst = sorted(((k, v) for k, v in errs.items() if "gain" not in k), key=lambda kv: -kv[1])[:5]
+    print(f"train batch: loss {loss.tolist()} vs {loss_ref.tolist()} (rel {e_loss:.2e}); {len(names)} gradients, worst: " + ", ".join(f"{k} {v:.2e}" for k, v in worst))
+    assert e_loss < 1e-2
+    assert all(v < 3e-2 for k, v in errs.items() if "gain" not in k), {k: v for k, v in errs.items() if "gain" not in k and v >= 3e-2}
+    gk = [k for k in names if "gain" in k]
+    gmax = max(abs(float(gref[k])) for k in gk)
+    bad = {k: (float(grads[k]), float(gref[k])) for k in gk if abs(float(grads[k]) - float(gref[k])) > 3e-2 * abs(float(gref[k])) + 1e-2 * gmax}
+    assert not bad, bad
