@@ -233,3 +233,23 @@ def test_unet_train_batch():
     gmax = max(abs(float(gref[k])) for k in gk)
     bad = {k: (float(grads[k]), float(gref[k])) for k in gk if abs(float(grads[k]) - float(gref[k])) > 3e-2 * abs(float(gref[k])) + 1e-2 * gmax}
     assert not bad, bad
+
+
+def test_unet_train_batch_vs_reference_fixture():
+    """Same train batch against the REFERENCE's own loss and gradients (tests/golden/unet_train.safetensors)."""
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.training.unet_grad import UNetTrainer
+    from tests.util import load_golden
+    t, m = load_golden("unet_train")
+    cfg = O.unet_cfg(**m["cfg"])
+    sd = O.random_unet_state(cfg, seed=m["seed"], gain_value=m["gain_value"], normalized=False)
+    unet = UNet(UNetConfig(**m["cfg"])).requires_grad_(False)
+    unet.load_state_dict(sd, strict=True)
+    unet = unet.to(device="cuda", dtype=torch.float32).train(True)
+    loss, grads = UNetTrainer(unet).train_batch(t["samples"], t["clap"], t["sigma"], t["noise"], t["mask"].bool(), _Fmt(*m["freq_range"]), t["pert"],
+                                                m["input_perturbation"])
+    torch.cuda.synchronize()
+    assert rel_l2(loss, t["loss"]) < 1e-2
+    errs = {k: rel_l2(grads[k].reshape(t[f"grad.{k}"].shape), t[f"grad.{k}"]) for k in m["grads"]}
+    print("train batch vs reference fixture: loss rel %.2e; " % rel_l2(loss, t["loss"]) + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert all(v < (1e-1 if "gain" in k else 3e-2) for k, v in errs.items()), errs

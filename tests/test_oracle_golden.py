@@ -151,3 +151,19 @@ def test_mss_loss_golden():
         loss, grad = M.mss_loss_and_grad(t[f"{name}.sample"], t[f"{name}.target"], **kw)
         assert rel_l2(loss, t[f"{name}.loss"]) < 1e-6, name
         assert rel_l2(grad, t[f"{name}.grad"]) < 1e-5, name
+
+
+def test_unet_train_golden():
+    """Train-batch oracle (loss + parameter gradients by autograd) against the fixture produced by the reference UNet in train
+    mode with the loss lines of UNetTrainer.unet_train_batch."""
+    t, m = load_golden("unet_train")
+    cfg = O.unet_cfg(**m["cfg"])
+    sd = O.random_unet_state(cfg, seed=m["seed"], gain_value=m["gain_value"], normalized=False)
+    params = {k: sd[k].clone().requires_grad_(True) for k in m["grads"]}
+    sd_o = dict(sd); sd_o.update(params)
+    loss = O.unet_train_loss(sd_o, cfg, t["samples"], t["clap"], t["sigma"], t["noise"], t["mask"].bool(), t["pert"], m["input_perturbation"],
+                             tuple(m["freq_range"]))
+    assert rel_l2(loss, t["loss"]) < 1e-5
+    grads = torch.autograd.grad(loss.mean(), list(params.values()))
+    for k, g in zip(params, grads):
+        assert rel_l2(g, t[f"grad.{k}"]) < 1e-3, k

@@ -484,6 +484,58 @@ def gen_mss() -> None:
     save("mss_loss", t, meta)
 
 
+def gen_train() -> None:
+    """UNet train batch: the reference UNet (train mode, autograd) + the loss of UNetTrainer.unet_train_batch
+    (training/module_trainers/unet_trainer.py:236-282) evaluated on given random draws -> per-sample loss and parameter gradients."""
+    print("train")
+    cfg = O.unet_cfg(model_channels=256, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=64, num_layers_per_block=1,
+                     in_channels_emb=64, logvar_channels=32)
+    unet = make_ref_unet(cfg)
+    sd = O.random_unet_state(cfg, seed=5, gain_value=0.5, normalized=False)
+    unet.load_state_dict(sd)
+    unet.requires_grad_(True)
+    unet.train(True)
+    fmt = FakeFormat()
+    g = torch.Generator().manual_seed(23)
+    B, H, W = 2, 16, 32
+    samples = torch.randn(B, 4, H, W, generator=g)
+    noise, pert = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 4, H, W, generator=g)
+    sigma = torch.tensor([0.7, 5.0])
+    clap = torch.randn(B, 64, generator=g)
+    mask = torch.tensor([True, False])
+    # the lines of unet_train_batch, with the draws above in place of the device generator
+    emb = unet.get_embeddings(clap, mask)
+    s4 = sigma.view(-1, 1, 1, 1)
+    x_in = samples + noise * s4
+    perturbed = x_in + pert * s4 * 1.0
+    denoised = unet(x_in, sigma, fmt, emb, None, perturbed)
+    sdata = cfg["sigma_data"]
+    w = (s4 ** 2 + sdata ** 2) / (s4 * sdata) ** 2
+    wl = (torch.nn.functional.mse_loss(denoised, samples, reduction="none") * w).mean(dim=(1, 2, 3))
+    logvar = unet.get_sigma_loss_logvar(sigma=sigma)
+    loss = wl / logvar.exp().flatten() + logvar.flatten()
+    loss.mean().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in unet.named_parameters()}
+    # oracle on the same draws
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "fourier" not in k}
+    sd_o = dict(sd); sd_o.update(params)
+    loss_o = O.unet_train_loss(sd_o, cfg, samples, clap, sigma, noise, mask, pert, 1.0)
+    grads_o = dict(zip(params, torch.autograd.grad(loss_o.mean(), list(params.values()))))
+    check("train loss", loss_o.detach(), loss.detach(), 1e-5)
+    worst = max(rel_l2(grads_o[k], ref_grads[k]) for k in ref_grads)
+    print(f"    oracle vs reference  train gradients ({len(ref_grads)} parameters)  worst rel-L2 {worst:.2e}")
+    assert worst < 1e-3, worst
+    keep = ["enc.conv_in.weight", "enc.block1_down.conv_res0.weight", "enc.block1_layer0.attn_qk.weight", "dec.block1_in0.emb_linear_v.weight",
+            "dec.block1_layer1.conv_skip.weight", "dec.block0_layer0.conv_res1.weight", "dec.block0_up.emb_gain", "conv_out.weight", "out_gain",
+            "emb_noise.weight", "emb_label.weight", "emb_label_unconditional.weight", "logvar_linear.weight"]
+    t = {"samples": samples, "noise": noise, "pert": pert, "sigma": sigma, "clap": clap, "mask": mask.to(torch.uint8), "loss": loss.detach()}
+    for k in keep:
+        t[f"grad.{k}"] = ref_grads[k]
+    save("unet_train", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, seed=5, gain_value=0.5,
+                               input_perturbation=1.0, weights="oracle.random_unet_state(cfg, seed, gain_value, normalized=False)",
+                               grads=keep, freq_range=[20.0, 16000.0]))
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -494,7 +546,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
