@@ -64,6 +64,10 @@ class BgemmDesc(C.Structure):
                 ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32), ("c_fp32", C.c_int32), ("alpha", C.c_float)]
 
 
+class OptimJob(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_int64)]
+
+
 class MssDesc(C.Structure):
     _fields_ = [("sample", C.c_void_p), ("target", C.c_void_p), ("window", C.c_void_p), ("weight", C.c_void_p),
                 ("twiddle", C.c_void_p), ("loss", C.c_void_p), ("grad", C.c_void_p),
@@ -129,6 +133,9 @@ PROTOTYPES = {
     "ddx_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "ddx_edm2_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int64, C.c_void_p]),
+    "ddx_multi_grad_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "ddx_multi_adamw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int32, C.c_float, C.c_void_p]),
     "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -1,0 +1,79 @@
+// Optimizer step of the training loop as multi-tensor kernels over a device job table (one launch for all parameters):
+// global gradient norm, clipping, AdamW, EMA.  Replaces, for the UNet's ~100 parameter tensors (293 M values),
+// accelerator.clip_grad_norm_ + torch.optim.AdamW.step + the EMA lerp of reference src/training/trainer.py:1027-1063,456-474
+// (and ema.py) -- ~10 passes over 1.2 GB in the reference, 2 here (norm, update).  fp32 master weights and moments.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace ddx {
+namespace {
+
+constexpr int kChunk = 256 * 16;  // elements per workgroup pass
+
+__global__ __launch_bounds__(256) void multi_sqnorm_kernel(const ddx_optim_job* __restrict__ jobs, float* __restrict__ out) {
+  __shared__ float scratch[4];
+  const ddx_optim_job j = jobs[blockIdx.y];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (int64_t)gridDim.x * 256) {
+    const float g = j.g[i];
+    acc += g * g;
+  }
+  acc = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0 && acc != 0.f) atomicAdd(out, acc);
+}
+
+// clip coefficient exactly as torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)), norm of the SCALED grads
+__global__ void clip_coef_kernel(const float* __restrict__ sqnorm, float gscale, float max_norm, float* __restrict__ coef_norm) {
+  const float norm = sqrtf(sqnorm[0]) * gscale;
+  coef_norm[0] = fminf(1.0f, max_norm / (norm + 1e-6f));
+  coef_norm[1] = norm;
+}
+
+__global__ __launch_bounds__(256) void multi_adamw_kernel(const ddx_optim_job* __restrict__ jobs, const float* __restrict__ coef, float gscale, float lr,
+                                                          float beta1, float beta2, float eps, float weight_decay, float bias1, float bias2,
+                                                          float ema_beta) {
+  const ddx_optim_job j = jobs[blockIdx.y];
+  const float gs = gscale * (coef ? coef[0] : 1.0f);
+  const float step = lr / bias1;
+  const float inv_sqrt_bias2 = rsqrtf(bias2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (int64_t)gridDim.x * 256) {
+    const float g = j.g[i] * gs;
+    float p = j.p[i];
+    const float m = beta1 * j.m[i] + (1.0f - beta1) * g;
+    const float v = beta2 * j.v[i] + (1.0f - beta2) * g * g;
+    p -= lr * weight_decay * p;                                        // decoupled weight decay (torch.optim.AdamW)
+    p -= step * m / (sqrtf(v) * inv_sqrt_bias2 + eps);
+    j.m[i] = m; j.v[i] = v; j.p[i] = p;
+    if (j.ema) j.ema[i] = ema_beta * j.ema[i] + (1.0f - ema_beta) * p;  // torch.lerp(ema, p, 1 - beta)
+  }
+}
+
+}  // namespace
+}  // namespace ddx
+
+using namespace ddx;
+
+extern "C" int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float grad_scale, float max_norm,
+                                   float* workspace3, ddx_stream stream) {
+  if (!jobs_dev || njobs <= 0 || max_n <= 0 || !workspace3) return set_error(DDX_ERR_ARG, "multi_grad_norm: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    if (hipMemsetAsync(workspace3, 0, sizeof(float), s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "multi_grad_norm: memset");
+    dim3 grid((unsigned)std::min<int64_t>((max_n + kChunk - 1) / kChunk, 256), (unsigned)njobs);
+    hipLaunchKernelGGL(multi_sqnorm_kernel, grid, dim3(256), 0, s, jobs_dev, workspace3);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, (const float*)workspace3, grad_scale, max_norm, workspace3 + 1);
+    return check_launch("multi_grad_norm");
+  }, stream, "grad_norm");
+}
+
+extern "C" int ddx_multi_adamw(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, const float* clip_coef, float grad_scale, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float ema_beta, ddx_stream stream) {
+  if (!jobs_dev || njobs <= 0 || max_n <= 0 || step <= 0) return set_error(DDX_ERR_ARG, "multi_adamw: bad args");
+  const float bias1 = 1.0f - std::pow(beta1, (float)step), bias2 = 1.0f - std::pow(beta2, (float)step);
+  return dispatch([=](hipStream_t s) -> int {
+    dim3 grid((unsigned)std::min<int64_t>((max_n + kChunk - 1) / kChunk, 256), (unsigned)njobs);
+    hipLaunchKernelGGL(multi_adamw_kernel, grid, dim3(256), 0, s, jobs_dev, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, bias1, bias2,
+                       ema_beta);
+    return check_launch("multi_adamw");
+  }, stream, "adamw");
+}

@@ -360,6 +360,29 @@ typedef struct {
 int ddx_mss_loss_scale(const ddx_mss_desc* d, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer step (training/trainer.py:1027-1063 clip_grad_norm_ + optimizer.step, :456-474 torch.optim.AdamW, EMA lerp) as
+ * multi-tensor kernels over a DEVICE table of jobs, one job per parameter tensor (fp32 master weights / moments):
+ *   ddx_multi_grad_norm: workspace3[0] = sum g^2, [1] = clip coefficient min(1, max_norm / (norm + 1e-6)), [2] = norm,
+ *                        norm taken of grad_scale * g  (grad_scale = loss_scale / world_size after a SUM all-reduce)
+ *   ddx_multi_adamw    : g' = g * grad_scale * (clip_coef ? *clip_coef : 1); decoupled weight decay; bias-corrected AdamW
+ *                        (step = 1-based step count); ema (if non-NULL) <- lerp(ema, p, 1 - ema_beta).
+ * max_n = largest job size (grid sizing).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  float* ema;   /* or NULL */
+  int64_t n;
+} ddx_optim_job;
+
+int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float grad_scale, float max_norm,
+                        float* workspace3, ddx_stream stream);
+int ddx_multi_adamw(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, const float* clip_coef, float grad_scale, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float ema_beta, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Launch plans: a recorded sequence of the calls above, replayed with one FFI call and optionally
  * as a hipGraph (the MI355X replacement for the reference's torch.compile, modules/module.py:145-149).
  * Recording: between ddx_plan_begin() and ddx_plan_end() every entry point above is recorded into

@@ -38,6 +38,16 @@ def _worker(rank: int, ws: int, port: int, out_dir: str):
     sig = torch.arange(2, dtype=torch.float32) + 100 * rank
     gl, gs = D.gather_scalars([loss, sig])
     assert gl.tolist() == [0.0, 1.0, 10.0, 11.0] and gs.tolist() == [0.0, 1.0, 100.0, 101.0]
+    # data-parallel gradient exchange: one flat bucket, SUM over ranks; the optimizer then scales by loss_scale / world_size
+    from dualdiffusion_amd.training.train_step import allreduce_gradients
+    from dualdiffusion_amd.training.optimizer import LRScheduleConfig, lr_multiplier
+    grads = {"w": torch.full((3, 2), float(rank + 1)), "gain": torch.tensor(10.0 * (rank + 1)), "b": torch.arange(4.0) * (rank + 1)}
+    red = allreduce_gradients(grads)
+    assert torch.equal(red["w"], torch.full((3, 2), 3.0)) and float(red["gain"]) == 30.0 and torch.equal(red["b"], torch.arange(4.0) * 3)
+    assert red["w"].shape == (3, 2) and red["gain"].shape == ()
+    # every rank derives the same learning rate from the global step (host schedule, reference trainer.py:653-663)
+    c = LRScheduleConfig()
+    assert lr_multiplier(c, 2500) == 0.5 and lr_multiplier(c, 70000) == 1.0 and abs(lr_multiplier(c, 280000) - 0.5) < 1e-12
     D.barrier()
     dist.destroy_process_group()
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
