@@ -261,7 +261,7 @@ extern "C" int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* 
   if (C % ev || da_ld % ev || (add && add_ld % ev)) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C and the row strides must be multiples of the 16-byte vector");
   if (dc && !chan_scale) return set_error(DDX_ERR_ARG, "silu_scale_bwd: dc without chan_scale");
   return dispatch([=](hipStream_t s) -> int {
-    const int rows_per_block = 256;
+    const int rows_per_block = 32;  // many small blocks: the kernel is a pure HBM stream and needs the parallelism; dc costs C atomics per block
     dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)((C / ev + 255) / 256));
     if (dtype == DDX_BF16)
       hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (int)da_ld, (const bf16*)y, chan_scale, scale,

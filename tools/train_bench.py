@@ -1,0 +1,63 @@
+"""Timing of one UNet training step (train batch + optimizer) of the default UNet on the HIP kernels (GPU box only).
+
+    python tools/train_bench.py [B] [steps]
+Eager host orchestration (dualdiffusion_amd/training): an upper bound, the launch-plan / hipGraph form is future work.
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale  # noqa: E402
+from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig  # noqa: E402
+from dualdiffusion_amd.training.optimizer import LRScheduleConfig, OptimizerConfig  # noqa: E402
+from dualdiffusion_amd.training.train_step import UNetTrainStep  # noqa: E402
+
+
+class Fmt:
+    ms_freq_scale = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    torch.manual_seed(0)
+    unet = UNet(UNetConfig()).requires_grad_(False).to(device="cuda", dtype=torch.float32).train(True)
+    unet.normalize_weights()
+    for n, p in unet.named_parameters():
+        if p.ndim == 0:
+            p.data.fill_(0.7)
+    ts = UNetTrainStep(unet, Fmt(), OptimizerConfig(), LRScheduleConfig())
+    ts.global_step = 100
+    H, W = 32, 688
+    g = torch.Generator(device="cuda").manual_seed(1)
+    samples = torch.randn(B, 4, H, W, device="cuda", generator=g)
+    noise = torch.randn(B, 4, H, W, device="cuda", generator=g)
+    sigma = torch.exp(torch.randn(B, device="cuda", generator=g) * 1.2 - 0.4)
+    clap = torch.randn(B, 512, device="cuda", generator=g)
+    mask = torch.ones(B, dtype=torch.bool, device="cuda")
+    out = ts.step(samples, clap, sigma, noise, mask)       # warm-up (kernel attributes, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ts.step(samples, clap, sigma, noise, mask)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    # phases
+    tr = ts.trainer
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    loss, grads = tr.train_batch(samples, clap, sigma, noise, mask, Fmt())
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    ts.opt.step({k: grads[k] for k in ts.params}, 1e-4, 250.0)
+    unet.normalize_weights()
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    fl = 3 * 489.3e9 * B
+    print(f"UNet train step B={B} (4,{H},{W}) bf16 compute / fp32 master: {dt * 1e3:.1f} ms/step = {B / dt:.1f} samples/s, "
+          f"{fl / dt / 1e12:.0f} TFLOP/s (3 x forward FLOPs); train batch {1e3 * (t2 - t1):.1f} ms, optimizer + weight norm {1e3 * (t3 - t2):.1f} ms; "
+          f"loss {float(out['loss'].mean()):.4f} grad_norm {out['grad_norm']:.2f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
+if __name__ == "__main__":
+    main()
