@@ -18,7 +18,12 @@ $(LIB): $(OBJS)
 	@mkdir -p $(dir $(LIB))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# one-off hardware probes quoted in DESIGN.md (run on the GPU box)
+probes: tools/probe/bufload_lds_probe tools/probe/ds_read_tr_probe
+tools/probe/%: tools/probe/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
+
 clean:
 	rm -rf build $(LIB)
 
-.PHONY: all clean
+.PHONY: all clean probes
