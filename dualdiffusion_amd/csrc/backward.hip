@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict
   const int b = blockIdx.y;
   const int rsub = threadIdx.x / nvec, rstep = 256 / nvec;
   const int v = vbase + threadIdx.x % nvec;
-  if (rsub >= rstep) return;  // (256 not a multiple of nvec: idle tail threads)
+  const bool idle = rsub >= rstep;  // (256 not a multiple of nvec: idle tail threads; they still reach the barrier below)
   float cv[EV], acc[EV];
 #pragma unroll
   for (int e = 0; e < EV; ++e) { cv[e] = (cs ? cs[(size_t)b * C + v * EV + e] : 1.0f) * scale; acc[e] = 0.f; }
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+  const int r0 = blockIdx.x * rows_per_block, r1 = idle ? 0 : min(r0 + rows_per_block, HW);
   for (int r = r0 + rsub; r < r1; r += rstep) {
     const size_t row = (size_t)b * HW + r;
     const size_t o = row * C + (size_t)v * EV;
@@ -51,8 +51,20 @@ __global__ __launch_bounds__(256) void silu_scale_bwd_kernel(const T* __restrict
     *reinterpret_cast<decltype(g.v)*>(dy + o) = out.v;
   }
   if (dc) {
+    // one atomic per (block, channel): the row groups of the block are summed through LDS first (the [B][C] targets are few,
+    // so every atomic that is not issued is contention saved)
+    __shared__ float red[256 * 8];
 #pragma unroll
-    for (int e = 0; e < EV; ++e) atomicAdd(dc + (size_t)b * C + v * EV + e, acc[e] * scale);
+    for (int e = 0; e < EV; ++e) red[threadIdx.x * EV + e] = acc[e];
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+      for (int e = 0; e < EV; ++e) {
+        float sum = 0.f;
+        for (int r = 0; r < rstep; ++r) sum += red[(r * nvec + (v - vbase)) * EV + e];
+        atomicAdd(dc + (size_t)b * C + v * EV + e, sum * scale);
+      }
+    }
   }
 }
 
@@ -201,17 +213,31 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __re
                                                                int M, int O, int Kg, int groups, int x_stride) {
   const int o = blockIdx.x;
   const int g = o / (O / groups);
-  const float rs = row_scale[o];
   for (int k = threadIdx.x; k < Kg; k += 256) {
-    const float wv = to_f32<TW_>(w[(size_t)o * Kg + k]) * rs;
     float acc = 0.f;
     for (int m = 0; m < M; ++m) {
       const float d = dc[(size_t)m * O + o];
       acc += d * x[(size_t)m * x_stride + g * Kg + k];
-      if (dx) atomicAdd(dx + (size_t)m * x_stride + g * Kg + k, d * wv);
     }
     dwp[(size_t)o * Kg + k] = acc;
   }
+}
+
+// input gradient of the same layer: one thread per (m, input column, slice of the group's output rows)
+// (consecutive threads read consecutive weights of a row)
+template <typename TW_>
+__global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* __restrict__ dc, const TW_* __restrict__ w, const float* __restrict__ row_scale,
+                                                                  float* __restrict__ dx, int M, int O, int Kg, int groups, int x_stride) {
+  const int kk = blockIdx.x * 256 + threadIdx.x;  // column of x
+  const int m = blockIdx.y;
+  if (kk >= Kg * groups) return;
+  const int g = kk / Kg, k = kk - g * Kg, Og = O / groups;
+  // the group's output rows are split over blockIdx.z: 16 partial sums per element meet in one atomic each
+  const int per = (Og + gridDim.z - 1) / gridDim.z;
+  const int o0 = g * Og + blockIdx.z * per, o1 = min(o0 + per, (g + 1) * Og);
+  float acc = 0.f;
+  for (int o = o0; o < o1; ++o) acc += dc[(size_t)m * O + o] * row_scale[o] * to_f32<TW_>(w[(size_t)o * Kg + k]);
+  atomicAdd(dx + (size_t)m * x_stride + kk, acc);
 }
 
 // EDM2 training loss (reference training/module_trainers/unet_trainer.py:271-282): per sample
@@ -261,7 +287,7 @@ extern "C" int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* 
   if (C % ev || da_ld % ev || (add && add_ld % ev)) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C and the row strides must be multiples of the 16-byte vector");
   if (dc && !chan_scale) return set_error(DDX_ERR_ARG, "silu_scale_bwd: dc without chan_scale");
   return dispatch([=](hipStream_t s) -> int {
-    const int rows_per_block = 32;  // many small blocks: the kernel is a pure HBM stream and needs the parallelism; dc costs C atomics per block
+    const int rows_per_block = 128;
     dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)((C / ev + 255) / 256));
     if (dtype == DDX_BF16)
       hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (int)da_ld, (const bf16*)y, chan_scale, scale,
@@ -345,10 +371,14 @@ extern "C" int ddx_linear_small_bwd(const float* dc, const float* x, int32_t x_s
   if (!dc || !x || !w || !row_scale || !dwp || M <= 0 || O <= 0 || K <= 0 || groups <= 0 || O % groups || K % groups)
     return set_error(DDX_ERR_ARG, "linear_small_bwd: bad args");
   return dispatch([=](hipStream_t s) -> int {
-    if (w_dtype == DDX_F32)
+    dim3 gdx((K + 255) / 256, M, 16);
+    if (w_dtype == DDX_F32) {
       hipLaunchKernelGGL(linear_small_bwd_kernel<float>, dim3(O), dim3(256), 0, s, dc, x, (const float*)w, row_scale, dwp, dx, M, O, K / groups, groups, x_stride);
-    else
+      if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel<float>, gdx, dim3(256), 0, s, dc, (const float*)w, row_scale, dx, M, O, K / groups, groups, x_stride);
+    } else {
       hipLaunchKernelGGL(linear_small_bwd_kernel<bf16>, dim3(O), dim3(256), 0, s, dc, x, (const bf16*)w, row_scale, dwp, dx, M, O, K / groups, groups, x_stride);
+      if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel<bf16>, gdx, dim3(256), 0, s, dc, (const bf16*)w, row_scale, dx, M, O, K / groups, groups, x_stride);
+    }
     return check_launch("linear_small_bwd");
   }, stream, "linear_small_bwd");
 }
