@@ -18,6 +18,7 @@ DDX_F32, DDX_BF16 = 0, 1
 RESAMPLE_KEEP, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
 RESAMPLE_UP_BWD, RESAMPLE_DOWN_BWD = 3, 4
 PRO_NONE, PRO_SILU, PRO_SCALE, PRO_SCALE_SILU = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT_W = 0, 1
 EPI_STORE, EPI_MPSUM = 0, 1
 
 
@@ -41,7 +42,8 @@ class ConvDesc(C.Structure):
                 ("CK", C.c_int32), ("resample", C.c_int32), ("prologue", C.c_int32), ("epilogue", C.c_int32),
                 ("scale0", C.c_float), ("scale1", C.c_float), ("res_t", C.c_float), ("clip", C.c_float),
                 ("dtype", C.c_int32), ("force_direct", C.c_int32),
-                ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float)]
+                ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float),
+                ("pad_mode", C.c_int32)]
 
 
 class MelStftDesc(C.Structure):

@@ -217,6 +217,8 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;
   p.clip = d.clip;
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
+  p.reflect_w = d.pad_mode == DDX_PAD_REFLECT_W ? 1 : 0;
+  if (p.reflect_w && (d.W < 2 || d.resample != DDX_RESAMPLE_KEEP)) return set_error(DDX_ERR_UNSUPPORTED, "conv: reflect padding needs W >= 2 and no fused resample");
   const int ks = d.ksize, dt = d.dtype;
   // d.force_direct selects the kernel: 0 = automatic, 1 = scalar reference kernel, 2 = register-staged MFMA kernel,
   // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
     const int g = o / p.Ng, n = o - g * p.Ng;
     float acc = 0.f;
     for (int tap = 0; tap < taps; ++tap) {
-      const int ih = h + tap / KS - pad, iw = w + tap % KS - pad;
+      const int ih = h + tap / KS - pad;
+      int iw = w + tap % KS - pad;
+      if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W ? 2 * (p.W - 1) - iw : iw);
       if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) continue;
       for (int c = 0; c < p.Cg; ++c) {
         const int cabs = g * p.Cg + c;

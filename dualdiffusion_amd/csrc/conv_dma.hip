@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     isrc = -1;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int ih = it.h0 + ahh[i], iw = it.w0 + aww[i];
+      const int ih = it.h0 + ahh[i];
+      int iw = it.w0 + aww[i];
+      if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W && iw < p.W + PAD ? 2 * (p.W - 1) - iw : iw);  // only the true border mirrors
       const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
       const int pix = p.resample == DDX_RESAMPLE_UP ? (it.b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (it.b * p.sH + ih) * p.sW + iw;
       apix[i] = ok ? pix : -1;

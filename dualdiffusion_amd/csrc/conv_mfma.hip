@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     const int r = r0 + i * RPP;
     const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
     const int ww = r - hh * TWP;
-    const int ih = h0 - PAD + hh, iw = w0 - PAD + ww;
+    const int ih = h0 - PAD + hh;
+    int iw = w0 - PAD + ww;
+    if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W && iw < p.W + PAD ? 2 * (p.W - 1) - iw : iw);  // only the true border mirrors
     const bool ok = r < R && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
     int pix;
     if (DN) pix = (b * p.sH + 2 * ih) * p.sW + 2 * iw;

@@ -24,6 +24,7 @@ struct ConvParams {
   void* out2;           // activated twin of the output (or null)
   int out_act;
   float out2_scale;
+  int reflect_w;        // columns outside the image are mirrored (ReflectionPad on W) instead of zero
   // spatial tiling (MFMA kernel)
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;

@@ -86,6 +86,7 @@ enum { DDX_RESAMPLE_KEEP = 0, DDX_RESAMPLE_UP = 1, DDX_RESAMPLE_DOWN = 2,
        DDX_RESAMPLE_UP_BWD = 3, DDX_RESAMPLE_DOWN_BWD = 4 };
 enum { DDX_PRO_NONE = 0, DDX_PRO_SILU = 1, DDX_PRO_SCALE = 2, DDX_PRO_SCALE_SILU = 3 };
 enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1 };
+enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1 };
 
 typedef struct {
   const void* src0;         /* NHWC [B][sH][sW][C0] */
@@ -112,6 +113,9 @@ typedef struct {
   void* out2;               /* NHWC [B][H][W][Cout] or NULL */
   int32_t out_act;
   float out2_scale;
+  /* DDX_PAD_ZERO (F.conv2d padding) | DDX_PAD_REFLECT_W: zero rows above / below, mirrored columns left / right -- the
+   * ReflectionPad3d((k/2, k/2, 0, 0, ...)) + conv3d(padding=(0, k/2, 0)) of MPConv3D (modules/daes/dae_edm2_d3.py:62-84). */
+  int32_t pad_mode;
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);

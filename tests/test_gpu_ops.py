@@ -480,3 +480,25 @@ def test_wprep_backward():
         dw = ops.wprep_bwd(pw, dwp.cuda(), dgain=dgain)
         assert rel_l2(dw, dw_ref) < 2e-5, (Cout, rel_l2(dw, dw_ref))
         assert abs(float(dgain) - float(dgain_ref)) < 2e-5 * max(1.0, abs(float(dgain_ref)))
+
+
+@pytest.mark.parametrize("path,dtype", [("direct", torch.float32), ("mfma", torch.float32), ("mfma", torch.bfloat16), ("dma", torch.bfloat16)])
+def test_conv_reflect_w_padding(path, dtype):
+    """pad_mode = REFLECT_W (MPConv3D: ReflectionPad on W, zero padding on H) on every conv kernel, ragged tile widths included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    B, H, W, Cin, Cout = 2, 9, 45, 32, 64
+    x = _round(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
+    wp_ref = O.prepared_weight(w)
+    if dtype == torch.bfloat16:
+        wp_ref = _round(wp_ref, dtype)
+    xp = torch.nn.functional.pad(x, (1, 1, 0, 0), mode="reflect")
+    ref = torch.nn.functional.conv2d(xp, wp_ref, padding=(1, 0))
+    pw = ops.wprep(w.cuda(), 1, dtype)
+    out = ops.conv2d(to_nhwc(x, dtype), pw, reflect_w=True, path=path)
+    torch.cuda.synchronize()
+    e = rel_l2(to_nchw(out), ref)
+    assert e < TOL[dtype], (path, e)
+    # and it differs from zero padding (the test is not vacuous)
+    assert rel_l2(to_nchw(ops.conv2d(to_nhwc(x, dtype), pw, path=path)), ref) > 1e-2
