@@ -1,0 +1,279 @@
+"""MCLT diffusion-decoder UNet on the MI355X kernels (drop-in for the reference's `DDec_MCLT_UNet_B1`).
+
+Mirrors reference src/modules/unets/unet_edm2_ddec_mclt_b1.py:46-326 and `MPConv3D` (modules/daes/dae_edm2_d3.py:43-93):
+same config dataclass, constructor `(config)`, state-dict keys (5-D conv weights) and forward signature.  The reference
+keeps the stereo pair on a depth axis of 5-D tensors and convolves with (1,3,3) / (2,1,1) / (2,3,3) kernels; here the
+depth axis is folded into the image batch (image n = 2*b + z, NHWC) and every layer runs on the 2-D conv kernels:
+  * (1,3,3): the same 3x3 conv on both depth slices, with mirrored columns (`pad_mode = REFLECT_W`) and zero rows;
+  * (2,1,1) / (2,3,3): out[z] = W[0] x[z] + W[1] x[1-z] (the reflected depth row behind a 2-deep tensor is the other channel)
+    = ONE two-source conv over [x | x with the stereo pair swapped] with the weights [W[..,0] | W[..,1]].
+First version of this row: eager launches; input assembly, mp_cat materialisation, the pair swap and the final 1-channel
+combine are torch layout glue on the host side of the boundary (the conv operand traffic they add is noted in DESIGN.md).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional, Union
+
+import torch
+
+from ... import ops
+from ..._lib import DDXError, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_UP
+from ...engine import mp_cat_weights
+from .unet import DualDiffusionUNet, DualDiffusionUNetConfig
+
+
+@dataclass
+class DDec_MCLT_UNet_B1_Config(DualDiffusionUNetConfig):
+    in_channels: int = 1
+    out_channels: int = 1
+    in_channels_emb: int = 0
+    in_num_freqs: int = 256
+    in_psd_freqs: int = 4096
+    model_channels: int = 32
+    logvar_channels: int = 128
+    channel_mult: tuple = (1, 2, 3, 4)
+    double_midblock: bool = True
+    midblock_attn: bool = False
+    channel_mult_noise: Optional[int] = 4
+    channel_mult_emb: Optional[int] = 4
+    channels_per_head: int = 64
+    num_layers_per_block: int = 3
+    label_balance: float = 0.5
+    concat_balance: float = 0.5
+    res_balance: float = 0.3
+    attn_balance: float = 0.3
+    attn_levels: tuple = ()
+    mlp_multiplier: int = 1
+    mlp_groups: int = 1
+    emb_linear_groups: int = 1
+    add_constant_channel: bool = True
+
+
+class MPConv3DWeight(torch.nn.Module):
+    """Parameter holder of one MPConv3D (dae_edm2_d3.py:45-60): key `weight`, init randn."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel: tuple, groups: int = 1, disable_weight_norm: bool = False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.groups, self.kernel = in_channels, out_channels, groups, tuple(kernel)
+        self.disable_weight_norm = disable_weight_norm
+        self.weight = torch.nn.Parameter(torch.randn(out_channels, in_channels // groups, *kernel))
+
+
+class DDecBlockWeights(torch.nn.Module):
+    """Parameters of one block (unet_edm2_ddec_mclt_b1.py:75-125, attention not built)."""
+
+    def __init__(self, in_channels: int, out_channels: int, emb_channels: int, flavor: str, resample_mode: str, cfg: DDec_MCLT_UNet_B1_Config):
+        super().__init__()
+        self.in_channels, self.out_channels, self.flavor, self.resample_mode = in_channels, out_channels, flavor, resample_mode
+        mm, g = cfg.mlp_multiplier, cfg.mlp_groups
+        self.conv_res0 = MPConv3DWeight(out_channels if flavor == "enc" else in_channels, out_channels * mm, (1, 3, 3), groups=g)
+        self.conv_res1 = MPConv3DWeight(out_channels * mm, out_channels, (1, 3, 3), groups=g)
+        self.conv_skip = MPConv3DWeight(in_channels, out_channels, (2, 1, 1))
+        self.emb_gain = torch.nn.Parameter(torch.zeros([]))
+        self.emb_linear = MPConv3DWeight(emb_channels, out_channels * mm, (1, 1, 1), groups=cfg.emb_linear_groups)
+
+
+class DDec_MCLT_UNet_B1(DualDiffusionUNet):
+
+    config_class = DDec_MCLT_UNet_B1_Config
+    supports_channels_last = "3d"
+
+    def __init__(self, config: DDec_MCLT_UNet_B1_Config) -> None:
+        super().__init__()
+        self.config = config
+        if len(config.attn_levels) > 0 or config.midblock_attn or config.in_channels_emb > 0:
+            raise NotImplementedError("DDec_MCLT_UNet_B1: attention levels / label embeddings are not built (default config has neither)")
+        if config.in_channels != 1 or config.out_channels != 1:
+            raise NotImplementedError("DDec_MCLT_UNet_B1: one channel per stereo slice (the default config)")
+        cblock = [config.model_channels * m for m in config.channel_mult]
+        cnoise = config.model_channels * config.channel_mult_noise if config.channel_mult_noise is not None else max(cblock)
+        cemb = (config.model_channels * config.channel_mult_emb if config.channel_mult_emb is not None else max(cblock)) * config.mlp_multiplier
+        self.num_levels, self.cnoise, self.cemb = len(cblock), cnoise, cemb
+        assert config.in_psd_freqs % config.in_num_freqs == 0
+        self.psd_freqs_per_freq = config.in_psd_freqs // config.in_num_freqs
+        from .unet_edm2_b4 import FourierTable
+        self.emb_fourier = FourierTable(cnoise)
+        self.emb_noise = MPConv3DWeight(cnoise, cemb, ())
+        self.logvar_fourier = FourierTable(config.logvar_channels)
+        self.logvar_linear = MPConv3DWeight(config.logvar_channels, 1, (), disable_weight_norm=True)
+        self.enc = torch.nn.ModuleDict()
+        cout = config.in_channels + self.psd_freqs_per_freq + int(config.add_constant_channel)
+        for level, ch in enumerate(cblock):
+            if level == 0:
+                self.enc["conv_in"] = MPConv3DWeight(cout, ch, (2, 3, 3))
+                cout = ch
+            else:
+                self.enc[f"block{level}_down"] = DDecBlockWeights(cout, cout, cemb, "enc", "down", config)
+            for i in range(config.num_layers_per_block):
+                self.enc[f"block{level}_layer{i}"] = DDecBlockWeights(cout, ch, cemb, "enc", "keep", config)
+                cout = ch
+        skips = [m.out_channels for m in self.enc.values()]
+        self.dec = torch.nn.ModuleDict()
+        for level, ch in reversed(list(enumerate(cblock))):
+            if level == len(cblock) - 1:
+                self.dec[f"block{level}_in0"] = DDecBlockWeights(cout, cout, cemb, "dec", "keep", config)
+                if config.double_midblock:
+                    self.dec[f"block{level}_in1"] = DDecBlockWeights(cout, cout, cemb, "dec", "keep", config)
+            else:
+                self.dec[f"block{level}_up"] = DDecBlockWeights(cout, cout, cemb, "dec", "up", config)
+            for i in range(config.num_layers_per_block + 1):
+                self.dec[f"block{level}_layer{i}"] = DDecBlockWeights(cout + skips.pop(), ch, cemb, "dec", "keep", config)
+                cout = ch
+        self.out_gain = torch.nn.Parameter(torch.zeros([]))
+        self.conv_out = MPConv3DWeight(cout, config.out_channels, (2, 3, 3))
+        self._prepared: dict = {}
+        self._prepared_key = None
+
+    # ------------------------------------------------------------------ reference API
+    def _on_placement_change(self) -> None:
+        self._prepared, self._prepared_key = {}, None
+
+    def get_embeddings(self, emb_in, conditioning_mask):
+        return None     # in_channels_emb == 0 (unet_edm2_ddec_mclt_b1.py:256-262)
+
+    @torch.no_grad()
+    def get_sigma_loss_logvar(self, sigma: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._require_device()
+        dev = self.device
+        s = sigma.flatten().to(device=dev, dtype=torch.float32).contiguous()
+        f = torch.empty(s.numel(), self.config.logvar_channels, device=dev, dtype=torch.float32)
+        ops.mpfourier(s, self.logvar_fourier.freqs.float(), self.logvar_fourier.phases.float(), f, True)
+        out = torch.empty(s.numel(), 1, device=dev, dtype=torch.float32)
+        w = self.logvar_linear.weight
+        ops.linear_small(ops.make_linear_jobs([(w, None, out, 1.0, 0.0, 1, False)], dev), 1, 1, f, s.numel(), w.dtype)
+        torch.cuda.current_stream().synchronize()
+        return out.view(-1, 1, 1, 1)
+
+    def get_latent_shape(self, latent_shape: Union[torch.Size, tuple]) -> torch.Size:
+        q = 2 ** (self.num_levels - 1)
+        return torch.Size(tuple(latent_shape[0:2]) + ((latent_shape[2] // q) * q, (latent_shape[3] // q) * q))
+
+    def _require_device(self) -> None:
+        if self.device.type != "cuda":
+            raise DDXError("DDec_MCLT_UNet_B1 is not on a ROCm device: dualdiffusion_amd runs only on its HIP kernels (no CPU fallback)")
+
+    # ------------------------------------------------------------------ weight preparation (once per weight version)
+    def _prep(self) -> dict:
+        key = tuple(p._version for p in self.parameters()) + (self.dtype,)
+        if key == self._prepared_key:
+            return self._prepared
+        dt, G = self.dtype, self.config.mlp_groups
+        P: dict = {}
+
+        def pair(w5: torch.Tensor, cpad: int = 0) -> torch.Tensor:
+            """[Cout, Cin, 2, k, k] -> [Cout, 2*(Cin+pad), k, k]: depth tap 0 on the image itself, tap 1 on the swapped pair."""
+            a, b = w5[:, :, 0], w5[:, :, 1]
+            if cpad:
+                z = torch.zeros(a.shape[0], cpad, *a.shape[2:], dtype=a.dtype, device=a.device)
+                a, b = torch.cat([a, z], 1), torch.cat([b, z], 1)
+            return torch.cat([a, b], dim=1).contiguous()
+
+        w_in = self.enc["conv_in"].weight.data
+        cin = w_in.shape[1]
+        self._cin_pad = (cin + 7) // 8 * 8
+        w2 = pair(w_in, self._cin_pad - cin)
+        # weight scaling is gain / sqrt(fan_in of the 5-D kernel); the zero padding columns must not count
+        P["conv_in"] = ops.wprep(w2, 1, dt, gain=math.sqrt(w2[0].numel() / w_in[0].numel()))
+        for side in ("enc", "dec"):
+            for name, blk in getattr(self, side).items():
+                if name == "conv_in":
+                    continue
+                pre = f"{side}.{name}"
+                P[pre + ".res0"] = ops.wprep(blk.conv_res0.weight.data[:, :, 0].contiguous(), G, dt)
+                P[pre + ".res1"] = ops.wprep(blk.conv_res1.weight.data[:, :, 0].contiguous(), G, dt)
+                P[pre + ".skip"] = ops.wprep(pair(blk.conv_skip.weight.data), 1, dt)
+        w_out = self.conv_out.weight.data
+        w8 = torch.zeros(8, *w_out.shape[1:], dtype=w_out.dtype, device=w_out.device)   # 1 output channel -> one 16-byte NHWC vector
+        w8[:w_out.shape[0]] = w_out
+        self._out_gain = self.out_gain.data.float().reshape(1)
+        P["conv_out"] = ops.wprep(pair(w8), 1, dt, gain_ptr=self._out_gain)
+        self._prepared, self._prepared_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _swap(x: torch.Tensor) -> torch.Tensor:
+        """Images are ordered n = 2*b + z: exchange the stereo pair (the reflected depth row of MPConv3D)."""
+        N = x.shape[0]
+        return x.view(N // 2, 2, *x.shape[1:]).flip(1).reshape(x.shape).contiguous()
+
+    def _block(self, P: dict, pre: str, blk: DDecBlockWeights, x: torch.Tensor, emb2: torch.Tensor) -> torch.Tensor:
+        cfg = self.config
+        if blk.resample_mode != "keep":
+            N, H, W, Cn = x.shape
+            out = torch.empty((N, H * 2, W * 2, Cn) if blk.resample_mode == "up" else (N, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device)
+            x = ops.resample2d(x, out, RESAMPLE_UP if blk.resample_mode == "up" else RESAMPLE_DOWN)
+        N = x.shape[0]
+        Cmid = blk.conv_res0.out_channels
+        c = torch.empty(N, Cmid, dtype=torch.float32, device=x.device)
+        w_e = blk.emb_linear.weight
+        table = ops.make_linear_jobs([(w_e, self._gain32[pre], c, 1.0, 1.0, cfg.emb_linear_groups, False)], x.device)
+        ops.linear_small(table, 1, Cmid, emb2, N, w_e.dtype)
+        self._keep.append(table)
+        if blk.flavor == "enc":
+            x = ops.pixelnorm(ops.conv2d(x, P[pre + ".skip"], src1=self._swap(x)))
+        y = ops.conv2d(x, P[pre + ".res0"], prologue=PRO_SILU, reflect_w=True)
+        if blk.flavor == "dec":
+            x = ops.conv2d(x, P[pre + ".skip"], src1=self._swap(x))
+        return ops.conv2d(y, P[pre + ".res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=x, res_t=cfg.res_balance, clip=256.0, reflect_w=True)
+
+    @torch.no_grad()
+    def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: Optional[torch.Tensor] = None,
+                x_ref: Optional[torch.Tensor] = None, perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """reference unet_edm2_ddec_mclt_b1.py:275-326.  x_in [B, 2, H, W], x_ref [B, 2, in_psd_freqs, W] -> float32 [B, 2, H, W]."""
+        self._require_device()
+        cfg, dev, dt = self.config, self.device, self.dtype
+        if x_ref is None:
+            raise DDXError("DDec_MCLT_UNet_B1.forward needs x_ref (the un-mel'd PSD conditioning)")
+        B, _, H, W = x_in.shape
+        if H != cfg.in_num_freqs:
+            raise DDXError(f"x_in has {H} frequency rows, the config says in_num_freqs = {cfg.in_num_freqs}")
+        P = self._prep()
+        self._keep: list = []
+        self._gain32 = {f"{side}.{n}": b.emb_gain.data.float().reshape(1) for side in ("enc", "dec") for n, b in getattr(self, side).items()
+                        if n != "conv_in"}
+        x_in = x_in.to(dev, torch.float32)
+        sig = sigma.flatten().to(dev, torch.float32).contiguous()
+        sd = cfg.sigma_data
+        s5 = sig.view(-1, 1, 1, 1)
+        c_skip, c_out, c_in = sd ** 2 / (s5 ** 2 + sd ** 2), s5 * sd / torch.sqrt(s5 ** 2 + sd ** 2), 1 / torch.sqrt(sd ** 2 + s5 ** 2)
+        src = perturbed_input.to(dev, torch.float32) if perturbed_input is not None else x_in
+        # ---- input assembly (layout glue): channels [c_in * x, psd chunk 0..ppf-1, 1] of image n = 2b + z, zero padded to 8k
+        ppf = self.psd_freqs_per_freq
+        xr = x_ref.to(dev, torch.float32).view(B, 2, H, ppf, W).permute(0, 1, 2, 4, 3)                      # [B, z, H, W, ppf]
+        x0 = torch.zeros(B, 2, H, W, self._cin_pad, dtype=dt, device=dev)
+        x0[..., 0] = (c_in * src).to(dt)
+        x0[..., 1:1 + ppf] = xr.to(dt)
+        if cfg.add_constant_channel:
+            x0[..., 1 + ppf] = 1.0
+        x0 = x0.view(B * 2, H, W, self._cin_pad)
+        # ---- embedding: emb_noise(fourier(ln sigma / 4)) (no label path), one row per image
+        four = torch.empty(B, self.cnoise, dtype=torch.float32, device=dev)
+        ops.mpfourier(sig, self.emb_fourier.freqs.float().contiguous(), self.emb_fourier.phases.float().contiguous(), four, True)
+        emb = torch.empty(B, self.cemb, dtype=torch.float32, device=dev)
+        w_n = self.emb_noise.weight
+        t_n = ops.make_linear_jobs([(w_n, None, emb, 1.0, 0.0, 1, False)], dev)
+        ops.linear_small(t_n, 1, self.cemb, four, B, w_n.dtype)
+        if dt == torch.bfloat16:
+            emb = emb.to(dt).float()            # the reference casts emb to bfloat16 before the emb_linear layers (:305)
+        emb2 = emb.repeat_interleave(2, dim=0).contiguous()
+        # ---- encoder / decoder
+        x = ops.conv2d(x0, P["conv_in"], src1=self._swap(x0), reflect_w=True)
+        skips = [x]
+        for name, blk in self.enc.items():
+            if name == "conv_in":
+                continue
+            x = self._block(P, "enc." + name, blk, x, emb2)
+            skips.append(x)
+        for name, blk in self.dec.items():
+            if "layer" in name:
+                sk = skips.pop()
+                wa, wb = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
+                x = torch.cat([x * wa, sk * wb], dim=-1)          # mp_cat materialised: conv_skip mixes the pair over all channels
+            x = self._block(P, "dec." + name, blk, x, emb2)
+        y8 = ops.conv2d(x, P["conv_out"], src1=self._swap(x), reflect_w=True)
+        torch.cuda.current_stream().synchronize()    # job tables of this call are temporaries
+        y = y8[..., 0].float().view(B, 2, H, W)
+        return c_skip * x_in + c_out * y

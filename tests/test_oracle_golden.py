@@ -167,3 +167,17 @@ def test_unet_train_golden():
     grads = torch.autograd.grad(loss.mean(), list(params.values()))
     for k, g in zip(params, grads):
         assert rel_l2(g, t[f"grad.{k}"]) < 1e-3, k
+
+
+def test_ddec_golden():
+    """Diffusion-decoder oracle against the reference's forward (bit-equal in the reference's bfloat16 op sequence)."""
+    from oracle import ddec_oracle as DO
+    t, m = load_golden("ddec_small")
+    cfg = DO.ddec_cfg(**m["cfg"])
+    sd = DO.random_ddec_state(cfg, m["seed"])
+    coll = {}
+    out = DO.ddec_forward(sd, cfg, t["x_in"], t["sigma"], t["x_ref"], collect=coll)
+    assert rel_l2(out, t["out"]) < 1e-6
+    for k in [k for k in t if k.startswith("stage.")]:
+        assert rel_l2(coll[k[6:]].float(), t[k]) < 1e-6, k
+    assert rel_l2(DO.ddec_forward(sd, cfg, t["x_in"], t["sigma"], t["x_ref"], compute_dtype=torch.float32), t["out_fp32_oracle"]) < 1e-6

@@ -536,6 +536,42 @@ def gen_train() -> None:
                                grads=keep, freq_range=[20.0, 16000.0]))
 
 
+def gen_ddec() -> None:
+    """MCLT diffusion-decoder UNet (modules/unets/unet_edm2_ddec_mclt_b1.py): eval-mode forward, small config."""
+    print("ddec")
+    from modules.unets.unet_edm2_ddec_mclt_b1 import DDec_MCLT_UNet_B1, DDec_MCLT_UNet_B1_Config
+    sys.path.insert(0, ROOT)
+    from oracle import ddec_oracle as DO
+    over = dict(in_num_freqs=32, in_psd_freqs=64, model_channels=32, channel_mult=(1, 2), num_layers_per_block=1)
+    cfg = DO.ddec_cfg(**over)
+    rcfg = DDec_MCLT_UNet_B1_Config(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in over.items()})
+    unet = DDec_MCLT_UNet_B1(rcfg).requires_grad_(False).train(False)
+    shapes = DO.ddec_param_shapes(cfg)
+    ref_sd = unet.state_dict()
+    assert {k: tuple(v.shape) for k, v in ref_sd.items()} == {**{k: tuple(v) for k, v in shapes.items()},
+            **{k: tuple(ref_sd[k].shape) for k in ref_sd if "fourier" in k}}, "param shapes differ"
+    sd = DO.random_ddec_state(cfg, seed=21)
+    unet.load_state_dict(sd)
+    g = torch.Generator().manual_seed(22)
+    B, H, W = 2, 32, 24
+    sigma = torch.tensor([0.2, 4.0])
+    x_in = torch.randn(B, 2, H, W, generator=g) * torch.sqrt(sigma ** 2 + 1).view(-1, 1, 1, 1)
+    x_ref = torch.randn(B, 2, 64, W, generator=g).abs()
+    with torch.no_grad():
+        out = unet(x_in, sigma, None, None, x_ref=x_ref)
+        coll = {}
+        ours = DO.ddec_forward(sd, cfg, x_in, sigma, x_ref, collect=coll)
+        ours32 = DO.ddec_forward(sd, cfg, x_in, sigma, x_ref, compute_dtype=torch.float32)
+    check("ddec forward (bf16 body as the reference)", ours, out, 1e-5)
+    print(f"    fp32 oracle vs the reference's bf16 forward: rel-L2 {rel_l2(ours32, out):.2e}")
+    assert float((out - x_in * (1 / (sigma ** 2 + 1)).view(-1, 1, 1, 1)).abs().max()) > 1e-3, "vacuous (gains zero?)"
+    t = {"x_in": x_in, "sigma": sigma, "x_ref": x_ref, "out": out, "out_fp32_oracle": ours32}
+    for k in ("enc.conv_in", "enc.block1_down", "dec.block1_layer0", "dec.block0_up", "dec.block0_layer1"):
+        t[f"stage.{k}"] = coll[k].float()
+    save("ddec_small", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in over.items()}, seed=21, B=B, H=H, W=W,
+                               weights="oracle.ddec_oracle.random_ddec_state(cfg, seed)"))
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -546,7 +582,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ddec": gen_ddec}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
