@@ -32,6 +32,11 @@ CASES = {
     "L2_res1_raw": (4, 8, 172, 1536, 0, 768, 8, 3, 0, L.PRO_NONE, True),
     "L3_res0_raw": (4, 4, 86, 1024, 0, 2048, 8, 3, 0, L.PRO_NONE, False),
     "L0_skip_cat_raw": (4, 32, 688, 512, 256, 256, 1, 1, 0, L.PRO_NONE, False),
+    "L3_res1_raw": (4, 4, 86, 2048, 0, 1024, 8, 3, 0, L.PRO_NONE, True),
+    "L3_dec_res0_raw": (4, 4, 86, 1280, 1024, 2048, 8, 3, 0, L.PRO_NONE, False),
+    "L3_v_raw": (4, 4, 86, 1024, 0, 1024, 1, 1, 0, L.PRO_NONE, False),
+    "L3_skip_cat_raw": (4, 4, 86, 1280, 1024, 1024, 1, 1, 0, L.PRO_NONE, False),
+    "L3_proj_raw": (4, 4, 86, 1024, 0, 1024, 1, 1, 0, L.PRO_NONE, True),
     "L1_skip_cat_raw": (4, 16, 344, 768, 512, 512, 1, 1, 0, L.PRO_NONE, False),
     "L2_skip_cat_raw": (4, 8, 172, 1024, 768, 768, 1, 1, 0, L.PRO_NONE, False),
     "L0_skip_512_raw": (4, 32, 688, 512, 0, 512, 1, 1, 0, L.PRO_NONE, False),
@@ -70,7 +75,7 @@ def main():
         raw = name.endswith('_raw')
         kw = dict(out_hw=(H, W), src1=a1, scale0=1.0 if raw else 0.8, scale1=1.0 if raw else 1.1, resample=rs, prologue=pro,
                   chan_scale=cs if pro & L.PRO_SCALE else None, residual=res, res_t=0.3, clip=256.0, out=out)
-        for path in (["mfma", "dma"] if a.path == "both" else [a.path]):
+        for path in (["mfma", "dma"] if a.path == "both" else a.path.split("+")):
             kw["path"] = path
             try:
                 for _ in range(3):
