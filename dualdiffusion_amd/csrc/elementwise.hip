@@ -411,3 +411,115 @@ extern "C" int ddx_linear_small_batched(const ddx_linear_job* jobs_dev, int32_t 
     return check_launch("linear_small");
   }, stream, "linear_small");
 }
+
+// ------------------------------------------------------------------------------------------------ diffusion decoder glue
+// (reference src/modules/unets/unet_edm2_ddec_mclt_b1.py:295-326 around the block stack; images are ordered n = 2*b + z)
+namespace ddx {
+
+// channels [c_in * x, psd chunk 0 .. ppf-1, 1, 0-padding] of image n; also written pair-swapped (image n ^ 1) for the
+// depth-2 kernels of conv_in
+template <typename T>
+__global__ __launch_bounds__(256) void ddec_input_prep_kernel(const float* __restrict__ x, const float* __restrict__ xref, const float* __restrict__ sigma,
+                                                              T* __restrict__ out, T* __restrict__ out_sw, int B, int H, int W, int ppf, int Cpad,
+                                                              float sd, int add_const) {
+  const size_t total = (size_t)B * 2 * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    size_t r = i / W;
+    const int h = (int)(r % H); r /= H;
+    const int z = (int)(r & 1), b = (int)(r >> 1);
+    const float sg = sigma[b];
+    const float c_in = rsqrtf(sd * sd + sg * sg);
+    T* o = out + i * Cpad;
+    T* os = out_sw + ((((size_t)b * 2 + (1 - z)) * H + h) * W + w) * Cpad;
+    const T v0 = from_f32<T>(c_in * x[(((size_t)b * 2 + z) * H + h) * W + w]);
+    o[0] = v0; os[0] = v0;
+    for (int p = 0; p < ppf; ++p) {
+      const T v = from_f32<T>(xref[(((size_t)b * 2 + z) * H * ppf + (size_t)h * ppf + p) * W + w]);
+      o[1 + p] = v; os[1 + p] = v;
+    }
+    int c = 1 + ppf;
+    if (add_const) { o[c] = from_f32<T>(1.f); os[c] = from_f32<T>(1.f); ++c; }
+    for (; c < Cpad; ++c) { o[c] = from_f32<T>(0.f); os[c] = from_f32<T>(0.f); }
+  }
+}
+
+// out = [sa * a | sb * b] on channels (mp_cat, b optional), and the same rows written to the pair-swapped image
+template <typename T>
+__global__ __launch_bounds__(256) void cat2_swap_kernel(const T* __restrict__ a, float sa, const T* __restrict__ b, float sb, T* __restrict__ out,
+                                                        T* __restrict__ out_sw, size_t rows_per_image, size_t nrows, int C0, int C1) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int nv0 = C0 / EV, nv = (C0 + C1) / EV;
+  const size_t total = nrows * nv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / nv;
+    const int v = (int)(i - row * nv);
+    Vec16<T> x, o;
+    float s;
+    if (v < nv0) { x.v = *reinterpret_cast<const decltype(x.v)*>(a + row * C0 + (size_t)v * EV); s = sa; }
+    else { x.v = *reinterpret_cast<const decltype(x.v)*>(b + row * C1 + (size_t)(v - nv0) * EV); s = sb; }
+#pragma unroll
+    for (int e = 0; e < EV; ++e) o.set(e, to_f32<T>(from_f32<T>(x.get(e) * s)));   // wa * a rounded in the tensor dtype, as mp_cat does
+    const size_t img = row / rows_per_image;
+    const size_t row_sw = (img ^ 1) * rows_per_image + (row - img * rows_per_image);
+    if (out) *reinterpret_cast<decltype(x.v)*>(out + row * (C0 + C1) + (size_t)v * EV) = o.v;
+    *reinterpret_cast<decltype(x.v)*>(out_sw + row_sw * (C0 + C1) + (size_t)v * EV) = o.v;
+  }
+}
+
+// D[b][z][h][w] = c_skip * x_in + c_out * y[n = 2b+z][h][w][0]
+template <typename T>
+__global__ __launch_bounds__(256) void ddec_output_combine_kernel(const T* __restrict__ y, int ystride, const float* __restrict__ x_in,
+                                                                  const float* __restrict__ sigma, float* __restrict__ out, size_t per_b, size_t total,
+                                                                  float sd) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const float sg = sigma[i / per_b];
+    const float den = sg * sg + sd * sd;
+    out[i] = (sd * sd / den) * x_in[i] + (sg * sd * rsqrtf(den)) * to_f32<T>(y[i * ystride]);
+  }
+}
+
+}  // namespace ddx
+
+extern "C" int ddx_ddec_input_prep(const float* x, const float* x_ref, const float* sigma, void* out, void* out_swapped, int32_t B, int32_t H,
+                                   int32_t W, int32_t ppf, int32_t Cpad, float sigma_data, int32_t add_const, int32_t dtype, ddx_stream stream) {
+  if (!x || !x_ref || !sigma || !out || !out_swapped || Cpad < 1 + ppf + (add_const ? 1 : 0)) return set_error(DDX_ERR_ARG, "ddec_input_prep: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * 2 * H * W);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(ddec_input_prep_kernel<bf16>, dim3(blocks), dim3(256), 0, s, x, x_ref, sigma, (bf16*)out, (bf16*)out_swapped, B, H, W, ppf, Cpad, sigma_data, add_const);
+    else
+      hipLaunchKernelGGL(ddec_input_prep_kernel<float>, dim3(blocks), dim3(256), 0, s, x, x_ref, sigma, (float*)out, (float*)out_swapped, B, H, W, ppf, Cpad, sigma_data, add_const);
+    return check_launch("ddec_input_prep");
+  }, stream);
+}
+
+extern "C" int ddx_cat2_swap(const void* a, float scale_a, const void* b, float scale_b, void* out, void* out_swapped, int64_t images,
+                             int64_t rows_per_image, int32_t C0, int32_t C1, int32_t dtype, ddx_stream stream) {
+  if (!a || !out_swapped || images <= 0 || (images & 1) || rows_per_image <= 0 || C0 <= 0 || (C1 > 0) != (b != nullptr))
+    return set_error(DDX_ERR_ARG, "cat2_swap: bad args");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (C0 % ev || C1 % ev) return set_error(DDX_ERR_UNSUPPORTED, "cat2_swap: channel counts must fill 16-byte vectors");
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t nrows = (size_t)images * rows_per_image;
+    const int blocks = grid_for(nrows * ((C0 + C1) / ev));
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(cat2_swap_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)a, scale_a, (const bf16*)b, scale_b, (bf16*)out, (bf16*)out_swapped, (size_t)rows_per_image, nrows, C0, C1);
+    else
+      hipLaunchKernelGGL(cat2_swap_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)a, scale_a, (const float*)b, scale_b, (float*)out, (float*)out_swapped, (size_t)rows_per_image, nrows, C0, C1);
+    return check_launch("cat2_swap");
+  }, stream, "cat2_swap", 0.0, (double)images * rows_per_image * (C0 + C1) * (double)dtype_size(dtype) * (out ? 3.0 : 2.0));
+}
+
+extern "C" int ddx_ddec_output_combine(const void* y, int32_t y_channels, const float* x_in, const float* sigma, float* out, int32_t B,
+                                       int64_t per_sample, float sigma_data, int32_t dtype, ddx_stream stream) {
+  if (!y || !x_in || !sigma || !out || B <= 0 || per_sample <= 0) return set_error(DDX_ERR_ARG, "ddec_output_combine: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const size_t total = (size_t)B * per_sample;
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(ddec_output_combine_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)y, y_channels, x_in, sigma, out, (size_t)per_sample, total, sigma_data);
+    else
+      hipLaunchKernelGGL(ddec_output_combine_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)y, y_channels, x_in, sigma, out, (size_t)per_sample, total, sigma_data);
+    return check_launch("ddec_output_combine");
+  }, stream);
+}

@@ -7,8 +7,9 @@ depth axis is folded into the image batch (image n = 2*b + z, NHWC) and every la
   * (1,3,3): the same 3x3 conv on both depth slices, with mirrored columns (`pad_mode = REFLECT_W`) and zero rows;
   * (2,1,1) / (2,3,3): out[z] = W[0] x[z] + W[1] x[1-z] (the reflected depth row behind a 2-deep tensor is the other channel)
     = ONE two-source conv over [x | x with the stereo pair swapped] with the weights [W[..,0] | W[..,1]].
-First version of this row: eager launches; input assembly, mp_cat materialisation, the pair swap and the final 1-channel
-combine are torch layout glue on the host side of the boundary (the conv operand traffic they add is noted in DESIGN.md).
+First version of this row: eager launches; the pair-swapped copies and the materialised mp_cat are extra HBM passes
+(`ddx_cat2_swap`, one read + two writes per block input) that a swapped second-source addressing mode in the conv kernel
+would remove.
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ from typing import Optional, Union
 import torch
 
 from ... import ops
-from ..._lib import DDXError, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_UP
+from ..._lib import DDXError, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_UP, check, current_stream, dtype_code, lib, ptr
 from ...engine import mp_cat_weights
 from .unet import DualDiffusionUNet, DualDiffusionUNetConfig
 
@@ -193,18 +194,22 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         return P
 
     # ------------------------------------------------------------------ forward
-    @staticmethod
-    def _swap(x: torch.Tensor) -> torch.Tensor:
-        """Images are ordered n = 2*b + z: exchange the stereo pair (the reflected depth row of MPConv3D)."""
-        N = x.shape[0]
-        return x.view(N // 2, 2, *x.shape[1:]).flip(1).reshape(x.shape).contiguous()
-
-    def _block(self, P: dict, pre: str, blk: DDecBlockWeights, x: torch.Tensor, emb2: torch.Tensor) -> torch.Tensor:
+    def _block(self, P: dict, pre: str, blk: DDecBlockWeights, x: torch.Tensor, emb2: torch.Tensor, skip: Optional[torch.Tensor] = None,
+               wa: float = 1.0, wb: float = 1.0) -> torch.Tensor:
+        """x (| skip: mp_cat with weights wa, wb) -> block output.  conv_skip mixes the stereo pair: its second source is the
+        pair-swapped copy of its input."""
         cfg = self.config
+        if skip is not None:
+            assert blk.resample_mode == "keep"
+            x, x_sw = ops.cat2_swap(x, wa, skip, wb)                  # mp_cat materialised once, with its swapped twin
+        else:
+            x_sw = None
         if blk.resample_mode != "keep":
             N, H, W, Cn = x.shape
             out = torch.empty((N, H * 2, W * 2, Cn) if blk.resample_mode == "up" else (N, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device)
             x = ops.resample2d(x, out, RESAMPLE_UP if blk.resample_mode == "up" else RESAMPLE_DOWN)
+        if x_sw is None:
+            _, x_sw = ops.cat2_swap(x, want_cat=False)
         N = x.shape[0]
         Cmid = blk.conv_res0.out_channels
         c = torch.empty(N, Cmid, dtype=torch.float32, device=x.device)
@@ -213,10 +218,10 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         ops.linear_small(table, 1, Cmid, emb2, N, w_e.dtype)
         self._keep.append(table)
         if blk.flavor == "enc":
-            x = ops.pixelnorm(ops.conv2d(x, P[pre + ".skip"], src1=self._swap(x)))
+            x = ops.pixelnorm(ops.conv2d(x, P[pre + ".skip"], src1=x_sw))
         y = ops.conv2d(x, P[pre + ".res0"], prologue=PRO_SILU, reflect_w=True)
         if blk.flavor == "dec":
-            x = ops.conv2d(x, P[pre + ".skip"], src1=self._swap(x))
+            x = ops.conv2d(x, P[pre + ".skip"], src1=x_sw)
         return ops.conv2d(y, P[pre + ".res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=x, res_t=cfg.res_balance, clip=256.0, reflect_w=True)
 
     @torch.no_grad()
@@ -234,21 +239,18 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         self._keep: list = []
         self._gain32 = {f"{side}.{n}": b.emb_gain.data.float().reshape(1) for side in ("enc", "dec") for n, b in getattr(self, side).items()
                         if n != "conv_in"}
-        x_in = x_in.to(dev, torch.float32)
+        x_in = x_in.to(dev, torch.float32).contiguous()
         sig = sigma.flatten().to(dev, torch.float32).contiguous()
-        sd = cfg.sigma_data
-        s5 = sig.view(-1, 1, 1, 1)
-        c_skip, c_out, c_in = sd ** 2 / (s5 ** 2 + sd ** 2), s5 * sd / torch.sqrt(s5 ** 2 + sd ** 2), 1 / torch.sqrt(sd ** 2 + s5 ** 2)
-        src = perturbed_input.to(dev, torch.float32) if perturbed_input is not None else x_in
-        # ---- input assembly (layout glue): channels [c_in * x, psd chunk 0..ppf-1, 1] of image n = 2b + z, zero padded to 8k
+        src = perturbed_input.to(dev, torch.float32).contiguous() if perturbed_input is not None else x_in
+        xr = x_ref.to(dev, torch.float32).contiguous()
         ppf = self.psd_freqs_per_freq
-        xr = x_ref.to(dev, torch.float32).view(B, 2, H, ppf, W).permute(0, 1, 2, 4, 3)                      # [B, z, H, W, ppf]
-        x0 = torch.zeros(B, 2, H, W, self._cin_pad, dtype=dt, device=dev)
-        x0[..., 0] = (c_in * src).to(dt)
-        x0[..., 1:1 + ppf] = xr.to(dt)
-        if cfg.add_constant_channel:
-            x0[..., 1 + ppf] = 1.0
-        x0 = x0.view(B * 2, H, W, self._cin_pad)
+        if tuple(xr.shape) != (B, 2, H * ppf, W):
+            raise DDXError(f"x_ref must be [B, 2, {H * ppf}, W], got {tuple(xr.shape)}")
+        # ---- input assembly: channels [c_in * x, psd chunk 0..ppf-1, 1] of image n = 2b + z (zero padded to 8k), + swapped twin
+        x0 = torch.empty(B * 2, H, W, self._cin_pad, dtype=dt, device=dev)
+        x0_sw = torch.empty_like(x0)
+        check(lib().ddx_ddec_input_prep(ptr(src), ptr(xr), ptr(sig), ptr(x0), ptr(x0_sw), B, H, W, ppf, self._cin_pad, cfg.sigma_data,
+                                        int(cfg.add_constant_channel), dtype_code(dt), current_stream()), "ddec_input_prep")
         # ---- embedding: emb_noise(fourier(ln sigma / 4)) (no label path), one row per image
         four = torch.empty(B, self.cnoise, dtype=torch.float32, device=dev)
         ops.mpfourier(sig, self.emb_fourier.freqs.float().contiguous(), self.emb_fourier.phases.float().contiguous(), four, True)
@@ -260,7 +262,7 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
             emb = emb.to(dt).float()            # the reference casts emb to bfloat16 before the emb_linear layers (:305)
         emb2 = emb.repeat_interleave(2, dim=0).contiguous()
         # ---- encoder / decoder
-        x = ops.conv2d(x0, P["conv_in"], src1=self._swap(x0), reflect_w=True)
+        x = ops.conv2d(x0, P["conv_in"], src1=x0_sw, reflect_w=True)
         skips = [x]
         for name, blk in self.enc.items():
             if name == "conv_in":
@@ -271,9 +273,13 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
             if "layer" in name:
                 sk = skips.pop()
                 wa, wb = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
-                x = torch.cat([x * wa, sk * wb], dim=-1)          # mp_cat materialised: conv_skip mixes the pair over all channels
-            x = self._block(P, "dec." + name, blk, x, emb2)
-        y8 = ops.conv2d(x, P["conv_out"], src1=self._swap(x), reflect_w=True)
+                x = self._block(P, "dec." + name, blk, x, emb2, sk, wa, wb)
+            else:
+                x = self._block(P, "dec." + name, blk, x, emb2)
+        _, x_sw = ops.cat2_swap(x, want_cat=False)
+        y8 = ops.conv2d(x, P["conv_out"], src1=x_sw, reflect_w=True)
+        out = torch.empty(B, 2, H, W, dtype=torch.float32, device=dev)
+        check(lib().ddx_ddec_output_combine(ptr(y8), y8.shape[-1], ptr(x_in), ptr(sig), ptr(out), B, 2 * H * W, cfg.sigma_data, dtype_code(dt),
+                                            current_stream()), "ddec_output_combine")
         torch.cuda.current_stream().synchronize()    # job tables of this call are temporaries
-        y = y8[..., 0].float().view(B, 2, H, W)
-        return c_skip * x_in + c_out * y
+        return out

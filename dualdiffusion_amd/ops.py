@@ -232,6 +232,18 @@ def edm2_loss(denoised: torch.Tensor, target: torch.Tensor, sigma: torch.Tensor,
     return loss, dd, dlv
 
 
+def cat2_swap(a: torch.Tensor, scale_a: float = 1.0, b: Optional[torch.Tensor] = None, scale_b: float = 1.0, want_cat: bool = True):
+    """NHWC images ordered n = 2*b + z: returns ([scale_a*a | scale_b*b] or None, the same rows with the stereo pair swapped)."""
+    N, C0 = a.shape[0], a.shape[-1]
+    C1 = b.shape[-1] if b is not None else 0
+    shape = tuple(a.shape[:-1]) + (C0 + C1,)
+    out = torch.empty(shape, dtype=a.dtype, device=a.device) if (want_cat and (b is not None or scale_a != 1.0)) else None
+    out_sw = torch.empty(shape, dtype=a.dtype, device=a.device)
+    check(lib().ddx_cat2_swap(ptr(a), float(scale_a), ptr(b), float(scale_b), ptr(out), ptr(out_sw), N, a.numel() // (N * C0), C0, C1,
+                              dtype_code(a.dtype), current_stream()), "cat2_swap")
+    return (out if out is not None else a), out_sw
+
+
 def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 1e-4, out_act: Optional[torch.Tensor] = None) -> torch.Tensor:
     """RMS normalisation over the last (channel) axis of contiguous rows; `out_act` also receives mp_silu(result)."""
     Cn = x.shape[-1]

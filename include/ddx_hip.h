@@ -270,6 +270,23 @@ int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, i
 int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Layout glue of the diffusion decoder (modules/unets/unet_edm2_ddec_mclt_b1.py:295-326).  The 5-D (B, C, 2, H, W) tensors of the
+ * reference are NHWC images ordered n = 2*b + z; "pair-swapped" = the same rows stored at image n ^ 1 (the reflected depth row of
+ * MPConv3D, i.e. the other stereo channel), which the depth-2 kernels read as the conv's second source.
+ *   ddx_ddec_input_prep    : x [B][2][H][W], x_ref [B][2][H*ppf][W] fp32 -> out / out_swapped [2B][H][W][Cpad] with channels
+ *                            [x / sqrt(sd^2 + sigma^2), psd chunk 0..ppf-1, 1 (add_const), 0 ...]
+ *   ddx_cat2_swap          : out = [scale_a * a | scale_b * b] on channels (mp_cat; b / out may be NULL: plain copy) and the same
+ *                            rows pair-swapped into out_swapped
+ *   ddx_ddec_output_combine: out[b][z][h][w] = c_skip * x_in + c_out * y[n][h][w][0]   (y has y_channels per pixel)
+ * ------------------------------------------------------------------------------------------------ */
+int ddx_ddec_input_prep(const float* x, const float* x_ref, const float* sigma, void* out, void* out_swapped, int32_t B, int32_t H,
+                        int32_t W, int32_t ppf, int32_t Cpad, float sigma_data, int32_t add_const, int32_t dtype, ddx_stream stream);
+int ddx_cat2_swap(const void* a, float scale_a, const void* b, float scale_b, void* out, void* out_swapped, int64_t images,
+                  int64_t rows_per_image, int32_t C0, int32_t C1, int32_t dtype, ddx_stream stream);
+int ddx_ddec_output_combine(const void* y, int32_t y_channels, const float* x_in, const float* sigma, float* out, int32_t B,
+                            int64_t per_sample, float sigma_data, int32_t dtype, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused mel-STFT  (modules/formats/old/spectrogram.py:176-179,217-226 == torch.stft(center, reflect, onesided) -> abs ->
  * FrequencyScale.scale (modules/formats/frequency_scale.py:127-128) -> ** abs_exponent -> (x - mean) * scale).
  *   audio [B][C][L] fp32 (C = 1 or 2) -> out [B][C][n_mel][T] fp32, T = 1 + L / hop frames.
