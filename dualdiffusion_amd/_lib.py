@@ -143,6 +143,8 @@ PROTOTYPES = {
     "ddx_cat2_swap": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "ddx_ddec_output_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
+    "ddx_unet_output_combine_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                              C.c_int32, C.c_void_p]),
     "ddx_mss_loss_scale": (C.c_int, [C.POINTER(MssDesc), C.c_void_p]),
     "ddx_resample2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

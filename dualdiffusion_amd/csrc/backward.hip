@@ -407,3 +407,33 @@ extern "C" int ddx_edm2_loss(const float* denoised, const float* target, const f
     return check_launch("edm2_loss");
   }, stream, "edm2_loss");
 }
+
+// backward of D = c_skip * x_in + c_out * y w.r.t. y (unet_edm2_b4.py:291): dy[b][h][w][c] = c_out(sigma_b) * dD[b][c][h][w], written
+// NHWC in the activation dtype with the channel axis zero-padded to Cpad (conv_out's gradient operand)
+namespace ddx {
+template <typename T>
+__global__ __launch_bounds__(256) void output_combine_bwd_kernel(const float* __restrict__ dd, const float* __restrict__ sigma, T* __restrict__ dy, int B,
+                                                                 int C, int H, int W, int Cpad, float sd) {
+  const size_t total = (size_t)B * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t hw = i % ((size_t)H * W);
+    const int b = (int)(i / ((size_t)H * W));
+    const float sg = sigma[b];
+    const float c_out = sg * sd * rsqrtf(sg * sg + sd * sd);
+    for (int c = 0; c < Cpad; ++c) dy[i * Cpad + c] = from_f32<T>(c < C ? c_out * dd[((size_t)b * C + c) * H * W + hw] : 0.f);
+  }
+}
+}  // namespace ddx
+
+extern "C" int ddx_unet_output_combine_bwd(const float* d_out_nchw, const float* sigma, void* dy_nhwc, int32_t B, int32_t C, int32_t H, int32_t W,
+                                           int32_t Cpad, float sigma_data, int32_t dtype, ddx_stream stream) {
+  if (!d_out_nchw || !sigma || !dy_nhwc || Cpad < C) return set_error(DDX_ERR_ARG, "output_combine_bwd: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = (int)std::min<size_t>(((size_t)B * H * W + 255) / 256, 8192);
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(output_combine_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, s, d_out_nchw, sigma, (bf16*)dy_nhwc, B, C, H, W, Cpad, sigma_data);
+    else
+      hipLaunchKernelGGL(output_combine_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, d_out_nchw, sigma, (float*)dy_nhwc, B, C, H, W, Cpad, sigma_data);
+    return check_launch("output_combine_bwd");
+  }, stream);
+}

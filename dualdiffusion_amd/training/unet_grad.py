@@ -17,7 +17,7 @@ import torch
 
 from .. import ops
 from ..engine import mp_cat_weights
-from .._lib import DDXError
+from .._lib import DDXError, check, current_stream, dtype_code, lib, ptr
 from .block_grad import BlockWeightsT, block_backward, block_forward_train
 
 
@@ -112,11 +112,10 @@ class UNetTrainer:
             raise DDXError("UNetTrainer.backward before forward")
         B, H, W, Co = t["B"], t["H"], t["W"], t["Co"]
         grads: dict = {}
-        # D = c_skip * x_in + c_out * y  ->  dy = c_out[b] * dD   (tiny [B, 4, H, W] glue on the host side of the boundary)
-        sd = cfg.sigma_data
-        c_out = (t["sig"] * sd / torch.sqrt(t["sig"] ** 2 + sd ** 2)).view(B, 1, 1, 1)
-        dy8 = torch.zeros(B, H, W, 8, dtype=dt, device=dev)
-        dy8[..., :Co] = (dD.to(dev, torch.float32) * c_out).permute(0, 2, 3, 1).to(dt)
+        # D = c_skip * x_in + c_out * y  ->  dy = c_out[b] * dD, NHWC bf16 with the 4 channels padded to one 16-byte vector
+        dy8 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
+        check(lib().ddx_unet_output_combine_bwd(ptr(dD.to(dev, torch.float32).contiguous()), ptr(t["sig"]), ptr(dy8), B, Co, H, W, 8, cfg.sigma_data,
+                                                dtype_code(dt), current_stream()), "unet_output_combine_bwd")
         # conv_out (+ out_gain)
         dwp8 = ops.conv2d_wgrad(dy8, t["x_last"], 1, 3)
         dgain = torch.zeros(1, dtype=torch.float32, device=dev)

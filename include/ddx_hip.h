@@ -183,6 +183,10 @@ int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* d, const float* dwp, float* dw, f
  * workspace: B floats. */
 int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data, float* loss,
                   float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream);
+/* Backward of the preconditioning output D = c_skip x_in + c_out y (unet_edm2_b4.py:291) w.r.t. y: dy (NHWC, channels zero-padded to
+ * Cpad) = c_out(sigma_b) * dD (NCHW fp32). */
+int ddx_unet_output_combine_bwd(const float* d_out_nchw, const float* sigma, void* dy_nhwc, int32_t B, int32_t C, int32_t H, int32_t W,
+                                int32_t Cpad, float sigma_data, int32_t dtype, ddx_stream stream);
 /* Per-row factor of the weight path: row_scale[o] = gain_eff / sqrt(fan_in) / (normalize ? eps + |w_o| / sqrt(fan_in) : 1), so that
  * w' = w * row_scale[o]  (mp_tools.py:359-364). */
 int ddx_wprep_rowscale(const void* w, int32_t w_dtype, float* row_scale, const float* gain_ptr, float gain, int64_t rows,
