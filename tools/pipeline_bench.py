@@ -1,0 +1,62 @@
+"""End-to-end sampling timing (BASELINE.json configs[4] without the MCLT diffusion decoder stage): EDM sampler over the default
+UNet (CFG batch doubling, Heun) -> VAE decode -> FGLA phase reconstruction, random-init weights, synthetic conditioning.
+
+    python tools/pipeline_bench.py [batch] [sampler steps] [fgla iters]
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig  # noqa: E402
+from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig  # noqa: E402
+from dualdiffusion_amd.modules.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config  # noqa: E402
+from dualdiffusion_amd.pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams  # noqa: E402
+
+
+def init(m):
+    m.normalize_weights()
+    for _n, p in m.named_parameters():
+        if p.ndim == 0:
+            p.data.fill_(0.7)
+    return m
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    fgla = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    unet = init(UNet(UNetConfig()).requires_grad_(False).train(False).to(device="cuda", dtype=dt))
+    unet.compile()
+    vae = init(AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config()).requires_grad_(False).train(False).to(device="cuda", dtype=dt))
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
+    pipe = DualDiffusionPipeline({"unet": unet, "vae": vae, "format": fmt})
+    clap = torch.randn(1, 512, device="cuda").repeat(2 * B, 1)     # one prompt embedding for the conditioned and the dropped rows
+    shape = (B, 4, 32, 688)                                   # 45 s @ 32 kHz stereo mel latent
+    params = SampleParams(seed=1, num_steps=steps, batch_size=B)
+    pipe.diffusion_decode(SampleParams(seed=1, num_steps=2, batch_size=B), quiet=True, audio_embedding=clap, sample_shape=shape)   # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    latents = pipe.diffusion_decode(params, quiet=True, audio_embedding=clap, sample_shape=shape)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    with torch.no_grad():
+        vemb = vae.get_embeddings(torch.randn(B, 512, device="cuda"))
+        mel = vae.decode(latents.to(dt), vemb, fmt)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        mel = vae.decode(latents.to(dt), vemb, fmt)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        audio = fmt.sample_to_raw(mel.float(), n_fgla_iters=fgla, quiet=True)
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    assert torch.isfinite(audio).all()
+    evals = steps * 2 - 1                                    # Heun: two UNet evaluations per step except the last
+    print(f"pipeline B={B}: sampler {steps} steps (CFG x2 rows, Heun, {evals} UNet calls at batch {2 * B}) {t1 - t0:.2f} s = "
+          f"{(t1 - t0) / evals * 1e3:.1f} ms per call; VAE decode {t3 - t2:.3f} s (first call {t2 - t1:.2f} s); FGLA {fgla} iterations {t4 - t3:.2f} s; "
+          f"audio {tuple(audio.shape)}; total {t4 - t0 - (t2 - t1):.2f} s = {(t4 - t0 - (t2 - t1)) / B:.2f} s per 45 s sample")
+
+
+if __name__ == "__main__":
+    main()
