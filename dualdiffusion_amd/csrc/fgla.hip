@@ -18,7 +18,7 @@
 namespace ddx {
 
 constexpr int kFN = 6400;
-constexpr int kFNT = 256;
+constexpr int kFNT = 1024;
 
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][NB] state (nullptr: angles = 1)

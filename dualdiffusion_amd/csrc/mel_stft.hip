@@ -17,7 +17,7 @@
 namespace ddx {
 
 constexpr int kFPW = 8;      // frames per workgroup
-constexpr int kNT = 256;
+constexpr int kNT = 1024;
 
 struct MelStftParams {
   const float* audio; const float* window; const float2* tw;

@@ -22,7 +22,7 @@ struct MssParams {
   float scale;  // abs_loss_scale / (channels * nbh * nbw * w * (w/2+1))
 };
 
-constexpr int kMssNT = 256;
+constexpr int kMssNT = 1024;  // 16 waves per workgroup: the LDS-resident FFT passes need the latency hiding (one workgroup per CU)
 constexpr int kMssPts = 4096;
 
 __device__ __forceinline__ int reflect_pad_index(int j, int n) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
   cf* Bt = A + kMssPts;
   cf* Cs = Bt + kMssPts;
   float2* stw = reinterpret_cast<float2*>(Cs + kMssPts);           // W twiddles
-  __shared__ float red[4];
+  __shared__ float red[kMssNT / 64];
   const int tid = threadIdx.x;
   const int b = blockIdx.z, by = blockIdx.y, bx0 = blockIdx.x * NBLK;
   const size_t plane = (size_t)p.H * p.Wd;
@@ -156,7 +156,12 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
   lsum = wave_sum(lsum);
   if ((tid & 63) == 0) red[tid >> 6] = lsum;
   __syncthreads();  // also: every thread is done reading the spectra
-  if (tid == 0) atomicAdd(p.loss + b, (red[0] + red[1] + red[2] + red[3]) * p.scale);
+  if (tid == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < kMssNT / 64; ++w) tot += red[w];
+    atomicAdd(p.loss + b, tot * p.scale);
+  }
   if (!p.grad) return;
 
   // ---- gradient: G on the half spectrum -> Hermitian-symmetric packed spectrum -> inverse FFT -> window -> scatter
