@@ -135,14 +135,14 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W, int ld) {
   const size_t n = (size_t)B * C * H * W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int w = (int)(i % W);
     const int h = (int)((i / W) % H);
     const int c = (int)((i / ((size_t)W * H)) % C);
     const int b = (int)(i / ((size_t)W * H * C));
-    y[i] = to_f32<T>(x[(((size_t)b * H + h) * W + w) * C + c]);
+    y[i] = to_f32<T>(x[(((size_t)b * H + h) * W + w) * ld + c]);
   }
 }
 
@@ -346,14 +346,19 @@ extern "C" int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, i
   }, stream);
 }
 
-extern "C" int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream) {
-  if (!x || !y) return set_error(DDX_ERR_ARG, "nhwc_to_nchw: null");
+extern "C" int ddx_nhwc_to_nchw_ld(const void* x, int32_t ld, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype,
+                                   ddx_stream stream) {
+  if (!x || !y || ld < C) return set_error(DDX_ERR_ARG, "nhwc_to_nchw: bad args");
   return dispatch([=](hipStream_t s) -> int {
     const int blocks = grid_for((size_t)B * C * H * W);
-    if (dtype == DDX_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, y, B, C, H, W);
-    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, y, B, C, H, W);
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, y, B, C, H, W, ld);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, y, B, C, H, W, ld);
     return check_launch("nhwc_to_nchw");
   }, stream);
+}
+
+extern "C" int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream) {
+  return ddx_nhwc_to_nchw_ld(x, C, y, B, C, H, W, dtype, stream);
 }
 
 extern "C" int ddx_mpfourier(const float* x, const float* freqs, const float* phases, float* out, int32_t M, int32_t C,

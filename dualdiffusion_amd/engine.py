@@ -34,6 +34,7 @@ class PlanBuilder:
         self.keep: list = []        # every tensor the recorded launches point into
         self.gains: list = []       # 0-d gain parameters, mirrored into one fp32 vector read by the kernels
         self.convs: list = []       # weight-preparation specs
+        self.padded: list = []      # (conv, zero-row-padded weight copy) for convs prepared with cout_pad
         self.lin_jobs: list = []    # (weight holder, gain slot, out tensor, groups, add_const)
         self.steps: list = []       # closures executed while recording the forward plan
         self.wplan, self.fplan = Plan(), Plan()
@@ -56,16 +57,23 @@ class PlanBuilder:
         return len(self.gains) - 1
 
     def prep(self, conv, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0,
-             in_split: int = 0, in_scale0: float = 1.0, in_scale1: float = 1.0):
+             in_split: int = 0, in_scale0: float = 1.0, in_scale1: float = 1.0, cout_pad: int = 0):
         """Declare a conv's prepared weights; the buffer is filled whenever `wplan` runs.
-        in_split / in_scale*: mp_cat scales of a linear consumer folded into the weights."""
+        in_split / in_scale*: mp_cat scales of a linear consumer folded into the weights.
+        cout_pad: prepare from a zero-row-padded copy of the weight (refreshed with the weights), so that a conv with
+        fewer than 4 output channels still runs on the matrix-core kernels; the consumer reads the first channels."""
         w = conv.weight
+        wsrc = None
+        if cout_pad > w.shape[0]:
+            wsrc = torch.zeros((cout_pad,) + tuple(w.shape[1:]), dtype=w.dtype, device=self.dev)
+            self.padded.append((conv, wsrc))
+            w = wsrc
         Cg, ks = w.shape[1], (w.shape[2] if w.ndim == 4 else 1)
         CK = ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
         nbytes = ops.lib().ddx_wprep_bytes(w.shape[0], Cg, ks, conv.groups, CK, ops.dtype_code(self.dt))
         buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         self.keep.append(buf)
-        self.convs.append(dict(conv=conv, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad, in_split=in_split, in_scale0=in_scale0,
+        self.convs.append(dict(conv=conv, wsrc=wsrc, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad, in_split=in_split, in_scale0=in_scale0,
                                in_scale1=in_scale1, gain_slot=self.gain_slot(gain_param) if gain_param is not None else None))
         return ops.PreparedWeight(buf, w.shape[0], Cg, ks, conv.groups, CK, self.dt, None)
 
@@ -202,7 +210,7 @@ class PlanBuilder:
         with self.wplan.record():
             for sp in self.convs:
                 conv = sp["conv"]
-                ops.wprep(conv.weight, conv.groups, self.dt, gain_ptr=self.gain_ptr(sp["gain_slot"]),
+                ops.wprep(conv.weight if sp["wsrc"] is None else sp["wsrc"], conv.groups, self.dt, gain_ptr=self.gain_ptr(sp["gain_slot"]),
                           normalize=self.training and not conv.disable_weight_norm, qk_head_dim=sp["qk"], CK=sp["CK"],
                           cg_pad=sp["cg_pad"], out=sp["buf"], in_split=sp["in_split"], in_scale0=sp["in_scale0"],
                           in_scale1=sp["in_scale1"])
@@ -220,6 +228,8 @@ class PlanBuilder:
         if self.training or key != self._weights_key:
             if self.gains:
                 self.gain_f32.copy_(torch.stack([g.detach().float().reshape(()) for g in self.gains]))
+            for conv, wsrc in self.padded:
+                wsrc[:conv.weight.shape[0]].copy_(conv.weight.detach())
             self.wplan.run()
             self._weights_key = key
 

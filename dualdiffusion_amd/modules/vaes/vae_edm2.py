@@ -217,11 +217,14 @@ class _VAEEngine:
                 h, w = h * 2, w * 2
             tw = 1.0 if (kind == "dec" and bi + 1 < len(blocks)) else None
             x, x_act = pb.block(blk, x, None, 1.0, 1.0, h, w, act0=x_act, twin_scale=tw, **bk)
-        pw_last = pb.prep(last, gain_param=last_gain, npix=B * h * w)
-        y = pb.act(h, w, last.out_channels)
-        self.out = pb.f32(B, last.out_channels, h, w)
+        # a 2-channel conv_out would fall to the scalar kernel: prepare it with zero rows up to 8 and read back the real ones
+        cout = last.out_channels
+        cpad = cout if cout % 4 == 0 else (cout + 7) // 8 * 8
+        pw_last = pb.prep(last, gain_param=last_gain, npix=B * h * w, cout_pad=cpad)
+        y = pb.act(h, w, cpad)
+        self.out = pb.f32(B, cout, h, w)
         pb.step(lambda x=x: ops.conv2d(x, pw_last, out=y))
-        pb.step(lambda: ops.nhwc_to_nchw(y, out=self.out))
+        pb.step(lambda: ops.nhwc_to_nchw(y, out=self.out, channels=cout))
         pb.finalize(self.emb, vae.emb_dim, pre_steps=lambda: ops.unet_input_prep(self.x_in, self.zero_sigma, self.lnf, x0, 1.0))
 
     def run(self, x, emb, format, use_graph: bool) -> torch.Tensor:

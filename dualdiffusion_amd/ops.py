@@ -332,9 +332,11 @@ def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor
     return out
 
 
-def nhwc_to_nchw(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    B, H, W, Cn = x.shape
+def nhwc_to_nchw(x: torch.Tensor, out: Optional[torch.Tensor] = None, channels: Optional[int] = None) -> torch.Tensor:
+    """`channels`: take only the first channels of a wider (row-padded) NHWC tensor."""
+    B, H, W, ld = x.shape
+    Cn = channels or ld
     if out is None:
         out = torch.empty(B, Cn, H, W, dtype=torch.float32, device=x.device)
-    check(lib().ddx_nhwc_to_nchw(ptr(x), ptr(out), B, Cn, H, W, dtype_code(x.dtype), current_stream()), "nhwc_to_nchw")
+    check(lib().ddx_nhwc_to_nchw_ld(ptr(x), ld, ptr(out), B, Cn, H, W, dtype_code(x.dtype), current_stream()), "nhwc_to_nchw")
     return out

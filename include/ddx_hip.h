@@ -272,6 +272,9 @@ int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* 
 /* Layout conversion helpers NCHW fp32 <-> NHWC dtype (module boundary). */
 int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
 int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
+/* Same, reading the first C channels of pixels that are `ld` channels wide (outputs of convs padded to 8 rows). */
+int ddx_nhwc_to_nchw_ld(const void* x, int32_t ld, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype,
+                        ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layout glue of the diffusion decoder (modules/unets/unet_edm2_ddec_mclt_b1.py:295-326).  The 5-D (B, C, 2, H, W) tensors of the
