@@ -70,6 +70,16 @@ class OptimJob(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_int64)]
 
 
+class WPathJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wp_t", C.c_void_p), ("row_scale", C.c_void_p), ("gain_ptr", C.c_void_p),
+                ("dwp", C.c_void_p), ("dw", C.c_void_p), ("dgain", C.c_void_p), ("gain", C.c_float),
+                ("Cout", C.c_int32), ("Cg", C.c_int32), ("ksize", C.c_int32), ("groups", C.c_int32), ("CK", C.c_int32), ("CK_t", C.c_int32),
+                ("normalize", C.c_int32), ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float)]
+
+
+WPATH_NORMALIZE, WPATH_PREP, WPATH_ROWSCALE, WPATH_TRANSPOSED, WPATH_BWD = range(5)
+
+
 class MssDesc(C.Structure):
     _fields_ = [("sample", C.c_void_p), ("target", C.c_void_p), ("window", C.c_void_p), ("weight", C.c_void_p),
                 ("twiddle", C.c_void_p), ("loss", C.c_void_p), ("grad", C.c_void_p),
@@ -150,6 +160,7 @@ PROTOTYPES = {
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddx_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_wpath_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw_ld": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_plan_begin": (C.c_void_p, []),
     "ddx_plan_end": (C.c_int, [C.c_void_p]),

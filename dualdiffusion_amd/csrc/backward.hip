@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "wpath_rows.hpp"
 
 namespace ddx {
 namespace {
@@ -157,52 +158,15 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// one workgroup per DESTINATION row of the prepared weight (same row mapping as wprep_kernel)
+// one workgroup per DESTINATION row of the prepared weight (same row mapping as wprep_kernel; body in wpath_rows.hpp)
 template <typename TW_>
 __global__ __launch_bounds__(256) void wprep_bwd_kernel(const float* __restrict__ dwp, const TW_* __restrict__ w, const float* gain_ptr, float gain,
                                                         float* __restrict__ dw, float* __restrict__ dgain, int Cout, int Cg, int taps, int G,
                                                         int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1,
                                                         int accumulate) {
   __shared__ float scratch[4];
-  const int od = blockIdx.x;
-  const int Ng = Cout / G;
-  const int g = od / Ng;
-  int os = od;
-  if (qk_d > 0) {
-    const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
-    const int s = rem / qk_d, dd = rem - s * qk_d;
-    os = head * 2 * qk_d + dd * 2 + s;
-  }
-  const int fan = Cg * taps;
-  const TW_* wr = w + (size_t)os * fan;
-  const float* gr = dwp + (size_t)od * fan;
-  float ss = 0.f, su = 0.f;
-  for (int i = threadIdx.x; i < fan; i += 256) {
-    const float x = to_f32<TW_>(wr[i]);
-    const int c = i / taps;
-    const float sc = in_split > 0 ? ((g * Cg + c < in_split) ? in_s0 : in_s1) : 1.0f;
-    ss += x * x;
-    su += gr[i] * sc * x;
-  }
-  ss = block_sum_256(ss, scratch);
-  su = block_sum_256(su, scratch);
-  const float rfan = sqrtf(1.0f / (float)fan);
-  const float n = sqrtf(ss);
-  const float nu = normalize ? eps + n * rfan : 1.0f;
-  float gn = gain;
-  if (gain_ptr) gn *= *gain_ptr;
-  const float s = gn * rfan;
-  const float k = (normalize && n > 0.f) ? su * rfan / (nu * n) : 0.f;
-  for (int i = threadIdx.x; i < fan; i += 256) {
-    const float x = to_f32<TW_>(wr[i]);
-    const int c = i / taps;
-    const float sc = in_split > 0 ? ((g * Cg + c < in_split) ? in_s0 : in_s1) : 1.0f;
-    const float v = (s / nu) * (gr[i] * sc - x * k);
-    float* dst = dw + (size_t)os * fan + i;
-    *dst = accumulate ? *dst + v : v;
-  }
-  // d(loss)/d(gain parameter): g_eff = gain * (*gain_ptr)
-  if (dgain && threadIdx.x == 0) atomicAdd(dgain, gain * su * rfan / nu);
+  wprep_bwd_row<TW_>(dwp, w, gain_ptr, gain, dw, dgain, Cout, Cg, taps, G, normalize, qk_d, eps, in_split, in_s0, in_s1, accumulate, blockIdx.x,
+                     scratch);
 }
 
 // Backward of the small-M linear layers (emb_linear*: c = 1 + x @ w'^T at M = batch, reference unet_edm2_b4.py:121 through

@@ -5,44 +5,17 @@
 #include <cstdlib>
 
 #include "conv_params.hpp"
+#include "wpath_rows.hpp"
 
 namespace ddx {
 
-// one workgroup per (destination) output channel
+// one workgroup per (destination) output channel; row bodies in wpath_rows.hpp
 template <typename TW_, typename TP>
 __global__ __launch_bounds__(256) void wprep_kernel(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr,
                                                     float gain, int Cout, int Cg, int taps, int G, int CK, int normalize,
                                                     int qk_d, float eps, int in_split, float in_s0, float in_s1) {
   __shared__ float scratch[4];
-  const int od = blockIdx.x;
-  const int Ng = Cout / G, NgP = (Ng + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
-  const int g = od / Ng, n = od - g * Ng;
-  int os = od;
-  if (qk_d > 0) {  // destination (head, s, d) <- source (head, d, s)
-    const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
-    const int s = rem / qk_d, dd = rem - s * qk_d;
-    os = head * 2 * qk_d + dd * 2 + s;
-  }
-  const int fan = Cg * taps;
-  const TW_* wr = w + (size_t)os * fan;
-  float inv = 1.f;
-  if (normalize) {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
-    ss = block_sum_256(ss, scratch);
-    inv = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
-  }
-  float gn = gain;
-  if (gain_ptr) gn *= *gain_ptr;
-  const float sc = gn / sqrtf((float)fan);
-  for (int i = threadIdx.x; i < fan; i += 256) {
-    const int c = i / taps, tap = i - c * taps;
-    float x = to_f32<TW_>(wr[i]);
-    if (normalize) x = x / inv;
-    float scc = sc;
-    if (in_split > 0) scc *= (g * Cg + c < in_split) ? in_s0 : in_s1;  // mp_cat scales folded into a linear consumer
-    wp[wp_index(g, n, tap, c, nchunk, taps, NgP, CK)] = from_f32<TP>(x * scc);
-  }
+  wprep_row<TW_, TP>(w, wp, gain_ptr, gain, Cout, Cg, taps, G, CK, normalize, qk_d, eps, in_split, in_s0, in_s1, blockIdx.x, scratch);
 }
 
 // ---- data-gradient (transposed) preparation: per-row scale first, then one workgroup per destination row (g, c)
@@ -50,50 +23,20 @@ template <typename TW_>
 __global__ __launch_bounds__(256) void wprep_rowscale_kernel(const TW_* __restrict__ w, float* __restrict__ row_scale, const float* gain_ptr,
                                                              float gain, int fan, int normalize, float eps) {
   __shared__ float scratch[4];
-  const TW_* wr = w + (size_t)blockIdx.x * fan;
-  float inv = 1.f;
-  if (normalize) {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
-    ss = block_sum_256(ss, scratch);
-    inv = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
-  }
-  float gn = gain;
-  if (gain_ptr) gn *= *gain_ptr;
-  if (threadIdx.x == 0) row_scale[blockIdx.x] = gn / sqrtf((float)fan) / inv;
+  wprep_rowscale_row<TW_>(w, row_scale, gain_ptr, gain, fan, normalize, eps, blockIdx.x, scratch);
 }
 
 template <typename TW_, typename TP>
 __global__ __launch_bounds__(256) void wprep_transposed_kernel(const TW_* __restrict__ w, TP* __restrict__ wp, const float* __restrict__ row_scale,
                                                                int Cout, int Cg, int taps, int G, int CK, int qk_d, int in_split,
                                                                float in_s0, float in_s1) {
-  const int ci = blockIdx.x;  // destination row = input channel of the forward conv
-  const int Ng = Cout / G, CgP = (Cg + 31) / 32 * 32, nchunk = (Ng + CK - 1) / CK;
-  const int g = ci / Cg, c = ci - g * Cg;
-  const float cscale = in_split > 0 ? (ci < in_split ? in_s0 : in_s1) : 1.0f;
-  for (int i = threadIdx.x; i < Ng * taps; i += 256) {
-    const int n = i / taps, tap = i - n * taps;
-    const int od = g * Ng + n;
-    int os = od;
-    if (qk_d > 0) {
-      const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
-      const int s = rem / qk_d, dd = rem - s * qk_d;
-      os = head * 2 * qk_d + dd * 2 + s;
-    }
-    const float x = to_f32<TW_>(w[((size_t)os * Cg + c) * taps + tap]) * row_scale[os] * cscale;
-    wp[wp_index(g, c, taps - 1 - tap, n, nchunk, taps, CgP, CK)] = from_f32<TP>(x);
-  }
+  wprep_transposed_row<TW_, TP>(w, wp, row_scale, Cout, Cg, taps, G, CK, qk_d, in_split, in_s0, in_s1, blockIdx.x);
 }
 
 template <typename TW_>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(TW_* w, int64_t fan, float eps) {
   __shared__ float scratch[4];
-  TW_* wr = w + (size_t)blockIdx.x * fan;
-  float ss = 0.f;
-  for (int64_t i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
-  ss = block_sum_256(ss, scratch);
-  const float nrm = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
-  for (int64_t i = threadIdx.x; i < fan; i += 256) wr[i] = from_f32<TW_>(to_f32<TW_>(wr[i]) / nrm);
+  normalize_row<TW_>(w, fan, eps, blockIdx.x, scratch);
 }
 
 }  // namespace ddx

@@ -1,0 +1,128 @@
+// Row-level device functions of the weight path (reference src/modules/mp_tools.py:359-364 forward, :375-378 forced
+// normalisation) shared by the single-tensor kernels (conv.hip, backward.hip) and the multi-tensor launches (wpath.hip).
+// Every function is executed by ONE 256-thread workgroup for one row; `scratch` = 4 floats of LDS.
+#pragma once
+#include "conv_params.hpp"
+
+namespace ddx {
+
+// destination row od of the prepared weight -> source row of the master weight ((head, s, d) <- (head, d, s) for attn_qk)
+__device__ __forceinline__ int wpath_src_row(int od, int qk_d) {
+  if (qk_d <= 0) return od;
+  const int head = od / (2 * qk_d), rem = od - head * 2 * qk_d;
+  const int s = rem / qk_d, dd = rem - s * qk_d;
+  return head * 2 * qk_d + dd * 2 + s;
+}
+
+template <typename TW_, typename TP>
+__device__ __forceinline__ void wprep_row(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr, float gain, int Cout, int Cg,
+                                          int taps, int G, int CK, int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1,
+                                          int od, float* scratch) {
+  const int Ng = Cout / G, NgP = (Ng + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
+  const int g = od / Ng, n = od - g * Ng;
+  const int os = wpath_src_row(od, qk_d);
+  const int fan = Cg * taps;
+  const TW_* wr = w + (size_t)os * fan;
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
+    ss = block_sum_256(ss, scratch);
+    inv = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  }
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float sc = gn / sqrtf((float)fan);
+  for (int i = threadIdx.x; i < fan; i += 256) {
+    const int c = i / taps, tap = i - c * taps;
+    float x = to_f32<TW_>(wr[i]);
+    if (normalize) x = x / inv;
+    float scc = sc;
+    if (in_split > 0) scc *= (g * Cg + c < in_split) ? in_s0 : in_s1;  // mp_cat scales folded into a linear consumer
+    wp[wp_index(g, n, tap, c, nchunk, taps, NgP, CK)] = from_f32<TP>(x * scc);
+  }
+}
+
+// row_scale[o] = gain_eff / sqrt(fan) / (normalize ? eps + |w_o| / sqrt(fan) : 1)
+template <typename TW_>
+__device__ __forceinline__ void wprep_rowscale_row(const TW_* __restrict__ w, float* __restrict__ row_scale, const float* gain_ptr, float gain,
+                                                   int fan, int normalize, float eps, int row, float* scratch) {
+  const TW_* wr = w + (size_t)row * fan;
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
+    ss = block_sum_256(ss, scratch);
+    inv = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  }
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  if (threadIdx.x == 0) row_scale[row] = gn / sqrtf((float)fan) / inv;
+}
+
+// data-gradient (transposed) preparation, destination row ci = input channel of the forward conv
+template <typename TW_, typename TP>
+__device__ __forceinline__ void wprep_transposed_row(const TW_* __restrict__ w, TP* __restrict__ wp, const float* __restrict__ row_scale, int Cout,
+                                                     int Cg, int taps, int G, int CK, int qk_d, int in_split, float in_s0, float in_s1, int ci) {
+  const int Ng = Cout / G, CgP = (Cg + 31) / 32 * 32, nchunk = (Ng + CK - 1) / CK;
+  const int g = ci / Cg, c = ci - g * Cg;
+  const float cscale = in_split > 0 ? (ci < in_split ? in_s0 : in_s1) : 1.0f;
+  for (int i = threadIdx.x; i < Ng * taps; i += 256) {
+    const int n = i / taps, tap = i - n * taps;
+    const int os = wpath_src_row(g * Ng + n, qk_d);
+    const float x = to_f32<TW_>(w[((size_t)os * Cg + c) * taps + tap]) * row_scale[os] * cscale;
+    wp[wp_index(g, c, taps - 1 - tap, n, nchunk, taps, CgP, CK)] = from_f32<TP>(x);
+  }
+}
+
+template <typename TW_>
+__device__ __forceinline__ void normalize_row(TW_* w, int64_t fan, float eps, int64_t row, float* scratch) {
+  TW_* wr = w + (size_t)row * fan;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < fan; i += 256) { const float x = to_f32<TW_>(wr[i]); ss += x * x; }
+  ss = block_sum_256(ss, scratch);
+  const float nrm = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  for (int64_t i = threadIdx.x; i < fan; i += 256) wr[i] = from_f32<TW_>(to_f32<TW_>(wr[i]) / nrm);
+}
+
+// gradient w.r.t. the master weight row from the gradient w.r.t. the prepared weight (natural layout), destination row od
+template <typename TW_>
+__device__ __forceinline__ void wprep_bwd_row(const float* __restrict__ dwp, const TW_* __restrict__ w, const float* gain_ptr, float gain,
+                                              float* __restrict__ dw, float* __restrict__ dgain, int Cout, int Cg, int taps, int G, int normalize,
+                                              int qk_d, float eps, int in_split, float in_s0, float in_s1, int accumulate, int od, float* scratch) {
+  const int Ng = Cout / G;
+  const int g = od / Ng;
+  const int os = wpath_src_row(od, qk_d);
+  const int fan = Cg * taps;
+  const TW_* wr = w + (size_t)os * fan;
+  const float* gr = dwp + (size_t)od * fan;
+  float ss = 0.f, su = 0.f;
+  for (int i = threadIdx.x; i < fan; i += 256) {
+    const float x = to_f32<TW_>(wr[i]);
+    const int c = i / taps;
+    const float sc = in_split > 0 ? ((g * Cg + c < in_split) ? in_s0 : in_s1) : 1.0f;
+    ss += x * x;
+    su += gr[i] * sc * x;
+  }
+  ss = block_sum_256(ss, scratch);
+  su = block_sum_256(su, scratch);
+  const float rfan = sqrtf(1.0f / (float)fan);
+  const float n = sqrtf(ss);
+  const float nu = normalize ? eps + n * rfan : 1.0f;
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float s = gn * rfan;
+  const float k = (normalize && n > 0.f) ? su * rfan / (nu * n) : 0.f;
+  for (int i = threadIdx.x; i < fan; i += 256) {
+    const float x = to_f32<TW_>(wr[i]);
+    const int c = i / taps;
+    const float sc = in_split > 0 ? ((g * Cg + c < in_split) ? in_s0 : in_s1) : 1.0f;
+    const float v = (s / nu) * (gr[i] * sc - x * k);
+    float* dst = dw + (size_t)os * fan + i;
+    *dst = accumulate ? *dst + v : v;
+  }
+  // d(loss)/d(gain parameter): g_eff = gain * (*gain_ptr)
+  if (dgain && threadIdx.x == 0) atomicAdd(dgain, gain * su * rfan / nu);
+}
+
+}  // namespace ddx

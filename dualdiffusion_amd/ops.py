@@ -196,18 +196,29 @@ def wprep_bwd(pw: PreparedWeight, dwp: torch.Tensor, dw: Optional[torch.Tensor] 
 
 
 def linear_small_bwd(dc: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, groups: int = 1, gain_ptr: Optional[torch.Tensor] = None,
-                     normalize: bool = False, dx: Optional[torch.Tensor] = None):
+                     normalize: bool = False, dx: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+                     dwp: Optional[torch.Tensor] = None):
     """Backward of c = const + x @ w'^T (w' = weight path of `weight` [O, K/groups]): returns (dw, dgain) for the master weight
-    and the gain parameter; accumulates the input gradient into dx [M, K] (fp32) when given."""
+    and the gain parameter; accumulates the input gradient into dx [M, K] (fp32) when given.
+    With `row_scale` and `dwp` given (training.weight_bank: the row scales were computed for every layer at once and the
+    weight-path backward runs later for every layer at once) only the gradient w.r.t. the prepared weight is written, into
+    `dwp`, and (None, None) is returned."""
     M, O = dc.shape
     K = x.shape[1]
     w2 = weight.reshape(O, -1)
-    rs = torch.empty(O, dtype=torch.float32, device=dc.device)
-    check(lib().ddx_wprep_rowscale(ptr(w2), dtype_code(w2.dtype), ptr(rs), ptr(gain_ptr), 1.0, O, w2.shape[1], int(normalize), current_stream()),
-          "wprep_rowscale")
-    dwp = torch.empty(O, w2.shape[1], dtype=torch.float32, device=dc.device)
+    deferred = row_scale is not None and dwp is not None
+    if deferred:
+        rs = row_scale
+        dwp = dwp.view(O, w2.shape[1])
+    else:
+        rs = torch.empty(O, dtype=torch.float32, device=dc.device)
+        check(lib().ddx_wprep_rowscale(ptr(w2), dtype_code(w2.dtype), ptr(rs), ptr(gain_ptr), 1.0, O, w2.shape[1], int(normalize), current_stream()),
+              "wprep_rowscale")
+        dwp = torch.empty(O, w2.shape[1], dtype=torch.float32, device=dc.device)
     check(lib().ddx_linear_small_bwd(ptr(dc), ptr(x), x.stride(0), ptr(w2), dtype_code(w2.dtype), ptr(rs), ptr(dwp), ptr(dx), M, O, K, groups,
                                      current_stream()), "linear_small_bwd")
+    if deferred:
+        return None, None
     d = L.WPrepDesc(w=ptr(w2), wp=None, gain_ptr=ptr(gain_ptr), gain=1.0, w_dtype=dtype_code(w2.dtype), wp_dtype=L.DDX_F32, Cout=O, Cg=w2.shape[1],
                     ksize=1, groups=groups, CK=32, normalize=int(normalize), qk_head_dim=0, in_split=0, in_scale0=1.0, in_scale1=1.0, transpose=0,
                     row_scale=None)

@@ -46,6 +46,10 @@ class BlockWeightsT:
     emb_linear_v: Optional[torch.Tensor] = None
     emb_gain_v: Optional[torch.Tensor] = None
     heads: int = 0
+    # training.weight_bank: prepared weights come from / weight gradients go to the bank's persistent buffers under the
+    # state-dict keys `<prefix>.<layer>.weight`; the weight-path backward then runs once for all layers (bank.backward())
+    bank: Optional[object] = None
+    prefix: str = ""
 
 
 @dataclass
@@ -69,6 +73,40 @@ class BlockTape:
     clip: float
     pw: dict = field(default_factory=dict)
     attn: Optional[dict] = None       # c_qk, c_v, qk, v, ao, xa, attn_t
+
+
+def _prep(w: BlockWeightsT, key: str, weight: torch.Tensor, groups: int, dt, **kw):
+    """Forward prepared weight of layer `key`: the bank's (filled by bank.prepare()) or prepared here."""
+    if w.bank is not None:
+        return w.bank.pw[f"{w.prefix}.{key}.weight"]
+    return ops.wprep(weight, groups, dt, normalize=True, **kw)
+
+
+def _prep_t(w: BlockWeightsT, key: str, weight: torch.Tensor, groups: int, dt, **kw):
+    """Data-gradient prepared weight of layer `key`."""
+    if w.bank is not None:
+        return w.bank.pwt[f"{w.prefix}.{key}.weight"]
+    return ops.wprep(weight, groups, dt, normalize=True, transpose=True, **kw)
+
+
+def _wgrad(w: BlockWeightsT, key: str, pw, dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, x1: Optional[torch.Tensor] = None):
+    """Master-weight gradient of conv layer `key` (with a bank: the GEMM writes the bank's dwp slot and the returned view is
+    filled by bank.backward())."""
+    if w.bank is not None:
+        name = f"{w.prefix}.{key}.weight"
+        ops.conv2d_wgrad(dy, x0, groups, ksize, x1=x1, out=w.bank.dwp[name])
+        return w.bank.dw[name]
+    return ops.wprep_bwd(pw, ops.conv2d_wgrad(dy, x0, groups, ksize, x1=x1))
+
+
+def _linear_bwd(w: BlockWeightsT, key: str, dc: torch.Tensor, emb: torch.Tensor, weight: torch.Tensor, groups: int, gain: torch.Tensor,
+                demb: Optional[torch.Tensor]):
+    """(dw, dgain) of an emb_linear* layer; accumulates the embedding gradient into demb."""
+    if w.bank is not None:
+        name = f"{w.prefix}.{key}.weight"
+        ops.linear_small_bwd(dc, emb, weight, groups, gain, True, demb, row_scale=w.bank.rs[name], dwp=w.bank.dwp[name])
+        return w.bank.dw[name], w.bank.dgain[name]
+    return ops.linear_small_bwd(dc, emb, weight, groups, gain, True, demb)
 
 
 def _resample(x: torch.Tensor, mode: str) -> torch.Tensor:
@@ -100,12 +138,12 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     c = torch.empty(B, Cmid, dtype=torch.float32, device=in0.device)
     table = ops.make_linear_jobs([(w.emb_linear, gain_ptr, c, 1.0, 1.0, G, True)], in0.device)
     ops.linear_small(table, 1, Cmid, emb, B, w.emb_linear.dtype)
-    pw = {"res0": ops.wprep(w.conv_res0, G, dt, normalize=True), "res1": ops.wprep(w.conv_res1, G, dt, normalize=True)}
+    pw = {"res0": _prep(w, "conv_res0", w.conv_res0, G, dt), "res1": _prep(w, "conv_res1", w.conv_res1, G, dt)}
     xs = x1 = None
     if flavor == "enc":
         assert src1 is None and s0 == 1.0
         if w.conv_skip is not None:
-            pw["skip"] = ops.wprep(w.conv_skip, 1, dt, normalize=True)
+            pw["skip"] = _prep(w, "conv_skip", w.conv_skip, 1, dt)
             xs = ops.conv2d(src0, pw["skip"])
         else:
             xs = src0
@@ -115,7 +153,7 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     else:
         y0 = ops.conv2d(src0, pw["res0"], src1=src1, scale0=s0, scale1=s1, prologue=PRO_SILU)
         if w.conv_skip is not None:
-            pw["skip"] = ops.wprep(w.conv_skip, 1, dt, normalize=True, in_split=C0 if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
+            pw["skip"] = _prep(w, "conv_skip", w.conv_skip, 1, dt, in_split=C0 if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
             sk = ops.conv2d(src0, pw["skip"], src1=src1)
         else:
             assert src1 is None and s0 == 1.0
@@ -132,9 +170,9 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     table = ops.make_linear_jobs([(w.emb_linear_qk, w.emb_gain_qk.reshape(1), c_qk, 1.0, 1.0, 1, True),
                                   (w.emb_linear_v, w.emb_gain_v.reshape(1), c_v, 1.0, 1.0, 1, True)], in0.device)
     ops.linear_small(table, 2, Cout, emb, B, w.emb_linear_qk.dtype)
-    pw["qk"] = ops.wprep(w.attn_qk, 1, dt, normalize=True, qk_head_dim=Cout // w.heads)
-    pw["v"] = ops.wprep(w.attn_v, 1, dt, normalize=True)
-    pw["proj"] = ops.wprep(w.attn_proj, 1, dt, normalize=True)
+    pw["qk"] = _prep(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=Cout // w.heads)
+    pw["v"] = _prep(w, "attn_v", w.attn_v, 1, dt)
+    pw["proj"] = _prep(w, "attn_proj", w.attn_proj, 1, dt)
     qk = ops.conv2d(out, pw["qk"], prologue=PRO_SCALE, chan_scale=c_qk)
     vv = ops.conv2d(out, pw["v"])
     ao = ops.attention(qk, vv, w.heads)
@@ -156,54 +194,53 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         # xa = clip(mp_sum(out, attn_proj(ap), t)), ap = mp_silu(ao * c_v)
         dout_res, dyp = ops.mpsum_clip_bwd(dout, a["xa"], a["attn_t"], a["clip"])
         ap = ops.silu_scale_fwd(a["ao"], a["c_v"])
-        g["dw_attn_proj"] = ops.wprep_bwd(t.pw["proj"], ops.conv2d_wgrad(dyp, ap, 1, 1))
-        dap = ops.conv2d(dyp, ops.wprep(w.attn_proj, 1, dt, normalize=True, transpose=True))
+        g["dw_attn_proj"] = _wgrad(w, "attn_proj", t.pw["proj"], dyp, ap, 1, 1)
+        dap = ops.conv2d(dyp, _prep_t(w, "attn_proj", w.attn_proj, 1, dt))
         dc_v = torch.zeros_like(a["c_v"])
         dao = ops.silu_scale_bwd(dap, a["ao"], a["c_v"], 1.0, dc_v)
-        g["dw_emb_linear_v"], g["demb_gain_v"] = ops.linear_small_bwd(dc_v, t.emb, w.emb_linear_v, 1, w.emb_gain_v.reshape(1), True, demb)
+        g["dw_emb_linear_v"], g["demb_gain_v"] = _linear_bwd(w, "emb_linear_v", dc_v, t.emb, w.emb_linear_v, 1, w.emb_gain_v.reshape(1), demb)
         dqk, dv = attention_backward(a["qk"], a["v"], dao, w.heads)
         # v = attn_v(out);  qk = attn_qk(out * c_qk) with the (head, {q,k}, d) row order of the forward preparation
-        g["dw_attn_v"] = ops.wprep_bwd(t.pw["v"], ops.conv2d_wgrad(dv, t.out, 1, 1))
-        dout_v = ops.conv2d(dv, ops.wprep(w.attn_v, 1, dt, normalize=True, transpose=True))
+        g["dw_attn_v"] = _wgrad(w, "attn_v", t.pw["v"], dv, t.out, 1, 1)
+        dout_v = ops.conv2d(dv, _prep_t(w, "attn_v", w.attn_v, 1, dt))
         xs_qk = ops.silu_scale_fwd(t.out, a["c_qk"], 1.0, act=False)
-        g["dw_attn_qk"] = ops.wprep_bwd(t.pw["qk"], ops.conv2d_wgrad(dqk, xs_qk, 1, 1))
-        dxs = ops.conv2d(dqk, ops.wprep(w.attn_qk, 1, dt, normalize=True, transpose=True, qk_head_dim=t.out.shape[-1] // w.heads))
+        g["dw_attn_qk"] = _wgrad(w, "attn_qk", t.pw["qk"], dqk, xs_qk, 1, 1)
+        dxs = ops.conv2d(dqk, _prep_t(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=t.out.shape[-1] // w.heads))
         dc_qk = torch.zeros_like(a["c_qk"])
         dout_qk = ops.silu_scale_bwd(dxs, t.out, a["c_qk"], 1.0, dc_qk, add=dout_v, act=False)
-        g["dw_emb_linear_qk"], g["demb_gain_qk"] = ops.linear_small_bwd(dc_qk, t.emb, w.emb_linear_qk, 1, one, True, demb)
+        g["dw_emb_linear_qk"], g["demb_gain_qk"] = _linear_bwd(w, "emb_linear_qk", dc_qk, t.emb, w.emb_linear_qk, 1, one, demb)
         dout = ops.add3(dout_res, dout_qk)
     # out = clip(mp_sum(sk, y1, t))
     dsk, dy1 = ops.mpsum_clip_bwd(dout, t.out, t.res_t, t.clip)
     # y1 = conv_res1(a1), a1 = mp_silu(y0 * c)
     a1 = ops.silu_scale_fwd(t.y0, t.c)
-    g["dw_conv_res1"] = ops.wprep_bwd(t.pw["res1"], ops.conv2d_wgrad(dy1, a1, G, 3))
-    da1 = ops.conv2d(dy1, ops.wprep(w.conv_res1, G, dt, normalize=True, transpose=True))
+    g["dw_conv_res1"] = _wgrad(w, "conv_res1", t.pw["res1"], dy1, a1, G, 3)
+    da1 = ops.conv2d(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt))
     dc = torch.zeros_like(t.c)
     dy0 = ops.silu_scale_bwd(da1, t.y0, t.c, 1.0, dc)
     # c = emb_linear(emb) * emb_gain + 1
-    g["dw_emb_linear"], g["demb_gain"] = ops.linear_small_bwd(dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), True, demb)
+    g["dw_emb_linear"], g["demb_gain"] = _linear_bwd(w, "emb_linear", dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), demb)
     g["dc"] = dc
     if t.flavor == "enc":
         a0 = ops.silu_scale_fwd(t.x1)
-        g["dw_conv_res0"] = ops.wprep_bwd(t.pw["res0"], ops.conv2d_wgrad(dy0, a0, G, 3))
-        da0 = ops.conv2d(dy0, ops.wprep(w.conv_res0, G, dt, normalize=True, transpose=True))
+        g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a0, G, 3)
+        da0 = ops.conv2d(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt))
         dx1 = ops.silu_scale_bwd(da0, t.x1, None, 1.0, add=dsk)
         dxs = ops.pixelnorm_bwd(dx1, t.xs)
         if w.conv_skip is not None:
-            g["dw_conv_skip"] = ops.wprep_bwd(t.pw["skip"], ops.conv2d_wgrad(dxs, t.src0, 1, 1))
-            dsrc0 = ops.conv2d(dxs, ops.wprep(w.conv_skip, 1, dt, normalize=True, transpose=True))
+            g["dw_conv_skip"] = _wgrad(w, "conv_skip", t.pw["skip"], dxs, t.src0, 1, 1)
+            dsrc0 = ops.conv2d(dxs, _prep_t(w, "conv_skip", w.conv_skip, 1, dt))
         else:
             dsrc0 = dxs
         dsrc1 = None
     else:
         a00 = ops.silu_scale_fwd(t.src0, None, t.s0)
         a01 = ops.silu_scale_fwd(t.src1, None, t.s1) if C1 else None
-        g["dw_conv_res0"] = ops.wprep_bwd(t.pw["res0"], ops.conv2d_wgrad(dy0, a00, G, 3, x1=a01))
-        da0 = ops.conv2d(dy0, ops.wprep(w.conv_res0, G, dt, normalize=True, transpose=True))
+        g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a00, G, 3, x1=a01)
+        da0 = ops.conv2d(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt))
         if w.conv_skip is not None:
-            g["dw_conv_skip"] = ops.wprep_bwd(t.pw["skip"], ops.conv2d_wgrad(dsk, t.src0, 1, 1, x1=t.src1))
-            dxs = ops.conv2d(dsk, ops.wprep(w.conv_skip, 1, dt, normalize=True, transpose=True, in_split=C0 if C1 else 0,
-                                            in_scale0=t.s0, in_scale1=t.s1))
+            g["dw_conv_skip"] = _wgrad(w, "conv_skip", t.pw["skip"], dsk, t.src0, 1, 1, x1=t.src1)
+            dxs = ops.conv2d(dsk, _prep_t(w, "conv_skip", w.conv_skip, 1, dt, in_split=C0 if C1 else 0, in_scale0=t.s0, in_scale1=t.s1))
         else:
             dxs = dsk
         dsrc0 = ops.silu_scale_bwd(da0[..., :C0], t.src0, None, t.s0, add=dxs[..., :C0])

@@ -55,9 +55,18 @@ class UNetTrainStep:
         world = _world_size()
         loss, grads = self.trainer.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation,
                                                self.input_perturbation)
-        grads = allreduce_gradients({k: grads[k] for k in self.params})
+        missing = [k for k in self.params if k not in grads]
+        if missing:
+            raise RuntimeError(f"UNetTrainStep: no gradient for {missing[:4]}")
+        if world > 1:                       # every gradient already lives in the trainer's flat bucket: one all-reduce, no gather
+            import torch.distributed as dist
+            dist.all_reduce(self.trainer.grad_flat, op=dist.ReduceOp.SUM)
         lr = self.lr_cfg.learning_rate * lr_multiplier(self.lr_cfg, self.global_step)
         grad_norm = self.opt.step(grads, lr, self.opt.cfg.loss_scale / world)
-        self.unet.normalize_weights()           # trainer.py:375-381: forced weight normalisation after every optimizer step
+        # trainer.py:375-381: forced weight normalisation after every optimizer step (one launch over the weight bank)
+        if self.trainer.bank is not None:
+            self.trainer.bank.normalize()
+        else:
+            self.unet.normalize_weights()
         self.global_step += 1
         return {"loss": loss, "grad_norm": grad_norm, "lr": lr}

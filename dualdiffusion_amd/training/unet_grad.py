@@ -19,12 +19,13 @@ from .. import ops
 from ..engine import mp_cat_weights
 from .._lib import DDXError, check, current_stream, dtype_code, lib, ptr
 from .block_grad import BlockWeightsT, block_backward, block_forward_train
+from .weight_bank import BankEntry, WeightBank
 
 
-def _block_weights(blk, groups: int) -> BlockWeightsT:
+def _block_weights(blk, groups: int, bank=None, prefix: str = "") -> BlockWeightsT:
     w = BlockWeightsT(conv_res0=blk.conv_res0.weight.data, conv_res1=blk.conv_res1.weight.data, emb_linear=blk.emb_linear.weight.data,
                       emb_gain=blk.emb_gain.data.reshape(1), conv_skip=blk.conv_skip.weight.data if blk.conv_skip is not None else None,
-                      groups=groups)
+                      groups=groups, bank=bank, prefix=prefix)
     if blk.use_attention:
         w.attn_qk, w.attn_v, w.attn_proj = blk.attn_qk.weight.data, blk.attn_v.weight.data, blk.attn_proj.weight.data
         w.emb_linear_qk, w.emb_linear_v = blk.emb_linear_qk.weight.data, blk.emb_linear_v.weight.data
@@ -43,6 +44,87 @@ class UNetTrainer:
             raise DDXError("UNetTrainer: module must be on the ROCm device with float32 (master) parameters")
         self.u = unet
         self.tape: Optional[dict] = None
+        # one flat fp32 gradient bucket for every parameter (tensors first, the scalar gains at the end): the weight bank writes
+        # the master-weight gradients straight into it, the all-reduce and the optimizer read it without a gather copy
+        named = list(unet.named_parameters())
+        order = [k for k, p in named if p.ndim > 0] + [k for k, p in named if p.ndim == 0]
+        sizes = {k: p.numel() for k, p in named}
+        self.grad_flat = torch.zeros(sum(sizes.values()), dtype=torch.float32, device=unet.device)
+        self.grad_views, off = {}, 0
+        shapes = {k: p.shape for k, p in named}
+        for k in order:
+            self.grad_views[k] = self.grad_flat[off:off + sizes[k]].view(shapes[k])
+            off += sizes[k]
+        self._scalar_tail = self.grad_flat[sum(sizes[k] for k in order if len(shapes[k]) > 0):]
+        self.bank: Optional[WeightBank] = None
+        self._bank_key = None
+
+    # ------------------------------------------------------------------------------------------------ weight bank
+    def _build_bank(self, B: int, H: int, W: int) -> None:
+        """Every MPConv weight of the module as one job table (training.weight_bank) for input size (B, H, W)."""
+        u, cfg = self.u, self.u.config
+        G = cfg.mlp_groups
+        entries, seen = [], set()
+
+        def add(name, module, **kw):
+            entries.append(BankEntry(name=name + ".weight", weight=module.weight.data, **kw))
+            seen.add(name + ".weight")
+
+        def add_block(prefix, blk, npix, in_split=0, s0=1.0, s1=1.0):
+            add(prefix + ".conv_res0", blk.conv_res0, groups=G, npix=npix)
+            add(prefix + ".conv_res1", blk.conv_res1, groups=G, npix=npix)
+            if blk.conv_skip is not None:
+                add(prefix + ".conv_skip", blk.conv_skip, npix=npix, in_split=in_split, in_scale0=s0, in_scale1=s1)
+            lin = dict(prep=False, transpose=False)
+            add(prefix + ".emb_linear", blk.emb_linear, groups=G, gain=blk.emb_gain.data, gain_name=prefix + ".emb_gain", **lin)
+            if blk.use_attention:
+                add(prefix + ".attn_qk", blk.attn_qk, npix=npix, qk_head_dim=blk.out_channels // blk.num_heads)
+                add(prefix + ".attn_v", blk.attn_v, npix=npix)
+                add(prefix + ".attn_proj", blk.attn_proj, npix=npix)
+                add(prefix + ".emb_linear_qk", blk.emb_linear_qk, gain=blk.emb_gain_qk.data, gain_name=prefix + ".emb_gain_qk", **lin)
+                add(prefix + ".emb_linear_v", blk.emb_linear_v, gain=blk.emb_gain_v.data, gain_name=prefix + ".emb_gain_v", **lin)
+
+        def out_hw(blk, h, w):
+            return (h // 2, w // 2) if blk.resample_mode == "down" else ((h * 2, w * 2) if blk.resample_mode == "up" else (h, w))
+
+        h, w = H, W
+        cx = u.enc["conv_in"].out_channels
+        skip_ch = [cx]
+        for name, blk in u.enc.items():
+            if name == "conv_in":
+                continue
+            h, w = out_hw(blk, h, w)
+            add_block("enc." + name, blk, B * h * w)
+            cx = blk.out_channels
+            skip_ch.append(cx)
+        for name, blk in u.dec.items():
+            h, w = out_hw(blk, h, w)
+            if "layer" in name:
+                cs = skip_ch.pop()
+                s0, s1 = mp_cat_weights(cx, cs, cfg.concat_balance)
+                add_block("dec." + name, blk, B * h * w, in_split=cx, s0=s0, s1=s1)
+            else:
+                add_block("dec." + name, blk, B * h * w)
+            cx = blk.out_channels
+        # the remaining weight-normalised layers (conv_in / conv_out / embeddings) only take part in normalize()
+        for mname, m in u.named_modules():
+            if hasattr(m, "disable_weight_norm") and hasattr(m, "weight") and mname + ".weight" not in seen and not m.disable_weight_norm:
+                entries.append(BankEntry(name=mname + ".weight", weight=m.weight.data, prep=False, transpose=False, grad=False))
+        self.bank = WeightBank(entries, torch.bfloat16, self.grad_views)
+        self._bank_key = (B, H, W)
+
+    def store_grads(self, grads: dict) -> dict:
+        """Move gradients computed outside the bank into their slots of the flat bucket; returns {name: bucket view}."""
+        out = {}
+        for k, v in grads.items():
+            view = self.grad_views.get(k)
+            if view is None:
+                out[k] = v
+                continue
+            if v.data_ptr() != view.data_ptr():
+                view.copy_(v.reshape(view.shape))
+            out[k] = view
+        return out
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor,
@@ -55,6 +137,10 @@ class UNetTrainer:
         sig = sigma.flatten().to(dev, torch.float32).contiguous()
         emb_in = embeddings.to(dev, torch.float32).contiguous()
         lnf = u.get_ln_freqs_rows(format, B, H, W).to(dev)
+        if self._bank_key != (B, H, W):
+            self._build_bank(B, H, W)
+        bank = self.bank
+        bank.prepare()
         # front end
         x0 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
         ops.unet_input_prep(x_pre, sig, lnf, x0, cfg.sigma_data)
@@ -75,7 +161,8 @@ class UNetTrainer:
         for name, blk in u.enc.items():
             if name == "conv_in":
                 continue
-            x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G), flavor="enc", resample=blk.resample_mode, **kw)
+            x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "enc." + name), flavor="enc",
+                                       resample=blk.resample_mode, **kw)
             tapes.append(("enc." + name, blk, t, None))
             skips.append(x)
         n_enc = len(skips)
@@ -85,10 +172,12 @@ class UNetTrainer:
                 si = stack.pop()
                 sk = skips[si]
                 s0, s1 = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
-                x, t = block_forward_train(x, sk, s0, s1, emb, _block_weights(blk, G), flavor="dec", resample=blk.resample_mode, **kw)
+                x, t = block_forward_train(x, sk, s0, s1, emb, _block_weights(blk, G, bank, "dec." + name), flavor="dec",
+                                           resample=blk.resample_mode, **kw)
                 tapes.append(("dec." + name, blk, t, si))
             else:
-                x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G), flavor="dec", resample=blk.resample_mode, **kw)
+                x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "dec." + name), flavor="dec",
+                                           resample=blk.resample_mode, **kw)
                 tapes.append(("dec." + name, blk, t, None))
         # conv_out on an 8-row padded weight (4 output channels do not fill a 16-byte NHWC vector)
         w_out = u.conv_out.weight.data
@@ -112,6 +201,7 @@ class UNetTrainer:
             raise DDXError("UNetTrainer.backward before forward")
         B, H, W, Co = t["B"], t["H"], t["W"], t["Co"]
         grads: dict = {}
+        self._scalar_tail.zero_()          # the gain gradients are accumulated with atomics (bank.backward, out_gain)
         # D = c_skip * x_in + c_out * y  ->  dy = c_out[b] * dD, NHWC bf16 with the 4 channels padded to one 16-byte vector
         dy8 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
         check(lib().ddx_unet_output_combine_bwd(ptr(dD.to(dev, torch.float32).contiguous()), ptr(t["sig"]), ptr(dy8), B, Co, H, W, 8, cfg.sigma_data,
@@ -153,7 +243,8 @@ class UNetTrainer:
         de0 = ops.lincomb3(torch.empty_like(dpre), dpre, (1 - tb) / nrm)
         grads["embeddings"] = ops.lincomb3(torch.empty_like(dpre), dpre, tb / nrm)
         grads["emb_noise.weight"], _ = ops.linear_small_bwd(de0, t["four"], u.emb_noise.weight.data, 1, None, True, None)
-        return grads
+        self.bank.backward()               # weight-path backward of every block layer at once (fills the bucket views handed out above)
+        return self.store_grads(grads)
 
     # ------------------------------------------------------------------------------------------------ one training batch
     def train_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
@@ -199,4 +290,4 @@ class UNetTrainer:
         du = (dE * (1 - t) / nrm).sum(dim=0, keepdim=True).contiguous()
         grads["emb_label.weight"], _ = ops.linear_small_bwd(dc, xn, w_c, 1, None, True, None)
         grads["emb_label_unconditional.weight"], _ = ops.linear_small_bwd(du, ones, w_u, 1, None, True, None)
-        return loss, grads
+        return loss, self.store_grads(grads)

@@ -1,0 +1,135 @@
+"""Weight bank: every MPConv weight of a module prepared / back-propagated / normalised in ONE launch per phase.
+
+The weight branch of reference MPConv.forward (src/modules/mp_tools.py:359-364: forced normalisation in training, the
+1/sqrt(fan_in) * gain scale, the cast to the activation dtype) and MPConv.normalize_weights (:375-378) run per layer in the
+reference (autograd).  Per optimizer step the default UNet needs them for 151 convs + 69 linear layers -- about 1100 launches
+of a few microseconds of payload each.  The bank keeps all device buffers of that path persistent (prepared weights for the
+forward and for the data gradient, row scales, the natural-layout gradient w.r.t. the prepared weights) and drives
+`ddx_wpath_multi` over one job table:
+    prepare()    PREP + ROWSCALE + TRANSPOSED       before the forward
+    backward()   BWD                                after all weight-gradient GEMMs wrote `dwp[name]`
+    normalize()  NORMALIZE                          after the optimizer step (trainer.py:375-381)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import _lib as L
+from .. import ops
+from .._lib import check, current_stream, dtype_code, lib, ptr
+
+
+@dataclass
+class BankEntry:
+    name: str                                   # state-dict key of the weight
+    weight: torch.Tensor                        # fp32 master weight on the device, [Cout, Cg, k, k] or [O, K / groups]
+    groups: int = 1
+    gain: Optional[torch.Tensor] = None         # learnable gain parameter (0-d / [1] fp32) multiplied into the weight
+    gain_name: Optional[str] = None             # its state-dict key (receives dgain)
+    qk_head_dim: int = 0
+    in_split: int = 0                           # mp_cat scales folded into a linear consumer (decoder conv_skip)
+    in_scale0: float = 1.0
+    in_scale1: float = 1.0
+    npix: int = 0                               # B*H*W the conv runs at (chunk-width choice); 0 = unknown
+    prep: bool = True                           # forward prepared buffer   (False: linear layers, used from the master weight)
+    transpose: bool = True                      # data-gradient prepared buffer
+    grad: bool = True                           # takes part in backward()
+    normalize: bool = True                      # forced weight normalisation (False: MPConv.disable_weight_norm)
+
+
+def _align(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
+class WeightBank:
+
+    def __init__(self, entries: list, dtype: torch.dtype, grad_views: dict) -> None:
+        """grad_views: {parameter name: fp32 view} the master-weight gradients (and gain gradients) are written to."""
+        self.entries, self.dtype = entries, dtype
+        dev = entries[0].weight.device
+        self.dev = dev
+        geo = []
+        wp_bytes = wpt_bytes = rs_floats = dwp_floats = 0
+        for e in entries:
+            w = e.weight
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.device != dev:
+                raise L.DDXError(f"WeightBank: {e.name} must be a contiguous float32 device tensor")
+            Cout, Cg = w.shape[0], w.shape[1]
+            ks = w.shape[2] if w.ndim == 4 else 1
+            Ng, Cin = Cout // e.groups, Cg * e.groups
+            CK = ops.pick_ck(Cg, ks, dtype, e.npix) if e.prep else 32
+            CKt = ops.pick_ck(Ng, ks, dtype, e.npix) if e.transpose else 32
+            nb = _align(lib().ddx_wprep_bytes(Cout, Cg, ks, e.groups, CK, dtype_code(dtype))) if e.prep else 0
+            nbt = _align(lib().ddx_wprep_bytes(Cin, Ng, ks, e.groups, CKt, dtype_code(dtype))) if e.transpose else 0
+            geo.append(dict(Cout=Cout, Cg=Cg, ks=ks, Ng=Ng, Cin=Cin, CK=CK, CKt=CKt, wp_off=wp_bytes, wpt_off=wpt_bytes, rs_off=rs_floats,
+                            dwp_off=dwp_floats, nb=nb, nbt=nbt))
+            wp_bytes += nb
+            wpt_bytes += nbt
+            rs_floats += _align(Cout, 64) if (e.transpose or e.grad) else 0
+            dwp_floats += _align(w.numel(), 64) if e.grad else 0
+        # zero-initialised: the padding rows / channels of the prepared layouts are never written afterwards
+        self.wp_flat = torch.zeros(max(wp_bytes, 1), dtype=torch.uint8, device=dev)
+        self.wpt_flat = torch.zeros(max(wpt_bytes, 1), dtype=torch.uint8, device=dev)
+        self.rs_flat = torch.zeros(max(rs_floats, 1), dtype=torch.float32, device=dev)
+        self.dwp_flat = torch.zeros(max(dwp_floats, 1), dtype=torch.float32, device=dev)
+        self.pw, self.pwt, self.rs, self.dwp, self.dw, self.dgain = {}, {}, {}, {}, {}, {}
+        jobs = (L.WPathJob * len(entries))()
+        rows = {ph: [0] for ph in range(5)}
+        self._keep = []
+        for i, (e, g) in enumerate(zip(entries, geo)):
+            w = e.weight
+            if e.prep:
+                buf = self.wp_flat[g["wp_off"]:g["wp_off"] + g["nb"]]
+                self.pw[e.name] = ops.PreparedWeight(buf, g["Cout"], g["Cg"], g["ks"], e.groups, g["CK"], dtype, None)
+            if e.transpose:
+                buft = self.wpt_flat[g["wpt_off"]:g["wpt_off"] + g["nbt"]]
+                self.pwt[e.name] = ops.PreparedWeight(buft, g["Cin"], g["Ng"], g["ks"], e.groups, g["CKt"], dtype, None)
+            if e.transpose or e.grad:
+                self.rs[e.name] = self.rs_flat[g["rs_off"]:g["rs_off"] + g["Cout"]]
+            gain_ptr = e.gain.reshape(1) if e.gain is not None else None
+            if e.grad:
+                self.dwp[e.name] = self.dwp_flat[g["dwp_off"]:g["dwp_off"] + w.numel()].view(w.shape)
+                self.dw[e.name] = grad_views[e.name]
+                if self.dw[e.name].numel() != w.numel() or self.dw[e.name].dtype != torch.float32:
+                    raise L.DDXError(f"WeightBank: gradient view of {e.name} does not match the weight")
+                if e.gain is not None:
+                    self.dgain[e.name] = grad_views[e.gain_name].reshape(1)
+            self._keep.append((w, gain_ptr))
+            jobs[i] = L.WPathJob(w=ptr(w), wp=ptr(self.pw[e.name].wp) if e.prep else None,
+                                 wp_t=ptr(self.pwt[e.name].wp) if e.transpose else None,
+                                 row_scale=ptr(self.rs[e.name]) if e.name in self.rs else None, gain_ptr=ptr(gain_ptr),
+                                 dwp=ptr(self.dwp[e.name]) if e.grad else None, dw=ptr(self.dw[e.name]) if e.grad else None,
+                                 dgain=ptr(self.dgain[e.name]) if e.name in self.dgain else None, gain=1.0,
+                                 Cout=g["Cout"], Cg=g["Cg"], ksize=g["ks"], groups=e.groups, CK=g["CK"], CK_t=g["CKt"],
+                                 normalize=int(e.normalize), qk_head_dim=e.qk_head_dim, in_split=e.in_split, in_scale0=e.in_scale0,
+                                 in_scale1=e.in_scale1)
+            part = {L.WPATH_NORMALIZE: g["Cout"] if e.normalize else 0, L.WPATH_PREP: g["Cout"] if e.prep else 0,
+                    L.WPATH_ROWSCALE: g["Cout"] if e.name in self.rs else 0, L.WPATH_TRANSPOSED: g["Cin"] if e.transpose else 0,
+                    L.WPATH_BWD: g["Cout"] if e.grad else 0}
+            for ph in range(5):
+                rows[ph].append(rows[ph][-1] + part[ph])
+        self.njobs = len(entries)
+        self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.prefix = {ph: torch.tensor(rows[ph], dtype=torch.int32).to(dev) for ph in range(5)}
+        self.total = {ph: rows[ph][-1] for ph in range(5)}
+
+    def _run(self, phase: int) -> None:
+        check(lib().ddx_wpath_multi(ptr(self.jobs), ptr(self.prefix[phase]), self.njobs, self.total[phase], phase, dtype_code(self.dtype),
+                                    current_stream()), "wpath_multi")
+
+    def prepare(self) -> None:
+        """Forward + data-gradient prepared weights and row scales of every entry from the current master weights."""
+        self._run(L.WPATH_PREP)
+        self._run(L.WPATH_ROWSCALE)
+        self._run(L.WPATH_TRANSPOSED)
+
+    def backward(self) -> None:
+        """dw[name] (and dgain) from dwp[name] for every entry; the gain-gradient slots must be zero on entry."""
+        self._run(L.WPATH_BWD)
+
+    def normalize(self) -> None:
+        self._run(L.WPATH_NORMALIZE)

@@ -187,6 +187,33 @@ int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma
  * Cpad) = c_out(sigma_b) * dD (NCHW fp32). */
 int ddx_unet_output_combine_bwd(const float* d_out_nchw, const float* sigma, void* dy_nhwc, int32_t B, int32_t C, int32_t H, int32_t W,
                                 int32_t Cpad, float sigma_data, int32_t dtype, ddx_stream stream);
+/* ------------------------------------------------------------------------------------------------
+ * Multi-tensor weight path (training): one launch per phase over a job table that lives on the device.
+ * Replaces, per optimizer step, the per-module calls of MPConv.forward's weight branch under autograd and of
+ * MPConv.normalize_weights (mp_tools.py:359-364, :375-378; trainer.py:375-381) for every layer at once.
+ * Master weights are fp32.  row_prefix[j] = first workgroup (row) of job j in THIS phase, row_prefix[njobs] = total_rows;
+ * a job that takes no part in a phase has zero rows there.  Rows per job: Cout (NORMALIZE, PREP, ROWSCALE, BWD),
+ * Cg * groups (TRANSPOSED).  BWD accumulates into *dgain with atomics: zero it first.
+ * ------------------------------------------------------------------------------------------------ */
+enum { DDX_WPATH_NORMALIZE = 0, DDX_WPATH_PREP = 1, DDX_WPATH_ROWSCALE = 2, DDX_WPATH_TRANSPOSED = 3, DDX_WPATH_BWD = 4 };
+
+typedef struct {
+  void* w;               /* fp32 master weight [Cout][Cg][k][k] (rewritten in place by NORMALIZE) */
+  void* wp;              /* PREP: forward prepared buffer (ddx_wprep_bytes(Cout, Cg, ...), CK) */
+  void* wp_t;            /* TRANSPOSED: data-gradient prepared buffer (ddx_wprep_bytes(Cg*groups, Cout/groups, ...), CK_t) */
+  float* row_scale;      /* ROWSCALE writes, TRANSPOSED reads: [Cout] */
+  const float* gain_ptr; /* learnable gain (device scalar) or NULL */
+  const float* dwp;      /* BWD: gradient w.r.t. the prepared weight, natural [Cout][Cg][k][k] fp32 */
+  float* dw;             /* BWD: gradient w.r.t. the master weight */
+  float* dgain;          /* BWD: gradient w.r.t. *gain_ptr (accumulated) or NULL */
+  float gain;
+  int32_t Cout, Cg, ksize, groups, CK, CK_t, normalize, qk_head_dim, in_split;
+  float in_scale0, in_scale1;
+} ddx_wpath_job;
+
+int ddx_wpath_multi(const ddx_wpath_job* jobs_dev, const int32_t* row_prefix_dev, int32_t njobs, int32_t total_rows, int32_t phase,
+                    int32_t wp_dtype, ddx_stream stream);
+
 /* Per-row factor of the weight path: row_scale[o] = gain_eff / sqrt(fan_in) / (normalize ? eps + |w_o| / sqrt(fan_in) : 1), so that
  * w' = w * row_scale[o]  (mp_tools.py:359-364). */
 int ddx_wprep_rowscale(const void* w, int32_t w_dtype, float* row_scale, const float* gain_ptr, float gain, int64_t rows,

@@ -49,13 +49,14 @@ def main():
     tr = ts.trainer
     torch.cuda.synchronize(); t1 = time.perf_counter()
     loss, grads = tr.train_batch(samples, clap, sigma, noise, mask, Fmt())
+    t_host = time.perf_counter() - t1                   # host enqueue time of the batch (no device wait in between)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     ts.opt.step({k: grads[k] for k in ts.params}, 1e-4, 250.0)
     unet.normalize_weights()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     fl = 3 * 489.3e9 * B
     print(f"UNet train step B={B} (4,{H},{W}) bf16 compute / fp32 master: {dt * 1e3:.1f} ms/step = {B / dt:.1f} samples/s, "
-          f"{fl / dt / 1e12:.0f} TFLOP/s (3 x forward FLOPs); train batch {1e3 * (t2 - t1):.1f} ms, optimizer + weight norm {1e3 * (t3 - t2):.1f} ms; "
+          f"{fl / dt / 1e12:.0f} TFLOP/s (3 x forward FLOPs); train batch {1e3 * (t2 - t1):.1f} ms (host enqueue {1e3 * t_host:.1f} ms), optimizer + weight norm {1e3 * (t3 - t2):.1f} ms; "
           f"loss {float(out['loss'].mean()):.4f} grad_norm {out['grad_norm']:.2f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
 
