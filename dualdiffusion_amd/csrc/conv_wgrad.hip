@@ -62,7 +62,10 @@ template <int KS> struct WgGeom {
   static constexpr int DY_BYTES = DY_PIECES * 1024, X_BYTES = X_PIECES * 1024;
   static constexpr int STAGE = DY_BYTES + X_BYTES;
   static constexpr int DI = (DY_PIECES + 3) / 4, XI = (X_PIECES + 3) / 4;
-  static constexpr int SMEM = 2 * STAGE;
+  // epilogue transpose image [64 output channels][BCW x TAPS floats (+4: the two half-waves land on different banks)]
+  static constexpr int ROWF = BCW * TAPS, ROWP = ROWF + 4;
+  static constexpr int EPI_BYTES = BNW * ROWP * 4;
+  static constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
   // accumulator fragments per wave: 3x3: taps {0..4} / {5..8} of one 32-channel input tile; 1x1: one 32x32 block
   static constexpr int NFRAG = KS == 3 ? 5 : 1;
 };
@@ -195,10 +198,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     compute_w(S1{});
   }
 
-  // ---- store the partial sums: acc[f][4q+e] = dW'[n = 8q + 4*khalf + e][c = lane & 31] of tap0 + f
+  // ---- store the partial sums.  acc[f][4q+e] = dW'[n = 8q + 4*khalf + e][c = lane & 31] of tap0 + f: in the gradient's
+  // natural [n][c][tap] layout one lane's 16 values are 4-byte pieces 36 B apart, so the block is transposed through LDS
+  // (the stage buffers are free now) and leaves as 16-byte stores of contiguous (BCW x TAPS)-float runs per output channel.
   const int khalf = lane >> 5, l31 = lane & 31;
-  float* wsp = p.ws + (size_t)ksp * p.Cout * p.Cg * TAPS;
-  const int c = c0 + cf * 32 + l31;
+  float* sT = reinterpret_cast<float*>(smem);
+  __syncthreads();  // every wave is done reading the last stage
 #pragma unroll
   for (int f = 0; f < NFRAG; ++f) {
     if (f >= ntap) break;
@@ -206,10 +211,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + nf * 32 + 8 * q + 4 * khalf + e;
-        if (n < p.Ng && c < p.Cg) wsp[((size_t)(g * p.Ng + n) * p.Cg + c) * TAPS + tap] = acc[f][4 * q + e];
-      }
+      for (int e = 0; e < 4; ++e) sT[(nf * 32 + 8 * q + 4 * khalf + e) * GEO::ROWP + (cf * 32 + l31) * TAPS + tap] = acc[f][4 * q + e];
+  }
+  __syncthreads();
+  float* wsp = p.ws + (size_t)ksp * p.Cout * p.Cg * TAPS;
+  const int valid = min(GEO::BCW, p.Cg - c0) * TAPS;  // floats of a row that exist (multiple of 8: Cg % 8 == 0)
+  constexpr int V4 = GEO::ROWF / 4;
+#pragma unroll
+  for (int i = 0; i < GEO::BNW * V4 / 256; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx / V4, v = idx - row * V4;
+    if (n0 + row < p.Ng && 4 * v < valid)
+      *reinterpret_cast<f32x4*>(wsp + ((size_t)(g * p.Ng + n0 + row) * p.Cg + c0) * TAPS + 4 * v) = *reinterpret_cast<const f32x4*>(sT + row * GEO::ROWP + 4 * v);
   }
 }
 
