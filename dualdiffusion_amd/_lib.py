@@ -70,6 +70,10 @@ class OptimJob(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_int64)]
 
 
+class LinearBwdJob(C.Structure):
+    _fields_ = [("dc", C.c_void_p), ("w", C.c_void_p), ("row_scale", C.c_void_p), ("dwp", C.c_void_p), ("O", C.c_int32), ("groups", C.c_int32)]
+
+
 class WPathJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wp_t", C.c_void_p), ("row_scale", C.c_void_p), ("gain_ptr", C.c_void_p),
                 ("dwp", C.c_void_p), ("dw", C.c_void_p), ("dgain", C.c_void_p), ("gain", C.c_float),
@@ -160,6 +164,7 @@ PROTOTYPES = {
     "ddx_lincomb3": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "ddx_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_linear_small_bwd_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_wpath_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw_ld": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_plan_begin": (C.c_void_p, []),

@@ -204,6 +204,38 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dx_kernel(const float* _
   atomicAdd(dx + (size_t)m * x_stride + kk, acc);
 }
 
+// Batched forms over a device job table (all emb_linear* layers of a UNet share x = emb and dx = demb): blockIdx.y = job.
+__global__ __launch_bounds__(256) void linear_small_bwd_multi_kernel(const ddx_linear_bwd_job* __restrict__ jobs, const float* __restrict__ x,
+                                                                     int M, int K, int x_stride) {
+  const ddx_linear_bwd_job jb = jobs[blockIdx.y];
+  const int o = blockIdx.x;
+  if (o >= jb.O) return;
+  const int Kg = K / jb.groups;
+  const int g = o / (jb.O / jb.groups);
+  for (int k = threadIdx.x; k < Kg; k += 256) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += jb.dc[(size_t)m * jb.O + o] * x[(size_t)m * x_stride + g * Kg + k];
+    jb.dwp[(size_t)o * Kg + k] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_small_bwd_dx_multi_kernel(const ddx_linear_bwd_job* __restrict__ jobs, float* __restrict__ dx, int M, int K,
+                                                                        int x_stride, int slices) {
+  const ddx_linear_bwd_job jb = jobs[blockIdx.z / slices];
+  const int slice = blockIdx.z % slices;
+  const int kk = blockIdx.x * 256 + threadIdx.x;  // column of x
+  const int m = blockIdx.y;
+  if (kk >= K) return;
+  const int Kg = K / jb.groups, Og = jb.O / jb.groups;
+  const int g = kk / Kg, k = kk - g * Kg;
+  const int per = (Og + slices - 1) / slices;
+  const int o0 = g * Og + slice * per, o1 = min(o0 + per, (g + 1) * Og);
+  const float* w = reinterpret_cast<const float*>(jb.w);
+  float acc = 0.f;
+  for (int o = o0; o < o1; ++o) acc += jb.dc[(size_t)m * jb.O + o] * jb.row_scale[o] * w[(size_t)o * Kg + k];
+  atomicAdd(dx + (size_t)m * x_stride + kk, acc);
+}
+
 // EDM2 training loss (reference training/module_trainers/unet_trainer.py:271-282): per sample
 //   wl = mean_chw((D - x)^2) * (sigma^2 + sd^2) / (sigma * sd)^2,   loss = wl / exp(logvar) + logvar,
 // and the gradients of mean_b(loss): dD = (2 w / (N B exp(logvar))) (D - x), dlogvar = (1 - wl / exp(logvar)) / B.
@@ -344,6 +376,19 @@ extern "C" int ddx_linear_small_bwd(const float* dc, const float* x, int32_t x_s
       if (dx) hipLaunchKernelGGL(linear_small_bwd_dx_kernel<bf16>, gdx, dim3(256), 0, s, dc, (const bf16*)w, row_scale, dx, M, O, K / groups, groups, x_stride);
     }
     return check_launch("linear_small_bwd");
+  }, stream, "linear_small_bwd");
+}
+
+extern "C" int ddx_linear_small_bwd_batched(const ddx_linear_bwd_job* jobs_dev, int32_t njobs, int32_t max_O, const float* x, int32_t x_stride,
+                                            float* dx, int32_t M, int32_t K, ddx_stream stream) {
+  if (!jobs_dev || njobs <= 0 || max_O <= 0 || !x || M <= 0 || K <= 0) return set_error(DDX_ERR_ARG, "linear_small_bwd_batched: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(linear_small_bwd_multi_kernel, dim3(max_O, njobs), dim3(256), 0, s, jobs_dev, x, M, K, x_stride);
+    if (dx) {
+      constexpr int kSlices = 8;
+      hipLaunchKernelGGL(linear_small_bwd_dx_multi_kernel, dim3((K + 255) / 256, M, njobs * kSlices), dim3(256), 0, s, jobs_dev, dx, M, K, x_stride, kSlices);
+    }
+    return check_launch("linear_small_bwd_batched");
   }, stream, "linear_small_bwd");
 }
 

@@ -50,6 +50,9 @@ class BlockWeightsT:
     # state-dict keys `<prefix>.<layer>.weight`; the weight-path backward then runs once for all layers (bank.backward())
     bank: Optional[object] = None
     prefix: str = ""
+    # persistent [B, O] fp32 buffers of the emb_linear* outputs and their gradients (keys c, dc, c_qk, dc_qk, c_v, dc_v) when the
+    # caller evaluates every emb_linear* of the network in one batched launch (forward) / back-propagates them in one (backward)
+    cvec: Optional[dict] = None
 
 
 @dataclass
@@ -104,7 +107,8 @@ def _linear_bwd(w: BlockWeightsT, key: str, dc: torch.Tensor, emb: torch.Tensor,
     """(dw, dgain) of an emb_linear* layer; accumulates the embedding gradient into demb."""
     if w.bank is not None:
         name = f"{w.prefix}.{key}.weight"
-        ops.linear_small_bwd(dc, emb, weight, groups, gain, True, demb, row_scale=w.bank.rs[name], dwp=w.bank.dwp[name])
+        if w.cvec is None:         # (with cvec the caller back-propagates every emb_linear* at once from the persistent dc buffers)
+            ops.linear_small_bwd(dc, emb, weight, groups, gain, True, demb, row_scale=w.bank.rs[name], dwp=w.bank.dwp[name])
         return w.bank.dw[name], w.bank.dgain[name]
     return ops.linear_small_bwd(dc, emb, weight, groups, gain, True, demb)
 
@@ -135,9 +139,12 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     B = src0.shape[0]
     gain_ptr = w.emb_gain.reshape(1)
     Cmid = w.emb_linear.shape[0]
-    c = torch.empty(B, Cmid, dtype=torch.float32, device=in0.device)
-    table = ops.make_linear_jobs([(w.emb_linear, gain_ptr, c, 1.0, 1.0, G, True)], in0.device)
-    ops.linear_small(table, 1, Cmid, emb, B, w.emb_linear.dtype)
+    if w.cvec is not None:
+        c = w.cvec["c"]
+    else:
+        c = torch.empty(B, Cmid, dtype=torch.float32, device=in0.device)
+        table = ops.make_linear_jobs([(w.emb_linear, gain_ptr, c, 1.0, 1.0, G, True)], in0.device)
+        ops.linear_small(table, 1, Cmid, emb, B, w.emb_linear.dtype)
     pw = {"res0": _prep(w, "conv_res0", w.conv_res0, G, dt), "res1": _prep(w, "conv_res1", w.conv_res1, G, dt)}
     xs = x1 = None
     if flavor == "enc":
@@ -165,11 +172,14 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
         return out, tape
     # ---- self-attention: qk = attn_qk(x * c_qk), v = attn_v(x), y = attn_proj(mp_silu(attention * c_v)), x = mp_sum(x, y, t)
     Cout = out.shape[-1]
-    c_qk = torch.empty(B, Cout, dtype=torch.float32, device=in0.device)
-    c_v = torch.empty(B, Cout, dtype=torch.float32, device=in0.device)
-    table = ops.make_linear_jobs([(w.emb_linear_qk, w.emb_gain_qk.reshape(1), c_qk, 1.0, 1.0, 1, True),
-                                  (w.emb_linear_v, w.emb_gain_v.reshape(1), c_v, 1.0, 1.0, 1, True)], in0.device)
-    ops.linear_small(table, 2, Cout, emb, B, w.emb_linear_qk.dtype)
+    if w.cvec is not None:
+        c_qk, c_v = w.cvec["c_qk"], w.cvec["c_v"]
+    else:
+        c_qk = torch.empty(B, Cout, dtype=torch.float32, device=in0.device)
+        c_v = torch.empty(B, Cout, dtype=torch.float32, device=in0.device)
+        table = ops.make_linear_jobs([(w.emb_linear_qk, w.emb_gain_qk.reshape(1), c_qk, 1.0, 1.0, 1, True),
+                                      (w.emb_linear_v, w.emb_gain_v.reshape(1), c_v, 1.0, 1.0, 1, True)], in0.device)
+        ops.linear_small(table, 2, Cout, emb, B, w.emb_linear_qk.dtype)
     pw["qk"] = _prep(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=Cout // w.heads)
     pw["v"] = _prep(w, "attn_v", w.attn_v, 1, dt)
     pw["proj"] = _prep(w, "attn_proj", w.attn_proj, 1, dt)
@@ -196,7 +206,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         ap = ops.silu_scale_fwd(a["ao"], a["c_v"])
         g["dw_attn_proj"] = _wgrad(w, "attn_proj", t.pw["proj"], dyp, ap, 1, 1)
         dap = ops.conv2d(dyp, _prep_t(w, "attn_proj", w.attn_proj, 1, dt))
-        dc_v = torch.zeros_like(a["c_v"])
+        dc_v = w.cvec["dc_v"] if w.cvec is not None else torch.zeros_like(a["c_v"])
         dao = ops.silu_scale_bwd(dap, a["ao"], a["c_v"], 1.0, dc_v)
         g["dw_emb_linear_v"], g["demb_gain_v"] = _linear_bwd(w, "emb_linear_v", dc_v, t.emb, w.emb_linear_v, 1, w.emb_gain_v.reshape(1), demb)
         dqk, dv = attention_backward(a["qk"], a["v"], dao, w.heads)
@@ -206,7 +216,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         xs_qk = ops.silu_scale_fwd(t.out, a["c_qk"], 1.0, act=False)
         g["dw_attn_qk"] = _wgrad(w, "attn_qk", t.pw["qk"], dqk, xs_qk, 1, 1)
         dxs = ops.conv2d(dqk, _prep_t(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=t.out.shape[-1] // w.heads))
-        dc_qk = torch.zeros_like(a["c_qk"])
+        dc_qk = w.cvec["dc_qk"] if w.cvec is not None else torch.zeros_like(a["c_qk"])
         dout_qk = ops.silu_scale_bwd(dxs, t.out, a["c_qk"], 1.0, dc_qk, add=dout_v, act=False)
         g["dw_emb_linear_qk"], g["demb_gain_qk"] = _linear_bwd(w, "emb_linear_qk", dc_qk, t.emb, w.emb_linear_qk, 1, one, demb)
         dout = ops.add3(dout_res, dout_qk)
@@ -216,7 +226,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     a1 = ops.silu_scale_fwd(t.y0, t.c)
     g["dw_conv_res1"] = _wgrad(w, "conv_res1", t.pw["res1"], dy1, a1, G, 3)
     da1 = ops.conv2d(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt))
-    dc = torch.zeros_like(t.c)
+    dc = w.cvec["dc"] if w.cvec is not None else torch.zeros_like(t.c)
     dy0 = ops.silu_scale_bwd(da1, t.y0, t.c, 1.0, dc)
     # c = emb_linear(emb) * emb_gain + 1
     g["dw_emb_linear"], g["demb_gain"] = _linear_bwd(w, "emb_linear", dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), demb)

@@ -17,15 +17,16 @@ import torch
 
 from .. import ops
 from ..engine import mp_cat_weights
+from .. import _lib as L
 from .._lib import DDXError, check, current_stream, dtype_code, lib, ptr
 from .block_grad import BlockWeightsT, block_backward, block_forward_train
 from .weight_bank import BankEntry, WeightBank
 
 
-def _block_weights(blk, groups: int, bank=None, prefix: str = "") -> BlockWeightsT:
+def _block_weights(blk, groups: int, bank=None, prefix: str = "", cvec=None) -> BlockWeightsT:
     w = BlockWeightsT(conv_res0=blk.conv_res0.weight.data, conv_res1=blk.conv_res1.weight.data, emb_linear=blk.emb_linear.weight.data,
                       emb_gain=blk.emb_gain.data.reshape(1), conv_skip=blk.conv_skip.weight.data if blk.conv_skip is not None else None,
-                      groups=groups, bank=bank, prefix=prefix)
+                      groups=groups, bank=bank, prefix=prefix, cvec=cvec)
     if blk.use_attention:
         w.attn_qk, w.attn_v, w.attn_proj = blk.attn_qk.weight.data, blk.attn_v.weight.data, blk.attn_proj.weight.data
         w.emb_linear_qk, w.emb_linear_v = blk.emb_linear_qk.weight.data, blk.emb_linear_v.weight.data
@@ -112,6 +113,28 @@ class UNetTrainer:
                 entries.append(BankEntry(name=mname + ".weight", weight=m.weight.data, prep=False, transpose=False, grad=False))
         self.bank = WeightBank(entries, torch.bfloat16, self.grad_views)
         self._bank_key = (B, H, W)
+        # every emb_linear* (all read emb): persistent outputs / output gradients, one job table for the forward and one for the backward
+        lin = [e for e in entries if ".emb_linear" in e.name]
+        total = sum(e.weight.shape[0] for e in lin)
+        dev = u.device
+        self.c_pool = torch.empty(B * total, dtype=torch.float32, device=dev)
+        self.dc_pool = torch.zeros(B * total, dtype=torch.float32, device=dev)
+        self.cvecs: dict = {}
+        fwd, bwd, off = [], (L.LinearBwdJob * len(lin))(), 0
+        for i, e in enumerate(lin):
+            O = e.weight.shape[0]
+            prefix, key = e.name[:-len(".weight")].rsplit(".", 1)
+            suffix = key[len("emb_linear"):]                       # "", "_qk", "_v"
+            c = self.c_pool[off:off + B * O].view(B, O)
+            dc = self.dc_pool[off:off + B * O].view(B, O)
+            off += B * O
+            self.cvecs.setdefault(prefix, {}).update({"c" + suffix: c, "dc" + suffix: dc})
+            fwd.append((e.weight, e.gain.reshape(1), c, 1.0, 1.0, e.groups, True))
+            bwd[i] = L.LinearBwdJob(dc=ptr(dc), w=ptr(e.weight), row_scale=ptr(self.bank.rs[e.name]), dwp=ptr(self.bank.dwp[e.name]), O=O,
+                                    groups=e.groups)
+        self.lin_fwd = ops.make_linear_jobs(fwd, dev)
+        self.lin_bwd = torch.frombuffer(bytearray(bytes(bwd)), dtype=torch.uint8).to(dev)
+        self.lin_n, self.lin_max_O = len(lin), max(e.weight.shape[0] for e in lin)
 
     def store_grads(self, grads: dict) -> dict:
         """Move gradients computed outside the bank into their slots of the flat bucket; returns {name: bucket view}."""
@@ -152,6 +175,8 @@ class UNetTrainer:
         pre, emb = torch.empty_like(e0), torch.empty_like(e0)
         ops.mpsum_rows(e0, emb_in, pre, t=cfg.label_balance, silu=False)
         ops.mpsum_rows(e0, emb_in, emb, t=cfg.label_balance, silu=True)
+        # c = emb_linear(emb) * emb_gain + 1 of every block (and the attention c_qk, c_v) in one launch
+        ops.linear_small(self.lin_fwd, self.lin_n, self.lin_max_O, emb, B, torch.float32)
         # conv_in
         w_in = u.enc["conv_in"].weight.data
         pw_in = ops.wprep(w_in, 1, dt, normalize=True, cg_pad=8, npix=B * H * W)
@@ -161,7 +186,7 @@ class UNetTrainer:
         for name, blk in u.enc.items():
             if name == "conv_in":
                 continue
-            x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "enc." + name), flavor="enc",
+            x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "enc." + name, self.cvecs["enc." + name]), flavor="enc",
                                        resample=blk.resample_mode, **kw)
             tapes.append(("enc." + name, blk, t, None))
             skips.append(x)
@@ -172,11 +197,11 @@ class UNetTrainer:
                 si = stack.pop()
                 sk = skips[si]
                 s0, s1 = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
-                x, t = block_forward_train(x, sk, s0, s1, emb, _block_weights(blk, G, bank, "dec." + name), flavor="dec",
+                x, t = block_forward_train(x, sk, s0, s1, emb, _block_weights(blk, G, bank, "dec." + name, self.cvecs["dec." + name]), flavor="dec",
                                            resample=blk.resample_mode, **kw)
                 tapes.append(("dec." + name, blk, t, si))
             else:
-                x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "dec." + name), flavor="dec",
+                x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "dec." + name, self.cvecs["dec." + name]), flavor="dec",
                                            resample=blk.resample_mode, **kw)
                 tapes.append(("dec." + name, blk, t, None))
         # conv_out on an 8-row padded weight (4 output channels do not fill a 16-byte NHWC vector)
@@ -202,6 +227,7 @@ class UNetTrainer:
         B, H, W, Co = t["B"], t["H"], t["W"], t["Co"]
         grads: dict = {}
         self._scalar_tail.zero_()          # the gain gradients are accumulated with atomics (bank.backward, out_gain)
+        self.dc_pool.zero_()               # so are the emb_linear* output gradients (silu_scale_bwd)
         # D = c_skip * x_in + c_out * y  ->  dy = c_out[b] * dD, NHWC bf16 with the 4 channels padded to one 16-byte vector
         dy8 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
         check(lib().ddx_unet_output_combine_bwd(ptr(dD.to(dev, torch.float32).contiguous()), ptr(t["sig"]), ptr(dy8), B, Co, H, W, 8, cfg.sigma_data,
@@ -230,6 +256,9 @@ class UNetTrainer:
                     grads[f"{name}.{k[3:]}.weight"] = v
                 elif k.startswith("demb_gain"):
                     grads[f"{name}.emb_gain{k[len('demb_gain'):]}"] = v.reshape(())
+        # every emb_linear*: dwp from the blocks' dc buffers, demb += dc @ w'
+        check(lib().ddx_linear_small_bwd_batched(ptr(self.lin_bwd), self.lin_n, self.lin_max_O, ptr(t["emb"]), t["emb"].stride(0), ptr(demb), B,
+                                                 t["emb"].shape[1], current_stream()), "linear_small_bwd_batched")
         # conv_in: its output is skip 0 and the first block's input
         if 0 in dskip:
             dx = ops.add3(dx, dskip.pop(0))

@@ -187,6 +187,20 @@ int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma
  * Cpad) = c_out(sigma_b) * dD (NCHW fp32). */
 int ddx_unet_output_combine_bwd(const float* d_out_nchw, const float* sigma, void* dy_nhwc, int32_t B, int32_t C, int32_t H, int32_t W,
                                 int32_t Cpad, float sigma_data, int32_t dtype, ddx_stream stream);
+/* All small-M linear layers that share the input x [M][K] (every emb_linear* of a UNet reads emb) in two launches:
+ * dwp_j[o][k] = sum_m dc_j[m][o] x[m][g K/groups_j + k],  dx[m][.] += sum_j dc_j[m][o] w_j[o][k] row_scale_j[o]  (atomics;
+ * dx NULL: skipped).  fp32 master weights.  Job table on the device. */
+typedef struct {
+  const float* dc;         /* [M][O] */
+  const void* w;           /* fp32 [O][K/groups] */
+  const float* row_scale;  /* [O] (ddx_wprep_rowscale / DDX_WPATH_ROWSCALE) */
+  float* dwp;              /* [O][K/groups] gradient w.r.t. the prepared weight */
+  int32_t O, groups;
+} ddx_linear_bwd_job;
+
+int ddx_linear_small_bwd_batched(const ddx_linear_bwd_job* jobs_dev, int32_t njobs, int32_t max_O, const float* x, int32_t x_stride,
+                                 float* dx, int32_t M, int32_t K, ddx_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Multi-tensor weight path (training): one launch per phase over a job table that lives on the device.
  * Replaces, per optimizer step, the per-module calls of MPConv.forward's weight branch under autograd and of
