@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
     }
     if (p.epilogue == DDX_EPI_MPSUM) acc = to_f32<T>(reinterpret_cast<const T*>(p.res)[idx]) * p.res_a + acc * p.res_b;
     if (p.clip > 0.f) acc = fminf(fmaxf(acc, -p.clip), p.clip);
-    if (p.out2) reinterpret_cast<T*>(p.out2)[idx] = from_f32<T>(mp_silu_f(acc * p.out2_scale));
+    if (p.out2) {  // twin: with a channel scale and a raw main output the scale belongs to the twin (training forward)
+      const float tc = (p.out_cs && !p.out_act) ? p.out_cs[(size_t)b * p.Cout + o] : 1.0f;
+      reinterpret_cast<T*>(p.out2)[idx] = from_f32<T>(mp_silu_f(acc * tc * p.out2_scale));
+    }
     if (p.out_act) acc = mp_silu_f(p.out_cs ? acc * p.out_cs[(size_t)b * p.Cout + o] : acc);
     reinterpret_cast<T*>(p.out)[idx] = from_f32<T>(acc);
   }

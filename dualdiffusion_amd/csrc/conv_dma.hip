@@ -340,8 +340,19 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
           const long off = eoff[j][tt] + i * 32;
           if (p.out2) {
             Vec16<bf16> tv;
+            if (p.out_cs && !p.out_act) {  // raw main output: the channel scale belongs to the twin (training forward)
+              const float* csp = p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
+              const f32x4 ca = *reinterpret_cast<const f32x4*>(csp);
+              const f32x4 cb = *reinterpret_cast<const f32x4*>(csp + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
+              for (int e = 0; e < 4; ++e) {
+                tv.set(e, mp_silu_f(y[e] * ca[e] * p.out2_scale));
+                tv.set(4 + e, mp_silu_f(y[4 + e] * cb[e] * p.out2_scale));
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
+            }
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + off) = tv.v;
           }
           if (p.out_act) {

@@ -411,8 +411,15 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     if (eoff[it] < 0) continue;
     if (p.out2) {  // activated twin for the next block's conv_res0
       Vec4<T> tv;
+      if (p.out_cs && !p.out_act) {  // raw main output: the channel scale belongs to the twin (training forward keeps y AND mp_silu(y * c))
+        const int ch = g * p.Ng + n0 + (idx % G4) * 4;
+        const f32x4 c4v = *reinterpret_cast<const f32x4*>(p.out_cs + (size_t)b * p.Cout + ch);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
+        for (int e = 0; e < 4; ++e) tv.set(e, mp_silu_f(y[e] * c4v[e] * p.out2_scale));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
+      }
       *reinterpret_cast<V4*>(reinterpret_cast<T*>(p.out2) + eoff[it]) = tv.v;
     }
     if (p.out_act) {  // producer-side mp_silu(y * c): the consumer conv then stages its operand untouched

@@ -9,8 +9,8 @@ forward (module.training, mp_tools.py:360-361):
     y1  = conv_res1(mp_silu(y0 * c))
     dec: x = conv_skip(x) | x
     out = clip(mp_sum(x, y1, t))
-The training forward keeps the RAW tensors (block input, pre-norm skip output, y0, out); the backward recomputes the
-activated conv operands (HBM-bound element-wise kernels) and chains
+The training forward keeps the RAW tensors (block input, pre-norm skip output, y0, out) AND the activated conv operands (bf16
+twins written by the producers' epilogues, see block_forward_train); the backward chains
     mp_sum/clip backward -> conv_res1 wgrad + dgrad -> mp_silu(y0*c) backward (dy0, dc) -> emb_linear backward ->
     conv_res0 wgrad + dgrad -> mp_silu backward per source (+ residual / skip gradient) -> [pixel-norm backward ->]
     conv_skip wgrad + dgrad -> resample adjoint -> weight-path backward (weight norm, gains, folded mp_cat scales).
@@ -75,7 +75,12 @@ class BlockTape:
     res_t: float
     clip: float
     pw: dict = field(default_factory=dict)
-    attn: Optional[dict] = None       # c_qk, c_v, qk, v, ao, xa, attn_t
+    attn: Optional[dict] = None       # c_qk, c_v, qk, v, ao, ap, xs_qk, xa, attn_t
+    # activated twins kept for the weight gradients: operands of conv_res0 (per source) and of conv_res1; the block output's
+    a00: Optional[torch.Tensor] = None
+    a01: Optional[torch.Tensor] = None
+    a1: Optional[torch.Tensor] = None
+    out_twin: Optional[torch.Tensor] = None
 
 
 def _prep(w: BlockWeightsT, key: str, weight: torch.Tensor, groups: int, dt, **kw):
@@ -130,8 +135,16 @@ def _resample_bwd(dx: torch.Tensor, mode: str) -> torch.Tensor:
 
 
 def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: float, s1: float, emb: torch.Tensor, w: BlockWeightsT, *,
-                        flavor: str, resample: str = "keep", res_t: float = 0.3, clip: float = 256.0, attn_t: float = 0.3):
-    """in0 (| in1): NHWC bf16 block input(s) (mp_cat scales s0, s1); emb [B, Cemb] fp32.  Returns (out, tape)."""
+                        flavor: str, resample: str = "keep", res_t: float = 0.3, clip: float = 256.0, attn_t: float = 0.3,
+                        act0: Optional[torch.Tensor] = None, act1: Optional[torch.Tensor] = None, twin_scale: Optional[float] = None):
+    """in0 (| in1): NHWC bf16 block input(s) (mp_cat scales s0, s1); emb [B, Cemb] fp32.  Returns (out, tape).
+
+    Producer-side activation, as in the inference plan: every conv operand that the reference activates on the fly is stored
+    once as a bf16 twin next to the raw tensor -- conv_res0's epilogue writes y0 AND mp_silu(y0 * c), the block's last conv
+    writes its output AND (twin_scale given) mp_silu(twin_scale * out) for the consumer -- so all convs stage their operands
+    untouched (LDS-DMA kernels) and the backward finds the weight-gradient operands on the tape instead of recomputing them.
+    act0 / act1: mp_silu(s0 * in0) / mp_silu(s1 * in1) from the producers (decoder blocks; computed here when absent).
+    tape.out_twin: mp_silu(twin_scale * out) or None."""
     dt, G = in0.dtype, w.groups
     src0 = _resample(in0, resample)
     src1 = _resample(in1, resample) if in1 is not None else None
@@ -146,7 +159,7 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
         table = ops.make_linear_jobs([(w.emb_linear, gain_ptr, c, 1.0, 1.0, G, True)], in0.device)
         ops.linear_small(table, 1, Cmid, emb, B, w.emb_linear.dtype)
     pw = {"res0": _prep(w, "conv_res0", w.conv_res0, G, dt), "res1": _prep(w, "conv_res1", w.conv_res1, G, dt)}
-    xs = x1 = None
+    xs = x1 = a01 = None
     if flavor == "enc":
         assert src1 is None and s0 == 1.0
         if w.conv_skip is not None:
@@ -154,20 +167,32 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
             xs = ops.conv2d(src0, pw["skip"])
         else:
             xs = src0
-        x1 = ops.pixelnorm(xs)
-        y0 = ops.conv2d(x1, pw["res0"], prologue=PRO_SILU)
+        a00 = torch.empty_like(xs)
+        x1 = ops.pixelnorm(xs, out_act=a00)                 # x1 and mp_silu(x1)
         sk = x1
     else:
-        y0 = ops.conv2d(src0, pw["res0"], src1=src1, scale0=s0, scale1=s1, prologue=PRO_SILU)
+        # nearest upsampling commutes with the activation: the producer's twin is resampled like the raw input
+        a00 = _resample(act0, resample) if act0 is not None else ops.silu_scale_fwd(src0, None, s0)
+        if src1 is not None:
+            a01 = _resample(act1, resample) if act1 is not None else ops.silu_scale_fwd(src1, None, s1)
         if w.conv_skip is not None:
             pw["skip"] = _prep(w, "conv_skip", w.conv_skip, 1, dt, in_split=C0 if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
             sk = ops.conv2d(src0, pw["skip"], src1=src1)
         else:
             assert src1 is None and s0 == 1.0
             sk = src0
+    y0 = torch.empty(src0.shape[:3] + (Cmid,), dtype=dt, device=in0.device)
+    a1 = torch.empty_like(y0)
+    ops.conv2d(a00, pw["res0"], src1=a01, out=y0, out_scale=c, out2=a1)      # y0 and mp_silu(y0 * c)
     has_attn = w.attn_qk is not None
-    out = ops.conv2d(y0, pw["res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=sk, res_t=res_t, clip=0.0 if has_attn else clip)
+    out_twin = None
+    tw = {}
+    if twin_scale is not None:
+        out_twin = torch.empty(src0.shape[:3] + (w.conv_res1.shape[0],), dtype=dt, device=in0.device)
+        tw = dict(out2=out_twin, out2_scale=twin_scale)
+    out = ops.conv2d(a1, pw["res1"], residual=sk, res_t=res_t, clip=0.0 if has_attn else clip, **({} if has_attn else tw))
     tape = BlockTape(w, flavor, resample, in0, in1, src0, src1, s0, s1, emb, c, xs, x1, y0, out, res_t, 0.0 if has_attn else clip, pw)
+    tape.a00, tape.a01, tape.a1, tape.out_twin = a00, a01, a1, out_twin
     if not has_attn:
         return out, tape
     # ---- self-attention: qk = attn_qk(x * c_qk), v = attn_v(x), y = attn_proj(mp_silu(attention * c_v)), x = mp_sum(x, y, t)
@@ -183,11 +208,13 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     pw["qk"] = _prep(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=Cout // w.heads)
     pw["v"] = _prep(w, "attn_v", w.attn_v, 1, dt)
     pw["proj"] = _prep(w, "attn_proj", w.attn_proj, 1, dt)
-    qk = ops.conv2d(out, pw["qk"], prologue=PRO_SCALE, chan_scale=c_qk)
+    xs_qk = ops.silu_scale_fwd(out, c_qk, 1.0, act=False)                 # out * c_qk: operand of attn_qk and of its weight gradient
+    qk = ops.conv2d(xs_qk, pw["qk"])
     vv = ops.conv2d(out, pw["v"])
     ao = ops.attention(qk, vv, w.heads)
-    xa = ops.conv2d(ao, pw["proj"], prologue=PRO_SCALE_SILU, chan_scale=c_v, residual=out, res_t=attn_t, clip=clip)
-    tape.attn = dict(c_qk=c_qk, c_v=c_v, qk=qk, v=vv, ao=ao, xa=xa, attn_t=attn_t, clip=clip)
+    ap = ops.silu_scale_fwd(ao, c_v)
+    xa = ops.conv2d(ap, pw["proj"], residual=out, res_t=attn_t, clip=clip, **tw)
+    tape.attn = dict(c_qk=c_qk, c_v=c_v, qk=qk, v=vv, ao=ao, ap=ap, xs_qk=xs_qk, xa=xa, attn_t=attn_t, clip=clip)
     return xa, tape
 
 
@@ -203,7 +230,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         one = w.emb_gain_qk.reshape(1)
         # xa = clip(mp_sum(out, attn_proj(ap), t)), ap = mp_silu(ao * c_v)
         dout_res, dyp = ops.mpsum_clip_bwd(dout, a["xa"], a["attn_t"], a["clip"])
-        ap = ops.silu_scale_fwd(a["ao"], a["c_v"])
+        ap = a["ap"]
         g["dw_attn_proj"] = _wgrad(w, "attn_proj", t.pw["proj"], dyp, ap, 1, 1)
         dap = ops.conv2d(dyp, _prep_t(w, "attn_proj", w.attn_proj, 1, dt))
         dc_v = w.cvec["dc_v"] if w.cvec is not None else torch.zeros_like(a["c_v"])
@@ -213,7 +240,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         # v = attn_v(out);  qk = attn_qk(out * c_qk) with the (head, {q,k}, d) row order of the forward preparation
         g["dw_attn_v"] = _wgrad(w, "attn_v", t.pw["v"], dv, t.out, 1, 1)
         dout_v = ops.conv2d(dv, _prep_t(w, "attn_v", w.attn_v, 1, dt))
-        xs_qk = ops.silu_scale_fwd(t.out, a["c_qk"], 1.0, act=False)
+        xs_qk = a["xs_qk"]
         g["dw_attn_qk"] = _wgrad(w, "attn_qk", t.pw["qk"], dqk, xs_qk, 1, 1)
         dxs = ops.conv2d(dqk, _prep_t(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=t.out.shape[-1] // w.heads))
         dc_qk = w.cvec["dc_qk"] if w.cvec is not None else torch.zeros_like(a["c_qk"])
@@ -223,7 +250,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     # out = clip(mp_sum(sk, y1, t))
     dsk, dy1 = ops.mpsum_clip_bwd(dout, t.out, t.res_t, t.clip)
     # y1 = conv_res1(a1), a1 = mp_silu(y0 * c)
-    a1 = ops.silu_scale_fwd(t.y0, t.c)
+    a1 = t.a1
     g["dw_conv_res1"] = _wgrad(w, "conv_res1", t.pw["res1"], dy1, a1, G, 3)
     da1 = ops.conv2d(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt))
     dc = w.cvec["dc"] if w.cvec is not None else torch.zeros_like(t.c)
@@ -232,7 +259,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     g["dw_emb_linear"], g["demb_gain"] = _linear_bwd(w, "emb_linear", dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), demb)
     g["dc"] = dc
     if t.flavor == "enc":
-        a0 = ops.silu_scale_fwd(t.x1)
+        a0 = t.a00
         g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a0, G, 3)
         da0 = ops.conv2d(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt))
         dx1 = ops.silu_scale_bwd(da0, t.x1, None, 1.0, add=dsk)
@@ -244,8 +271,7 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
             dsrc0 = dxs
         dsrc1 = None
     else:
-        a00 = ops.silu_scale_fwd(t.src0, None, t.s0)
-        a01 = ops.silu_scale_fwd(t.src1, None, t.s1) if C1 else None
+        a00, a01 = t.a00, t.a01
         g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a00, G, 3, x1=a01)
         da0 = ops.conv2d(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt))
         if w.conv_skip is not None:

@@ -98,14 +98,22 @@ class UNetTrainer:
             add_block("enc." + name, blk, B * h * w)
             cx = blk.out_channels
             skip_ch.append(cx)
+        # producer-side activation across blocks: which mp_silu(scale * out) twin each producer writes for its consumer
+        self.skip_twin_scale, self.dec_twin_scale = {}, {}
+        prev = None
         for name, blk in u.dec.items():
             h, w = out_hw(blk, h, w)
             if "layer" in name:
                 cs = skip_ch.pop()
                 s0, s1 = mp_cat_weights(cx, cs, cfg.concat_balance)
+                self.skip_twin_scale[len(skip_ch)] = s1
                 add_block("dec." + name, blk, B * h * w, in_split=cx, s0=s0, s1=s1)
             else:
+                s0 = 1.0
                 add_block("dec." + name, blk, B * h * w)
+            if prev is not None:
+                self.dec_twin_scale[prev] = s0
+            prev = name
             cx = blk.out_channels
         # the remaining weight-normalised layers (conv_in / conv_out / embeddings) only take part in normalize()
         for mname, m in u.named_modules():
@@ -180,30 +188,35 @@ class UNetTrainer:
         # conv_in
         w_in = u.enc["conv_in"].weight.data
         pw_in = ops.wprep(w_in, 1, dt, normalize=True, cg_pad=8, npix=B * H * W)
-        x = ops.conv2d(x0, pw_in)
-        tapes, skips = [], [x]
+        x_tw = torch.empty(B, H, W, w_in.shape[0], dtype=dt, device=dev) if self.skip_twin_scale.get(0) is not None else None
+        x = ops.conv2d(x0, pw_in, out2=x_tw, out2_scale=self.skip_twin_scale.get(0) or 1.0)
+        tapes, skips, skip_tw = [], [x], [x_tw]
         kw = dict(res_t=cfg.res_balance, attn_t=cfg.attn_balance)
         for name, blk in u.enc.items():
             if name == "conv_in":
                 continue
             x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "enc." + name, self.cvecs["enc." + name]), flavor="enc",
-                                       resample=blk.resample_mode, **kw)
+                                       resample=blk.resample_mode, twin_scale=self.skip_twin_scale.get(len(skips)), **kw)
             tapes.append(("enc." + name, blk, t, None))
             skips.append(x)
+            skip_tw.append(t.out_twin)
         n_enc = len(skips)
         stack = list(range(n_enc))
+        x_tw = None                       # the last encoder output's twin carries the skip scale, not the first decoder block's
         for name, blk in u.dec.items():
+            bw = _block_weights(blk, G, bank, "dec." + name, self.cvecs["dec." + name])
+            ts = self.dec_twin_scale.get(name)
             if "layer" in name:
                 si = stack.pop()
                 sk = skips[si]
                 s0, s1 = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
-                x, t = block_forward_train(x, sk, s0, s1, emb, _block_weights(blk, G, bank, "dec." + name, self.cvecs["dec." + name]), flavor="dec",
-                                           resample=blk.resample_mode, **kw)
+                x, t = block_forward_train(x, sk, s0, s1, emb, bw, flavor="dec", resample=blk.resample_mode, act0=x_tw, act1=skip_tw[si],
+                                           twin_scale=ts, **kw)
                 tapes.append(("dec." + name, blk, t, si))
             else:
-                x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "dec." + name, self.cvecs["dec." + name]), flavor="dec",
-                                           resample=blk.resample_mode, **kw)
+                x, t = block_forward_train(x, None, 1.0, 1.0, emb, bw, flavor="dec", resample=blk.resample_mode, act0=x_tw, twin_scale=ts, **kw)
                 tapes.append(("dec." + name, blk, t, None))
+            x_tw = t.out_twin
         # conv_out on an 8-row padded weight (4 output channels do not fill a 16-byte NHWC vector)
         w_out = u.conv_out.weight.data
         Co = w_out.shape[0]

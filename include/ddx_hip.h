@@ -108,7 +108,9 @@ typedef struct {
    *   out_act = 1: the stored output is mp_silu(y * out_scale[b][cout]) (out_scale NULL: mp_silu(y))  -- conv_res0 feeding
    *                conv_res1 (unet_edm2_b4.py:119-122);
    *   out2 != NULL: additionally store out2 = mp_silu(out2_scale * y) of the final (post mp_sum / clip) value -- the
-   *                activated twin of a block output that the next block's conv_res0 reads (unet_edm2_b4.py:119). */
+   *                activated twin of a block output that the next block's conv_res0 reads (unet_edm2_b4.py:119).
+   *                With out_act = 0 and out_scale != NULL the channel scale belongs to the twin: out = y (raw) and
+   *                out2 = mp_silu(out2_scale * out_scale[b][cout] * y) -- the training forward keeps both. */
   const float* out_scale;   /* [B][Cout] fp32 or NULL */
   void* out2;               /* NHWC [B][H][W][Cout] or NULL */
   int32_t out_act;
