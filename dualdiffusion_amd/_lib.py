@@ -46,6 +46,12 @@ class ConvDesc(C.Structure):
                 ("pad_mode", C.c_int32)]
 
 
+class DgradActDesc(C.Structure):
+    _fields_ = [("conv", ConvDesc), ("y0", C.c_void_p), ("y1", C.c_void_p), ("out1", C.c_void_p), ("add", C.c_void_p),
+                ("chan_scale", C.c_void_p), ("dchan_scale", C.c_void_p), ("workspace", C.c_void_p),
+                ("split", C.c_int32), ("act", C.c_int32), ("scale0", C.c_float), ("scale1", C.c_float)]
+
+
 class MelStftDesc(C.Structure):
     _fields_ = [("audio", C.c_void_p), ("window", C.c_void_p), ("twiddle", C.c_void_p), ("band_start", C.c_void_p),
                 ("band_len", C.c_void_p), ("band_w", C.c_void_p), ("out", C.c_void_p),
@@ -165,6 +171,8 @@ PROTOTYPES = {
     "ddx_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_linear_small_bwd_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_mpconv2d_dgrad_act_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "ddx_mpconv2d_dgrad_act": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ddx_wpath_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw_ld": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_plan_begin": (C.c_void_p, []),

@@ -283,8 +283,11 @@ extern "C" int ddx_silu_scale_bwd_ex(const void* da, int64_t da_ld, const void* 
   if (C % ev || da_ld % ev || (add && add_ld % ev)) return set_error(DDX_ERR_UNSUPPORTED, "silu_scale_bwd: C and the row strides must be multiples of the 16-byte vector");
   if (dc && !chan_scale) return set_error(DDX_ERR_ARG, "silu_scale_bwd: dc without chan_scale");
   return dispatch([=](hipStream_t s) -> int {
-    const int rows_per_block = 128;
-    dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)((C / ev + 255) / 256));
+    // rows per workgroup: as many as possible (one dc atomic per workgroup and channel) while ~1024 workgroups remain --
+    // a fixed 128 left the low-resolution levels (HW = 86 ... 1376) with 8 ... 44 workgroups, latency-bound at 60 us
+    const int zb = (C / ev + 255) / 256;
+    const int rows_per_block = (int)std::min<int64_t>(128, std::max<int64_t>(4, HW * B * zb / 1024));
+    dim3 grid((unsigned)((HW + rows_per_block - 1) / rows_per_block), (unsigned)B, (unsigned)zb);
     if (dtype == DDX_BF16)
       hipLaunchKernelGGL(silu_scale_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)da, (int)da_ld, (const bf16*)y, chan_scale, scale,
                          (const bf16*)add, (int)add_ld, (bf16*)dy, dc, (int)HW, C, rows_per_block, act);

@@ -132,9 +132,8 @@ extern "C" int ddx_normalize_weights(void* w, int32_t w_dtype, int64_t rows, int
   }, stream);
 }
 
-extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
-  if (!dp) return set_error(DDX_ERR_ARG, "conv: null descriptor");
-  const ddx_conv_desc d = *dp;
+// descriptor checks + the device parameter block shared by the forward entry and the fused data-gradient entry
+static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   if (!d.src0 || !d.wp || !d.out) return set_error(DDX_ERR_ARG, "conv: null buffer");
   if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.C0 <= 0 || d.Cout <= 0 || d.groups <= 0) return set_error(DDX_ERR_ARG, "conv: bad size");
   if ((d.C1 > 0) != (d.src1 != nullptr)) return set_error(DDX_ERR_ARG, "conv: src1/C1 mismatch");
@@ -162,6 +161,16 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   p.reflect_w = d.pad_mode == DDX_PAD_REFLECT_W ? 1 : 0;
   if (p.reflect_w && (d.W < 2 || d.resample != DDX_RESAMPLE_KEEP)) return set_error(DDX_ERR_UNSUPPORTED, "conv: reflect padding needs W >= 2 and no fused resample");
+  *pp = p;
+  return 0;
+}
+
+extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
+  if (!dp) return set_error(DDX_ERR_ARG, "conv: null descriptor");
+  const ddx_conv_desc d = *dp;
+  if (d.epilogue != DDX_EPI_STORE && d.epilogue != DDX_EPI_MPSUM) return set_error(DDX_ERR_ARG, "conv: epilogue");
+  ConvParams p{};
+  if (int rc = conv_fill(d, &p)) return rc;
   const int ks = d.ksize, dt = d.dtype;
   // d.force_direct selects the kernel: 0 = automatic, 1 = scalar reference kernel, 2 = register-staged MFMA kernel,
   // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)
@@ -178,4 +187,50 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
     if (dma) return launch_conv_dma(p, ks, s);
     return mfma ? launch_conv_mfma(p, ks, dt, s) : launch_conv_direct(p, ks, dt, s);
   }, stream, dma ? (ks == 3 ? "conv3x3_dma" : "conv1x1_dma") : mfma ? (ks == 3 ? "conv3x3_mfma" : "conv1x1_mfma") : "conv_direct", flops, bytes);
+}
+
+// ---- data-gradient conv fused with the backward of the producer-side activation (LDS-DMA kernel only)
+static int dgrad_act_fill(const ddx_dgrad_act_desc& d, ConvParams* pp) {
+  ddx_conv_desc c = d.conv;
+  c.epilogue = DDX_EPI_STORE; c.residual = nullptr; c.out2 = nullptr; c.out_act = 0; c.out_scale = nullptr;
+  ConvParams p{};
+  if (int rc = conv_fill(c, &p)) return rc;
+  if (!d.y0 || (d.split > 0 && (!d.y1 || !d.out1)) || d.split < 0 || d.split >= d.conv.Cout) return set_error(DDX_ERR_ARG, "dgrad_act: bad parts");
+  if (d.dchan_scale && (!d.chan_scale || d.split > 0)) return set_error(DDX_ERR_ARG, "dgrad_act: dchan_scale needs chan_scale and one part");
+  p.epilogue = DDX_EPI_SILU_BWD;
+  p.res = d.y0; p.bwd_y1 = d.y1; p.bwd_out1 = d.out1; p.bwd_add = d.add; p.out_cs = d.chan_scale;
+  p.bwd_dc = d.dchan_scale; p.bwd_ws = d.dchan_scale ? d.workspace : nullptr;
+  p.bwd_split = d.split; p.bwd_act = d.act; p.bwd_s0 = d.scale0; p.bwd_s1 = d.scale1;
+  *pp = p;
+  return 0;
+}
+
+extern "C" size_t ddx_mpconv2d_dgrad_act_workspace_bytes(const ddx_dgrad_act_desc* dp) {
+  if (!dp) return 0;
+  ConvParams p{};
+  ddx_dgrad_act_desc d = *dp;
+  static float dummy;
+  if (!d.conv.src0) d.conv.src0 = &dummy;
+  if (!d.conv.wp) d.conv.wp = &dummy;
+  if (!d.conv.out) d.conv.out = &dummy;
+  if (!d.y0) d.y0 = &dummy;
+  if (d.split > 0 && !d.y1) d.y1 = &dummy;
+  if (d.split > 0 && !d.out1) d.out1 = &dummy;
+  if (dgrad_act_fill(d, &p) != 0) return 0;
+  if (d.conv.dtype != DDX_BF16 || !conv_mfma_supported(p, d.conv.ksize, d.conv.dtype) || !conv_dma_supported(p, d.conv.ksize, d.conv.dtype, false)) return 0;
+  return conv_dma_bwd_ws_bytes(p, d.conv.ksize);
+}
+
+extern "C" int ddx_mpconv2d_dgrad_act(const ddx_dgrad_act_desc* dp, ddx_stream stream) {
+  if (!dp) return set_error(DDX_ERR_ARG, "dgrad_act: null descriptor");
+  const ddx_dgrad_act_desc d = *dp;
+  ConvParams p{};
+  if (int rc = dgrad_act_fill(d, &p)) return rc;
+  const int ks = d.conv.ksize;
+  if (d.conv.dtype != DDX_BF16 || !conv_dma_supported(p, ks, d.conv.dtype, /*any_size=*/true))
+    return set_error(DDX_ERR_UNSUPPORTED, "dgrad_act: layer does not qualify for the LDS-DMA kernel (run the conv and ddx_silu_scale_bwd)");
+  if (d.dchan_scale && !d.workspace) return set_error(DDX_ERR_ARG, "dgrad_act: workspace missing");
+  const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
+  const double bytes = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.add ? 3.0 : 2.0) + (double)p.Cout * p.Cg * ks * ks);
+  return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_dma(p, ks, s); }, stream, ks == 3 ? "conv3x3_dma_bwd" : "conv1x1_dma_bwd", flops, bytes);
 }

@@ -70,7 +70,8 @@ template <int KS, int SK, int NF, int WN> struct DmaGeom {
 // while the last stage of the current one is multiplied and its epilogue runs), and the second workgroup of every CU
 // starts half a unit late so that one workgroup's memory phases (epilogue stores, first-stage latency) fall into the
 // other's matrix phase instead of both doing the same thing at the same time.
-template <int KS, int SK, int NF, int WN, int PD>
+// EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
+template <int KS, int SK, int NF, int WN, int PD, int EB = 0>
 __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n) {
   using GEO = DmaGeom<KS, SK, NF, WN>;
   constexpr int NW = GEO::NW;
@@ -252,6 +253,28 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // (EB) the output channels may belong to two tensors (gradients of the two mp_cat sources): this unit's part
+    int ld_u = p.Cout, cofs = 0;
+    const bf16* res_u = res;
+    bf16* out_u = out;
+    float sc_u = 1.0f;
+    [[maybe_unused]] int epix[MF][2];
+    [[maybe_unused]] float dcacc[NF][8];
+    if constexpr (EB) {
+      sc_u = p.bwd_s0;
+      if (p.bwd_split > 0) {
+        const bool second = t.g * p.Ng + t.n0 >= p.bwd_split;
+        ld_u = second ? p.Cout - p.bwd_split : p.bwd_split;
+        cofs = second ? p.bwd_split : 0;
+        res_u = second ? reinterpret_cast<const bf16*>(p.bwd_y1) : res;
+        out_u = second ? reinterpret_cast<bf16*>(p.bwd_out1) : out;
+        sc_u = second ? p.bwd_s1 : p.bwd_s0;
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dcacc[i][e] = 0.f;
+    }
     // epilogue addressing: items of a 32 pixel x 32 channel patch are (pixel, 8-channel run); 128 items, 2 per lane
     long eoff[MF][2];
 #pragma unroll
@@ -264,7 +287,9 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
         const int tw = ml - th * TW;
         const int h = t.h0 + th, w = t.w0 + tw;
         const bool ok = h < p.H && w < p.W;
-        eoff[j][tt] = ok ? (long)((((size_t)t.b * p.H + h) * p.W + w) * p.Cout + (size_t)t.g * p.Ng + t.n0 + wn * (NF * 32) + (idx & 3) * 8) : -1;
+        const int pix = (t.b * p.H + h) * p.W + w;
+        eoff[j][tt] = ok ? (long)((size_t)pix * ld_u + (size_t)t.g * p.Ng + t.n0 - cofs + wn * (NF * 32) + (idx & 3) * 8) : -1;
+        if constexpr (EB) epix[j][tt] = ok ? pix : -1;
       }
     u32x4 rres[NF > 2 ? 2 : NF][MF][2];
 
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         issue_next(S0{});
-        if (NF <= 2 && q + 2 == nk && p.epilogue == DDX_EPI_MPSUM) {  // residual rows ride along with the last matrix phase
+        if (NF <= 2 && q + 2 == nk && (EB || p.epilogue == DDX_EPI_MPSUM)) {  // residual (EB: y) rows ride along with the last matrix phase
 #pragma unroll
           for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt) {
                 const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
-                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
+                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
               }
         }
         compute(S1{});
@@ -325,6 +350,41 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
           float y[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { y[e] = ya[e]; y[4 + e] = yb[e]; }
+          if constexpr (EB) {
+            // y[] = dL/da of 8 channels of one pixel; a = mp_silu(z), z = yy * s, s = chan_scale[b][c] * scale:
+            //   dz = da * mp_silu'(z) (act) | da;   out = dz * s (+ add);   dc partial += dz * yy
+            const int nch = t.n0 + (wn * NF + i) * 32 + c8;
+            if (eoff[j][tt] < 0 || nch >= p.Ng) continue;
+            Vec16<bf16> yv, ov, av;
+            yv.v = __builtin_bit_cast(bf16x8, rres[i][j][tt]);
+            float s8[8];
+            if (p.out_cs) {
+              const float* csp = p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
+              const f32x4 ca = *reinterpret_cast<const f32x4*>(csp);
+              const f32x4 cb = *reinterpret_cast<const f32x4*>(csp + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { s8[e] = ca[e] * sc_u; s8[4 + e] = cb[e] * sc_u; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) s8[e] = sc_u;
+            }
+            if (p.bwd_add)
+              av.v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.bwd_add) + (size_t)epix[j][tt] * p.Cout + t.g * p.Ng + nch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float yy = yv.get(e);
+              float dz = y[e];
+              if (p.bwd_act) {
+                const float z = yy * s8[e];
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+                dz *= sg * (1.0f + z * (1.0f - sg)) * kMpSiluInv;
+              }
+              dcacc[i][e] += dz * yy;
+              ov.set(e, dz * s8[e] + (p.bwd_add ? av.get(e) : 0.f));
+            }
+            *reinterpret_cast<bf16x8*>(out_u + eoff[j][tt] + i * 32) = ov.v;
+            continue;
+          }
           if (p.epilogue == DDX_EPI_MPSUM) {
             Vec16<bf16> rv;
             rv.v = __builtin_bit_cast(bf16x8, rres[NF > 2 ? (i & 1) : i][j][tt]);
@@ -374,14 +434,67 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
       }
     }
+    if constexpr (EB) {
+      if (p.bwd_ws) {
+        // channel sums of this wave's 64 pixels: the 16 lanes that share (lane & 3) hold the same 8*NF channels.  Transposing
+        // all-reduce: every step halves the values a lane is responsible for and adds the partner's half, so 8*NF - 1 (+1)
+        // shuffles leave ONE finished channel sum per lane instead of 4 * 8 * NF shuffles for a plain butterfly.
+        constexpr int NV = NF * 8;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i * 8 + e] = dcacc[i][e];
+        int vid = 0;
+        auto step = [&](auto n_tag, int m) {  // keep one half of the n*2 live values, add the partner's copy of it
+          constexpr int n = decltype(n_tag)::value;
+          const bool hi = (lane & m) != 0;
+#pragma unroll
+          for (int k = 0; k < n; ++k) {
+            const float send = hi ? v[k] : v[k + n];
+            const float keep = hi ? v[k + n] : v[k];
+            v[k] = keep + __shfl_xor(send, m, 64);
+          }
+          vid = vid * 2 + (hi ? 1 : 0);
+        };
+        step(std::integral_constant<int, NV / 2>{}, 32);
+        step(std::integral_constant<int, NV / 4>{}, 16);
+        step(std::integral_constant<int, NV / 8>{}, 8);
+        if constexpr (NV == 16) step(std::integral_constant<int, 1>{}, 4);
+        else v[0] += __shfl_xor(v[0], 4, 64);  // NF = 1: the last step is a plain pair sum (both lanes hold it)
+        const bool writer = NV == 16 || (lane & 4) == 0;
+        if (writer) p.bwd_ws[((size_t)u * NW + wave) * (NF * 32) + (vid >> 3) * 32 + (lane & 3) * 8 + (vid & 7)] = v[0];
+      }
+    }
   }
 }
 
-template <int KS, int SK, int NF, int WN>
+// dc[b][c] += scale * sum over the (pixel tile, wave) partial rows of image b written by the EB epilogue.
+// Row index = unit * NW + wave with unit = (g * ntile_n + nt) * ntile_px + b * tiles_per_image + tile.
+__global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dc, int rows_per_image, int rows_per_gn,
+                                                             int BN, int ntile_n, int Ng, int Cout, float scale) {
+  __shared__ float red[256];
+  const int gn = blockIdx.x, b = blockIdx.y;
+  const int g = gn / ntile_n, nt = gn - g * ntile_n;
+  const int ch = threadIdx.x % BN, sub = threadIdx.x / BN, nsub = 256 / BN;
+  const float* base = ws + ((size_t)gn * rows_per_gn + (size_t)b * rows_per_image) * BN;
+  float s = 0.f;
+  for (int r = sub; r < rows_per_image; r += nsub) s += base[(size_t)r * BN + ch];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0) {
+    for (int k = 1; k < nsub; ++k) s += red[k * BN + ch];
+    const int c = nt * BN + ch;
+    if (c < Ng) dc[(size_t)b * Cout + g * Ng + c] += s * scale;
+  }
+}
+
+template <int KS, int SK, int NF, int WN, int EB = 0>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN>;
   static_assert(GEO::SMEM <= (WN == 1 ? 80 : 160) * 1024, "LDS budget");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, 1>;
+  static_assert(!EB || (NF <= 2 && WN == 1), "the fused backward epilogue keeps y in the residual registers");
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, 1, EB>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::SMEM) != hipSuccess)
@@ -392,6 +505,11 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
   const int grid = (int)std::min<long>(total, WN == 1 ? 512 : 256);  // persistent: every CU holds 8 waves
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WN), GEO::SMEM, s, p, (int)total, ntile_n);
+  if (EB && p.bwd_ws && p.bwd_dc) {
+    const int tpi = p.tiles_h * p.tiles_w;
+    hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
+                       p.B * tpi * GEO::NW, GEO::BN, ntile_n, p.Ng, p.Cout, p.bwd_s0);
+  }
   return check_launch("conv_dma");
 }
 
@@ -417,6 +535,14 @@ bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util) {
 
 }  // namespace
 
+// channel-tile width of the fused-backward launch: tiles start at g * Ng + k * BN, the part boundary must be one of them
+static int dma_bwd_bn(const ConvParams& p) {
+  const int in_group = p.bwd_split % p.Ng;
+  if (p.Ng > 32 && in_group % 64 == 0) return 64;
+  if (in_group % 32 == 0) return 32;
+  return 0;
+}
+
 bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size) {
   if (dtype != DDX_BF16 || (ksize != 1 && ksize != 3)) return false;
   if (p.prologue != DDX_PRO_NONE || p.scale0 != 1.0f || (p.src1 && p.scale1 != 1.0f)) return false;
@@ -426,6 +552,7 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   if (p.CK % SK) return false;
   if (p.Ng % 8 || p.Cout % 8) return false;
   if (p.epilogue == DDX_EPI_MPSUM && p.out_act && p.out_cs && (p.Cout % 4)) return false;
+  if (p.epilogue == DDX_EPI_SILU_BWD && dma_bwd_bn(p) == 0) return false;  // every channel tile must lie in ONE part
   if ((size_t)p.B * p.sH * p.sW >= (size_t)1 << 31) return false;
   int TH, TW; double util;
   if (!dma_tile(p, ksize, &TH, &TW, &util)) return false;
@@ -436,6 +563,15 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   if (util < 0.6) return false;
   if (ksize == 1 && dma_wide_1x1(p, tiles)) return true;
   return tiles * ceil_div(p.Ng, p.Ng <= 32 ? 32 : 64) >= 512;
+}
+
+size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize) {
+  int TH = 0, TW = 0; double util;
+  if (!dma_tile(p, ksize, &TH, &TW, &util)) return 0;
+  const int BN = dma_bwd_bn(p);
+  if (BN == 0) return 0;
+  const size_t units = (size_t)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, BN) * p.G;
+  return units * 4 * BN * sizeof(float);
 }
 
 int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
@@ -449,6 +585,11 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   p.inv_TWP = 1.0f / (float)(TW + 2 * pad);
   // channel tile: 32 (one fragment column) or 64 with 4 waves and 2 workgroups per CU; 256 for wide 1x1 layers (8 waves).
   // (A 128-channel 8-wave 3x3 variant measured within 3% of the 64-channel one and loses on ragged groups: not built.)
+  if (p.epilogue == DDX_EPI_SILU_BWD) {
+    const bool narrow = dma_bwd_bn(p) == 32;
+    if (ksize == 3) return narrow ? launch_dma_t<3, 16, 1, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 1>(p, s);
+    return narrow ? launch_dma_t<1, 32, 1, 1, 1>(p, s) : launch_dma_t<1, 32, 2, 1, 1>(p, s);
+  }
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
   const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);

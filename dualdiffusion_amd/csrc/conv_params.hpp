@@ -25,6 +25,14 @@ struct ConvParams {
   int out_act;
   float out2_scale;
   int reflect_w;        // columns outside the image are mirrored (ReflectionPad on W) instead of zero
+  // DDX_EPI_SILU_BWD (data-gradient conv fused with the backward of the producer-side activation; `res` = y of the first part)
+  const void* bwd_y1;   // y of the second channel part (or null)
+  void* bwd_out1;       // output of the second channel part
+  const void* bwd_add;  // [B][H][W][Cout] gradient added to the result (or null)
+  float* bwd_ws;        // per (unit, wave) channel sums of dz * y for the dc reduction (or null)
+  float* bwd_dc;        // [B][Cout] accumulated chan_scale gradient (with bwd_ws)
+  int bwd_split, bwd_act;
+  float bwd_s0, bwd_s1;
   // spatial tiling (MFMA kernel)
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;
@@ -42,5 +50,6 @@ void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype);
 int launch_conv_direct(const ConvParams& p, int ksize, int dtype, hipStream_t s);  // conv_direct.hip
 bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size);  // conv_dma.hip
 int launch_conv_dma(const ConvParams& p, int ksize, hipStream_t s);
+size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize);  // per (unit, wave) channel sums of the DDX_EPI_SILU_BWD epilogue
 
 }  // namespace ddx

@@ -7,6 +7,7 @@ fallback.  Activations are NHWC (`[B, H, W, C]` contiguous) float32 or bfloat16 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -111,6 +112,46 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    pad_mode=L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO)
     check(lib().ddx_mpconv2d_fwd(C.byref(d), current_stream()), "mpconv2d_fwd")
     return out
+
+
+def conv2d_dgrad_act(dy: torch.Tensor, pw_t: PreparedWeight, y0: torch.Tensor, *, y1: Optional[torch.Tensor] = None, scale0: float = 1.0,
+                     scale1: float = 1.0, chan_scale: Optional[torch.Tensor] = None, dchan_scale: Optional[torch.Tensor] = None,
+                     add: Optional[torch.Tensor] = None, act: bool = True):
+    """Data gradient of a conv whose operand was a = mp_silu(y * chan_scale * scale) (act) / y * chan_scale * scale, through the
+    activation:  returns (dy0, dy1 | None) = silu_scale_bwd(conv2d(dy, pw_t), y, ...) per channel part (y0 | y1 are the two
+    sources of an mp_cat operand), `add` [.., C0 + C1] is added, dchan_scale [B, C] accumulates.  One LDS-DMA launch with the
+    activation backward in its epilogue when the layer qualifies (include/ddx_hip.h: ddx_mpconv2d_dgrad_act), otherwise the
+    conv followed by ddx_silu_scale_bwd per part."""
+    B, H, W, C0 = dy.shape
+    Cs = y0.shape[-1]
+    split = Cs if y1 is not None else 0
+    assert pw_t.Cout == Cs + (y1.shape[-1] if y1 is not None else 0)
+    out0 = torch.empty_like(y0)
+    out1 = torch.empty_like(y1) if y1 is not None else None
+    conv = L.ConvDesc(src0=ptr(dy), src1=None, chan_scale=None, wp=ptr(pw_t.wp), residual=None, out=ptr(out0), B=B, H=H, W=W, C0=C0, C1=0,
+                      Cout=pw_t.Cout, groups=pw_t.groups, ksize=pw_t.ksize, CK=pw_t.CK, resample=L.RESAMPLE_KEEP, prologue=L.PRO_NONE,
+                      epilogue=L.EPI_STORE, scale0=1.0, scale1=1.0, res_t=0.0, clip=0.0, dtype=dtype_code(dy.dtype), force_direct=0,
+                      out_scale=None, out2=None, out_act=0, out2_scale=1.0, pad_mode=L.PAD_ZERO)
+    d = L.DgradActDesc(conv=conv, y0=ptr(y0), y1=ptr(y1), out1=ptr(out1), add=ptr(add), chan_scale=ptr(chan_scale), dchan_scale=ptr(dchan_scale),
+                       workspace=None, split=split, act=int(act), scale0=float(scale0), scale1=float(scale1))
+    nbytes = lib().ddx_mpconv2d_dgrad_act_workspace_bytes(C.byref(d)) if (dy.dtype == torch.bfloat16 and _FUSE_DGRAD_ACT) else 0
+    if nbytes:
+        global _dgrad_act_fused_calls
+        _dgrad_act_fused_calls += 1
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if dchan_scale is not None else None
+        d.workspace = ptr(ws)
+        check(lib().ddx_mpconv2d_dgrad_act(C.byref(d), current_stream()), "mpconv2d_dgrad_act")
+        return out0, out1
+    da = conv2d(dy, pw_t)
+    if y1 is None:
+        return silu_scale_bwd(da, y0, chan_scale, scale0, dchan_scale, add=add, act=act), None
+    assert chan_scale is None and dchan_scale is None
+    return (silu_scale_bwd(da[..., :Cs], y0, None, scale0, add=add[..., :Cs] if add is not None else None, act=act),
+            silu_scale_bwd(da[..., Cs:], y1, None, scale1, add=add[..., Cs:] if add is not None else None, act=act))
+
+
+_FUSE_DGRAD_ACT = os.environ.get("DDX_FUSE_DGRAD_ACT", "1") != "0"
+_dgrad_act_fused_calls = 0      # how often the fused launch was taken (tests check that a qualifying layer really used it)
 
 
 def conv2d_wgrad(dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, *, x1: Optional[torch.Tensor] = None,

@@ -232,9 +232,8 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         dout_res, dyp = ops.mpsum_clip_bwd(dout, a["xa"], a["attn_t"], a["clip"])
         ap = a["ap"]
         g["dw_attn_proj"] = _wgrad(w, "attn_proj", t.pw["proj"], dyp, ap, 1, 1)
-        dap = ops.conv2d(dyp, _prep_t(w, "attn_proj", w.attn_proj, 1, dt))
         dc_v = w.cvec["dc_v"] if w.cvec is not None else torch.zeros_like(a["c_v"])
-        dao = ops.silu_scale_bwd(dap, a["ao"], a["c_v"], 1.0, dc_v)
+        dao, _ = ops.conv2d_dgrad_act(dyp, _prep_t(w, "attn_proj", w.attn_proj, 1, dt), a["ao"], chan_scale=a["c_v"], dchan_scale=dc_v)
         g["dw_emb_linear_v"], g["demb_gain_v"] = _linear_bwd(w, "emb_linear_v", dc_v, t.emb, w.emb_linear_v, 1, w.emb_gain_v.reshape(1), demb)
         dqk, dv = attention_backward(a["qk"], a["v"], dao, w.heads)
         # v = attn_v(out);  qk = attn_qk(out * c_qk) with the (head, {q,k}, d) row order of the forward preparation
@@ -242,9 +241,9 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
         dout_v = ops.conv2d(dv, _prep_t(w, "attn_v", w.attn_v, 1, dt))
         xs_qk = a["xs_qk"]
         g["dw_attn_qk"] = _wgrad(w, "attn_qk", t.pw["qk"], dqk, xs_qk, 1, 1)
-        dxs = ops.conv2d(dqk, _prep_t(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=t.out.shape[-1] // w.heads))
         dc_qk = w.cvec["dc_qk"] if w.cvec is not None else torch.zeros_like(a["c_qk"])
-        dout_qk = ops.silu_scale_bwd(dxs, t.out, a["c_qk"], 1.0, dc_qk, add=dout_v, act=False)
+        dout_qk, _ = ops.conv2d_dgrad_act(dqk, _prep_t(w, "attn_qk", w.attn_qk, 1, dt, qk_head_dim=t.out.shape[-1] // w.heads), t.out,
+                                          chan_scale=a["c_qk"], dchan_scale=dc_qk, add=dout_v, act=False)
         g["dw_emb_linear_qk"], g["demb_gain_qk"] = _linear_bwd(w, "emb_linear_qk", dc_qk, t.emb, w.emb_linear_qk, 1, one, demb)
         dout = ops.add3(dout_res, dout_qk)
     # out = clip(mp_sum(sk, y1, t))
@@ -252,17 +251,16 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     # y1 = conv_res1(a1), a1 = mp_silu(y0 * c)
     a1 = t.a1
     g["dw_conv_res1"] = _wgrad(w, "conv_res1", t.pw["res1"], dy1, a1, G, 3)
-    da1 = ops.conv2d(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt))
+    # data gradient of conv_res1 through a1 = mp_silu(y0 * c): one launch, the activation backward runs in the conv's epilogue
     dc = w.cvec["dc"] if w.cvec is not None else torch.zeros_like(t.c)
-    dy0 = ops.silu_scale_bwd(da1, t.y0, t.c, 1.0, dc)
+    dy0, _ = ops.conv2d_dgrad_act(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt), t.y0, chan_scale=t.c, dchan_scale=dc)
     # c = emb_linear(emb) * emb_gain + 1
     g["dw_emb_linear"], g["demb_gain"] = _linear_bwd(w, "emb_linear", dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), demb)
     g["dc"] = dc
     if t.flavor == "enc":
         a0 = t.a00
         g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a0, G, 3)
-        da0 = ops.conv2d(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt))
-        dx1 = ops.silu_scale_bwd(da0, t.x1, None, 1.0, add=dsk)
+        dx1, _ = ops.conv2d_dgrad_act(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt), t.x1, add=dsk)
         dxs = ops.pixelnorm_bwd(dx1, t.xs)
         if w.conv_skip is not None:
             g["dw_conv_skip"] = _wgrad(w, "conv_skip", t.pw["skip"], dxs, t.src0, 1, 1)
@@ -273,14 +271,14 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     else:
         a00, a01 = t.a00, t.a01
         g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a00, G, 3, x1=a01)
-        da0 = ops.conv2d(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt))
         if w.conv_skip is not None:
             g["dw_conv_skip"] = _wgrad(w, "conv_skip", t.pw["skip"], dsk, t.src0, 1, 1, x1=t.src1)
             dxs = ops.conv2d(dsk, _prep_t(w, "conv_skip", w.conv_skip, 1, dt, in_split=C0 if C1 else 0, in_scale0=t.s0, in_scale1=t.s1))
         else:
             dxs = dsk
-        dsrc0 = ops.silu_scale_bwd(da0[..., :C0], t.src0, None, t.s0, add=dxs[..., :C0])
-        dsrc1 = ops.silu_scale_bwd(da0[..., C0:], t.src1, None, t.s1, add=dxs[..., C0:]) if C1 else None
+        # data gradient of conv_res0 through mp_silu(s0 * src0) | mp_silu(s1 * src1), plus the skip-path gradient
+        dsrc0, dsrc1 = ops.conv2d_dgrad_act(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt), t.src0, y1=t.src1 if C1 else None, scale0=t.s0,
+                                            scale1=t.s1, add=dxs)
     g["din0"] = _resample_bwd(dsrc0, t.resample)
     g["din1"] = _resample_bwd(dsrc1, t.resample) if dsrc1 is not None else None
     return g

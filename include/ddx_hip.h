@@ -85,7 +85,7 @@ enum { DDX_RESAMPLE_KEEP = 0, DDX_RESAMPLE_UP = 1, DDX_RESAMPLE_DOWN = 2,
        /* adjoints, ddx_resample2d only: gradient of UP (2x2 sums) and of DOWN (nearest, x 1/4) */
        DDX_RESAMPLE_UP_BWD = 3, DDX_RESAMPLE_DOWN_BWD = 4 };
 enum { DDX_PRO_NONE = 0, DDX_PRO_SILU = 1, DDX_PRO_SCALE = 2, DDX_PRO_SCALE_SILU = 3 };
-enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1 };
+enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1, DDX_EPI_SILU_BWD = 2 /* internal: ddx_mpconv2d_dgrad_act */ };
 enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1 };
 
 typedef struct {
@@ -123,6 +123,33 @@ typedef struct {
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
 /* CK the library wants for a conv of this shape (call before wprep).  npix = B*H*W of the output (0 = unknown). */
 int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-gradient conv fused with the backward of the producer-side activation it feeds (training).
+ * The forward stored a = mp_silu(y * s) (act = 1) or a = y * s (act = 0), s[b][c] = chan_scale[b][c] * scale, as the operand
+ * of the conv described by `conv` (unet_edm2_b4.py:119-122, :139).  With dA = conv (src0 = dY, wp = the transposed
+ * preparation) this writes in the conv's epilogue, without dA ever reaching HBM,
+ *     dz = dA * mp_silu'(y * s) | dA;     out = dz * s (+ add);     dchan_scale[b][c] += scale * sum_pixels dz * y.
+ * The output channels may be split after `split` channels over two tensors with their own y and scalar scale (the two
+ * sources of an mp_cat: conv.out / y0 / scale0 hold channels [0, split), out1 / y1 / scale1 the rest; split % 64 == 0).
+ * LDS-DMA kernel only: ddx_mpconv2d_dgrad_act_workspace_bytes() returns 0 when the layer does not qualify -- run
+ * ddx_mpconv2d_fwd + ddx_silu_scale_bwd_ex then.  conv.epilogue / residual / out2 / out_act / out_scale are ignored.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  ddx_conv_desc conv;
+  const void* y0;            /* NHWC [B][H][W][split ? split : Cout] pre-activation tensor */
+  const void* y1;            /* NHWC [B][H][W][Cout - split] or NULL */
+  void* out1;                /* NHWC [B][H][W][Cout - split] or NULL */
+  const void* add;           /* NHWC [B][H][W][Cout] or NULL */
+  const float* chan_scale;   /* [B][Cout] fp32 or NULL */
+  float* dchan_scale;        /* [B][Cout] fp32, accumulated, or NULL (needs chan_scale, split = 0) */
+  float* workspace;          /* ddx_mpconv2d_dgrad_act_workspace_bytes() bytes (only used with dchan_scale) */
+  int32_t split, act;
+  float scale0, scale1;
+} ddx_dgrad_act_desc;
+
+size_t ddx_mpconv2d_dgrad_act_workspace_bytes(const ddx_dgrad_act_desc* d);
+int ddx_mpconv2d_dgrad_act(const ddx_dgrad_act_desc* d, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the conv (training, unet_trainer.py:246 `accelerator.backward`):

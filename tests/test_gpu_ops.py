@@ -502,3 +502,48 @@ def test_conv_reflect_w_padding(path, dtype):
     assert e < TOL[dtype], (path, e)
     # and it differs from zero padding (the test is not vacuous)
     assert rel_l2(to_nchw(ops.conv2d(to_nhwc(x, dtype), pw, path=path)), ref) > 1e-2
+
+
+@pytest.mark.parametrize("case", ["chan_scale", "two_parts_add", "two_parts_ng96", "scale_only"])
+def test_conv_dgrad_act_fused_matches_unfused(case):
+    """ddx_mpconv2d_dgrad_act (activation backward in the data-gradient conv's epilogue, LDS-DMA kernel) against the conv
+    followed by ddx_silu_scale_bwd.  The fused form differentiates the fp32 accumulator instead of the bf16-rounded conv
+    output: agreement to a bf16 rounding of the result (rel-L2 <= 4e-3), channel-scale gradient to 2e-3."""
+    ops = _ops()
+    dt, dev = torch.bfloat16, "cuda"
+    torch.manual_seed(3)
+    B, H, W, Cin_f, Cout_f, G = 2, 32, 256, 512, 256, 8
+    if case == "two_parts_ng96":     # 96 channels per group: the part boundary (512) only falls on a 32-channel tile start
+        Cin_f, Cout_f = 768, 512
+    w = torch.randn(Cout_f, Cin_f // G, 3, 3, device=dev)
+    pw_t = ops.wprep(w, G, dt, normalize=True, transpose=True)
+    dy = (torch.randn(B, H, W, Cout_f, device=dev) * 0.5).to(dt)
+    kw, y1 = {}, None
+    if case == "chan_scale":
+        y0 = torch.randn(B, H, W, Cin_f, device=dev).to(dt)
+        kw = dict(chan_scale=torch.rand(B, Cin_f, device=dev) + 0.5)
+    elif case.startswith("two_parts"):
+        c0 = 320 if case == "two_parts_add" else 512
+        y0 = torch.randn(B, H, W, c0, device=dev).to(dt)
+        y1 = torch.randn(B, H, W, Cin_f - c0, device=dev).to(dt)
+        kw = dict(scale0=0.8, scale1=1.3, add=torch.randn(B, H, W, Cin_f, device=dev).to(dt))
+    else:
+        y0 = torch.randn(B, H, W, Cin_f, device=dev).to(dt)
+        kw = dict(chan_scale=torch.rand(B, Cin_f, device=dev) + 0.5, add=torch.randn(B, H, W, Cin_f, device=dev).to(dt), act=False)
+    res = {}
+    n_fused = ops._dgrad_act_fused_calls
+    for fused in (True, False):
+        ops._FUSE_DGRAD_ACT = fused
+        dc = torch.zeros(B, Cin_f, device=dev) if "chan_scale" in kw else None
+        try:
+            o0, o1 = ops.conv2d_dgrad_act(dy, pw_t, y0, y1=y1, dchan_scale=dc, **kw)
+        finally:
+            ops._FUSE_DGRAD_ACT = True
+        torch.cuda.synchronize()
+        res[fused] = (o0.float(), o1.float() if o1 is not None else None, dc)
+    assert ops._dgrad_act_fused_calls == n_fused + 1, "the layer must qualify for the fused LDS-DMA launch"
+    assert rel_l2(res[True][0], res[False][0]) <= 4e-3
+    if y1 is not None:
+        assert rel_l2(res[True][1], res[False][1]) <= 4e-3
+    if res[True][2] is not None:
+        assert rel_l2(res[True][2], res[False][2]) <= 2e-3
