@@ -31,7 +31,7 @@ class WPrepDesc(C.Structure):
                 ("w_dtype", C.c_int32), ("wp_dtype", C.c_int32), ("Cout", C.c_int32), ("Cg", C.c_int32),
                 ("ksize", C.c_int32), ("groups", C.c_int32), ("CK", C.c_int32), ("normalize", C.c_int32),
                 ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float),
-                ("transpose", C.c_int32), ("row_scale", C.c_void_p)]
+                ("transpose", C.c_int32), ("row_scale", C.c_void_p), ("row_offset", C.c_int32), ("rows_total", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
                 ("scale0", C.c_float), ("scale1", C.c_float), ("res_t", C.c_float), ("clip", C.c_float),
                 ("dtype", C.c_int32), ("force_direct", C.c_int32),
                 ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float),
-                ("pad_mode", C.c_int32)]
+                ("pad_mode", C.c_int32), ("prologue_rows", C.c_int32)]
 
 
 class DgradActDesc(C.Structure):
@@ -173,6 +173,8 @@ PROTOTYPES = {
     "ddx_linear_small_bwd_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_mpconv2d_dgrad_act_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "ddx_mpconv2d_dgrad_act": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_attn_act_fwd_ld": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_wpath_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_nhwc_to_nchw_ld": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_plan_begin": (C.c_void_p, []),

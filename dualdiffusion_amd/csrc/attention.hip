@@ -26,7 +26,7 @@ template <> struct AttnMma<float> {
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
-                                                       const float* __restrict__ out_cs, int B, int Tn, int heads, float eps) {
+                                                       const float* __restrict__ out_cs, int B, int Tn, int heads, float eps, int qk_ld, int v_ld) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int VPR = D / EV;           // 16-byte vectors per token row
   constexpr int RPP = 256 / VPR;        // rows staged per pass
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
     float f[EV];
     float ss = 0.f;
     if (q < Tn) {
-      x.v = *reinterpret_cast<const decltype(x.v)*>(qk + ((size_t)b * Tn + q) * (2 * C) + head * 2 * D + sv * EV);
+      x.v = *reinterpret_cast<const decltype(x.v)*>(qk + ((size_t)b * Tn + q) * qk_ld + head * 2 * D + sv * EV);
 #pragma unroll
       for (int e = 0; e < EV; ++e) { f[e] = x.get(e); ss += f[e] * f[e]; }
     } else {
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
       float ssk = 0.f, ssv = 0.f;
       if (key < Tn) {
         Vec16<T> xk, xv;
-        xk.v = *reinterpret_cast<const decltype(xk.v)*>(qk + ((size_t)b * Tn + key) * (2 * C) + head * 2 * D + D + sv * EV);
-        xv.v = *reinterpret_cast<const decltype(xv.v)*>(v + ((size_t)b * Tn + key) * C + head * D + sv * EV);
+        xk.v = *reinterpret_cast<const decltype(xk.v)*>(qk + ((size_t)b * Tn + key) * qk_ld + head * 2 * D + D + sv * EV);
+        xv.v = *reinterpret_cast<const decltype(xv.v)*>(v + ((size_t)b * Tn + key) * v_ld + head * D + sv * EV);
 #pragma unroll
         for (int e = 0; e < EV; ++e) {
           fk[e] = xk.get(e); ssk += fk[e] * fk[e];
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 }
 
 template <typename T, int D>
-static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s) {
+static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
+                       int v_ld) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int KC = 128;
   const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + (size_t)D * (KC + AttnMma<T>::VPAD)) * sizeof(T);
@@ -245,7 +246,7 @@ static int launch_attn(const void* qk, const void* v, void* out, const float* cs
     attr_done = true;
   }
   dim3 grid((Tn + 127) / 128, heads, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps, qk_ld, v_ld);
   return check_launch("attn_fwd");
 }
 
@@ -260,17 +261,24 @@ extern "C" int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B,
 
 extern "C" int ddx_attn_act_fwd(const void* qk, const void* v, void* out, const float* out_scale, int32_t B, int32_t T, int32_t heads,
                                 int32_t head_dim, float eps, int32_t dtype, ddx_stream stream) {
+  return ddx_attn_act_fwd_ld(qk, 2 * heads * head_dim, v, heads * head_dim, out, out_scale, B, T, heads, head_dim, eps, dtype, stream);
+}
+
+extern "C" int ddx_attn_act_fwd_ld(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t B,
+                                   int32_t T, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream) {
   if (!qk || !v || !out || B <= 0 || T <= 0 || heads <= 0) return set_error(DDX_ERR_ARG, "attn: bad args");
   if (head_dim != 32 && head_dim != 64 && head_dim != 128) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim must be 32, 64 or 128");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (qk_ld < 2 * heads * head_dim || v_ld < heads * head_dim || qk_ld % ev || v_ld % ev) return set_error(DDX_ERR_ARG, "attn: bad row strides");
   return dispatch([=](hipStream_t s) -> int {
     if (dtype == DDX_BF16) {
-      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s);
-      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, out_scale, B, T, heads, eps, s);
-      return launch_attn<bf16, 128>(qk, v, out, out_scale, B, T, heads, eps, s);
+      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
+      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
+      return launch_attn<bf16, 128>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
     }
-    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, out_scale, B, T, heads, eps, s);
-    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, out_scale, B, T, heads, eps, s);
-    return launch_attn<float, 128>(qk, v, out, out_scale, B, T, heads, eps, s);
+    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
+    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
+    return launch_attn<float, 128>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
   }, stream, "attention", 4.0 * B * heads * (double)T * T * head_dim,
      (double)dtype_size(dtype) * 4.0 * B * T * heads * head_dim);
 }

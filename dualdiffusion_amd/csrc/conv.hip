@@ -13,9 +13,10 @@ namespace ddx {
 template <typename TW_, typename TP>
 __global__ __launch_bounds__(256) void wprep_kernel(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr,
                                                     float gain, int Cout, int Cg, int taps, int G, int CK, int normalize,
-                                                    int qk_d, float eps, int in_split, float in_s0, float in_s1) {
+                                                    int qk_d, float eps, int in_split, float in_s0, float in_s1, int row_off, int rows_total) {
   __shared__ float scratch[4];
-  wprep_row<TW_, TP>(w, wp, gain_ptr, gain, Cout, Cg, taps, G, CK, normalize, qk_d, eps, in_split, in_s0, in_s1, blockIdx.x, scratch);
+  wprep_row<TW_, TP>(w, wp, gain_ptr, gain, Cout, Cg, taps, G, CK, normalize, qk_d, eps, in_split, in_s0, in_s1, blockIdx.x, scratch, row_off,
+                     rows_total);
 }
 
 // ---- data-gradient (transposed) preparation: per-row scale first, then one workgroup per destination row (g, c)
@@ -63,6 +64,8 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
   if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 32 && d.CK != 64 && d.CK != 128))
     return set_error(DDX_ERR_ARG, "wprep: bad shape");
   if (d.qk_head_dim > 0 && (d.groups != 1 || d.Cout % (2 * d.qk_head_dim))) return set_error(DDX_ERR_ARG, "wprep: bad qk_head_dim");
+  if (d.rows_total != 0 && (d.groups != 1 || d.transpose || d.row_offset < 0 || d.row_offset + d.Cout > d.rows_total))
+    return set_error(DDX_ERR_ARG, "wprep: row_offset / rows_total describe a slice of a merged forward matrix (groups = 1)");
   if (d.transpose) {
     if (!d.row_scale) return set_error(DDX_ERR_ARG, "wprep: transpose needs the row_scale workspace");
     return dispatch([d](hipStream_t s) -> int {
@@ -92,13 +95,13 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
     const int taps = d.ksize * d.ksize;
     const int Ng = d.Cout / d.groups;
     const size_t bytes = ddx_wprep_bytes(d.Cout, d.Cg, d.ksize, d.groups, d.CK, d.wp_dtype);
-    if (round_up(Ng, 32) != Ng || d.Cg % d.CK) {
+    if (d.rows_total == 0 && (round_up(Ng, 32) != Ng || d.Cg % d.CK)) {  // (merged matrices are zero-filled by their owner)
       if (hipMemsetAsync(d.wp, 0, bytes, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "wprep: memset");
     }
 #define DDX_WPREP(TWT, TPT)                                                                                         \
   hipLaunchKernelGGL((wprep_kernel<TWT, TPT>), dim3(d.Cout), dim3(256), 0, s, (const TWT*)d.w, (TPT*)d.wp, d.gain_ptr, \
                      d.gain, d.Cout, d.Cg, taps, d.groups, d.CK, d.normalize, d.qk_head_dim, 1e-4f, d.in_split, d.in_scale0,   \
-                     d.in_scale1)
+                     d.in_scale1, d.row_offset, d.rows_total)
     if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_F32) DDX_WPREP(float, float);
     else if (d.w_dtype == DDX_F32 && d.wp_dtype == DDX_BF16) DDX_WPREP(float, bf16);
     else if (d.w_dtype == DDX_BF16 && d.wp_dtype == DDX_BF16) DDX_WPREP(bf16, bf16);
@@ -154,6 +157,7 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.Cg = Cin / d.groups; p.Ng = d.Cout / d.groups; p.NgP = round_up(p.Ng, 32);
   p.CK = d.CK; p.nchunk = ceil_div(p.Cg, d.CK);
   p.resample = d.resample; p.prologue = d.prologue; p.epilogue = d.epilogue;
+  p.pro_rows = d.prologue_rows;
   p.scale0 = d.scale0; p.scale1 = d.scale1;
   const float t = d.res_t, nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
   p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;

@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
           x = to_f32<T>(src[(((size_t)b * p.sH + sh) * p.sW + sw) * Cs + cc]);
         }
         x *= first ? p.scale0 : p.scale1;
-        if (p.prologue & DDX_PRO_SCALE) x *= p.cscale[(size_t)b * p.Cin + cabs];
-        if (p.prologue & DDX_PRO_SILU) x = mp_silu_f(x);
+        const int pro = (p.pro_rows > 0 && o >= p.pro_rows) ? DDX_PRO_NONE : p.prologue;
+        if (pro & DDX_PRO_SCALE) x *= p.cscale[(size_t)b * p.Cin + cabs];
+        if (pro & DDX_PRO_SILU) x = mp_silu_f(x);
         x = to_f32<T>(from_f32<T>(x));  // the MFMA path rounds the operand to T in LDS
         acc += x * to_f32<T>(wp[wp_index(g, n, tap, c, p.nchunk, taps, p.NgP, p.CK)]);
       }

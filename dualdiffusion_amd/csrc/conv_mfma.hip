@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
   const int v = tid % V;
   const int r0 = tid / V;
   const T* wp = reinterpret_cast<const T*>(p.wp);
-  const bool do_silu = (p.prologue & DDX_PRO_SILU) != 0;
+  // (n0 is workgroup-uniform: a merged conv switches the prologue per output-channel tile)
+  const int pro = (p.pro_rows > 0 && g * p.Ng + n0 >= p.pro_rows) ? DDX_PRO_NONE : p.prologue;
+  const bool do_silu = (pro & DDX_PRO_SILU) != 0;
 
   // per-item source pixel offsets (in pixels of the source image); invalid items load pixel 0 and are zeroed at
   // commit time, so the issue phase is straight-line code (no per-item branches -> no forced vmcnt(0) at joins)
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     a_cc = first ? cabs : cabs - p.C0;
     cvalid_cur = cvalid;
     sscale_cur = first ? p.scale0 : p.scale1;
-    if (p.prologue & DDX_PRO_SCALE) {  // raw per-(b, channel) factors; folded with the source scale at commit time
+    if (pro & DDX_PRO_SCALE) {  // raw per-(b, channel) factors; folded with the source scale at commit time
       const float* csp = p.cscale + (size_t)b * p.Cin + cabs;
 #pragma unroll
       for (int e = 0; e < EV; e += 4) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     }
   };
   // prologue-free fast path: the staged vectors go to LDS untouched (no unpack / scale / repack VALU work)
-  const bool do_raw = !DN && p.prologue == DDX_PRO_NONE && p.scale0 == 1.0f && (p.src1 == nullptr || p.scale1 == 1.0f);
+  const bool do_raw = !DN && pro == DDX_PRO_NONE && p.scale0 == 1.0f && (p.src1 == nullptr || p.scale1 == 1.0f);
   auto commit_raw = [&]() {
     Vec16<T> z;
 #pragma unroll

@@ -17,6 +17,7 @@ struct ConvParams {
   int Cout, G, Cg, Ng, NgP;
   int nchunk, CK;
   int resample, prologue, epilogue;
+  int pro_rows;       // > 0: the prologue only applies to output channels below it (merged attn_qk | attn_v conv: qk reads x * c_qk, v reads x)
   float scale0, scale1;
   float res_a, res_b;  // out = res * res_a + acc * res_b
   float clip;

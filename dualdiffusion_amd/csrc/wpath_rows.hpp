@@ -17,9 +17,10 @@ __device__ __forceinline__ int wpath_src_row(int od, int qk_d) {
 template <typename TW_, typename TP>
 __device__ __forceinline__ void wprep_row(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr, float gain, int Cout, int Cg,
                                           int taps, int G, int CK, int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1,
-                                          int od, float* scratch) {
-  const int Ng = Cout / G, NgP = (Ng + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
-  const int g = od / Ng, n = od - g * Ng;
+                                          int od, float* scratch, int row_off = 0, int rows_total = 0) {
+  // row_off / rows_total: this weight fills rows [row_off, row_off + Cout) of a wider prepared matrix (merged 1x1 convs, G = 1)
+  const int Ng = Cout / G, NgP = ((rows_total > 0 ? rows_total : Ng) + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
+  const int g = od / Ng, n = od - g * Ng + row_off;
   const int os = wpath_src_row(od, qk_d);
   const int fan = Cg * taps;
   const TW_* wr = w + (size_t)os * fan;

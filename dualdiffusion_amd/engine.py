@@ -11,6 +11,7 @@ src/modules/old/vaes/vae_edm2.py:96-156), which is the same launch sequence for 
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Optional
 
 import torch
@@ -25,6 +26,9 @@ def mp_cat_weights(na: int, nb: int, t: float) -> tuple:
     """Scalars of the magnitude-preserving concat (reference mp_tools.py:294-301)."""
     c = math.sqrt((na + nb) / ((1 - t) ** 2 + t ** 2))
     return c / math.sqrt(na) * (1 - t), c / math.sqrt(nb) * t
+
+
+MERGE_QKV = os.environ.get("DDX_MERGE_QKV", "1") != "0"     # attn_qk | attn_v as one conv (engine.PlanBuilder.block)
 
 
 class PlanBuilder:
@@ -76,6 +80,25 @@ class PlanBuilder:
         self.convs.append(dict(conv=conv, wsrc=wsrc, buf=buf, CK=CK, qk=qk_head_dim, cg_pad=cg_pad, in_split=in_split, in_scale0=in_scale0,
                                in_scale1=in_scale1, gain_slot=self.gain_slot(gain_param) if gain_param is not None else None))
         return ops.PreparedWeight(buf, w.shape[0], Cg, ks, conv.groups, CK, self.dt, None)
+
+    def prep_merged(self, parts: list, npix: int = 0):
+        """Several 1x1 convs on the same input as ONE prepared matrix (rows concatenated): parts = [(conv, qk_head_dim), ...].
+        Each part is prepared into its row range whenever `wplan` runs."""
+        w0 = parts[0][0].weight
+        Cg = w0.shape[1]
+        total = sum(c.weight.shape[0] for c, _ in parts)
+        assert all(c.weight.shape[1] == Cg and c.groups == 1 and c.weight.ndim in (2, 4) and (c.weight.ndim == 2 or c.weight.shape[2] == 1)
+                   for c, _ in parts)
+        CK = ops.pick_ck(Cg, 1, self.dt, npix)
+        nbytes = ops.lib().ddx_wprep_bytes(total, Cg, 1, 1, CK, ops.dtype_code(self.dt))
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)       # padding rows stay zero
+        self.keep.append(buf)
+        off = 0
+        for conv, qk in parts:
+            self.convs.append(dict(conv=conv, wsrc=None, buf=buf, CK=CK, qk=qk, cg_pad=None, in_split=0, in_scale0=1.0, in_scale1=1.0,
+                                   gain_slot=None, row_offset=off, rows_total=total))
+            off += conv.weight.shape[0]
+        return ops.PreparedWeight(buf, total, Cg, 1, 1, CK, self.dt, None)
 
     def cvec(self, lin, gain_param, add_const: float = 1.0) -> torch.Tensor:
         """Per-(batch, channel) vector lin(emb)*gain + add_const, produced by the batched small-M kernel."""
@@ -158,19 +181,21 @@ class PlanBuilder:
             return xo, twin
         c_qk, c_v = self.cvec(blk.emb_linear_qk, blk.emb_gain_qk), self.cvec(blk.emb_linear_v, blk.emb_gain_v)
         heads = blk.num_heads
-        pw_qk = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix)
-        pw_v, pw_proj = self.prep(blk.attn_v, npix=npix), self.prep(blk.attn_proj, npix=npix)
-        qk, vv, ao, xa = self.act(h, w, 2 * cout), self.act(h, w, cout), self.act(h, w, cout), self.act(h, w, cout)
+        # attn_qk and attn_v read the same tensor: ONE conv over the row-concatenated weights writes [q|k (2C) | v (C)]; the
+        # channel-scale prologue (x * c_qk) only applies to the q|k output tiles (one 15 us small-M launch less per block)
+        pw_proj = self.prep(blk.attn_proj, npix=npix)
+        ao, xa = self.act(h, w, cout), self.act(h, w, cout)
         tw_proj = dict(out2=twin, out2_scale=twin_scale) if twin is not None else {}
-        two_lanes = npix <= self.LANE_MAX_PIXELS
-        if two_lanes:
-            S(self._fork)                                       # attn_v next to attn_qk (both read the block output)
-        S(lambda: ops.conv2d(xo, pw_v, out=vv))
-        if two_lanes:
-            S(self._main)
-        S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
-        if two_lanes:
-            S(self._join)
+        if MERGE_QKV:
+            pw_qkv = self.prep_merged([(blk.attn_qk, cout // heads), (blk.attn_v, 0)], npix=npix)
+            qkv = self.act(h, w, 3 * cout)
+            qk, vv = qkv[..., :2 * cout], qkv[..., 2 * cout:]
+            S(lambda: ops.conv2d(xo, pw_qkv, prologue=PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * cout, out=qkv))
+        else:
+            pw_qk, pw_v = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix), self.prep(blk.attn_v, npix=npix)
+            qk, vv = self.act(h, w, 2 * cout), self.act(h, w, cout)
+            S(lambda: ops.conv2d(xo, pw_v, out=vv))
+            S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
@@ -213,7 +238,7 @@ class PlanBuilder:
                 ops.wprep(conv.weight if sp["wsrc"] is None else sp["wsrc"], conv.groups, self.dt, gain_ptr=self.gain_ptr(sp["gain_slot"]),
                           normalize=self.training and not conv.disable_weight_norm, qk_head_dim=sp["qk"], CK=sp["CK"],
                           cg_pad=sp["cg_pad"], out=sp["buf"], in_split=sp["in_split"], in_scale0=sp["in_scale0"],
-                          in_scale1=sp["in_scale1"])
+                          in_scale1=sp["in_scale1"], row_offset=sp.get("row_offset", 0), rows_total=sp.get("rows_total", 0))
         with self.fplan.record():
             if pre_steps is not None:
                 pre_steps()

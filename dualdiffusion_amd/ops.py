@@ -33,7 +33,7 @@ def pick_ck(Cg: int, ksize: int, dtype: torch.dtype, npix: int = 0) -> int:
 def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float = 1.0, gain_ptr: Optional[torch.Tensor] = None,
           normalize: bool = False, qk_head_dim: int = 0, CK: Optional[int] = None, cg_pad: Optional[int] = None,
           out: Optional[torch.Tensor] = None, npix: int = 0, in_split: int = 0, in_scale0: float = 1.0,
-          in_scale1: float = 1.0, transpose: bool = False) -> PreparedWeight:
+          in_scale1: float = 1.0, transpose: bool = False, row_offset: int = 0, rows_total: int = 0) -> PreparedWeight:
     """Prepare MPConv weights `[Cout, Cg, k, k]` for ddx_mpconv2d_fwd.  `cg_pad`: channel count of the activation
     tensor per group when it is zero-padded beyond the weight's Cg (conv_in: 6 -> 8).
     transpose: prepare the data-gradient conv instead (dX = conv2d(dY, wprep(w, transpose=True)))."""
@@ -44,17 +44,19 @@ def wprep(weight: torch.Tensor, groups: int, dtype: torch.dtype, *, gain: float 
         return _wprep_transposed(weight, groups, dtype, gain, gain_ptr, normalize, qk_head_dim, CK, out, npix, in_split, in_scale0, in_scale1)
     if CK is None:
         CK = pick_ck(cg_pad or Cg, ksize, dtype, npix)
-    nbytes = lib().ddx_wprep_bytes(Cout, Cg, ksize, groups, CK, dtype_code(dtype))
+    nbytes = lib().ddx_wprep_bytes(rows_total or Cout, Cg, ksize, groups, CK, dtype_code(dtype))
     if cg_pad is not None:
         assert (cg_pad + CK - 1) // CK == (Cg + CK - 1) // CK, "padded channels must stay inside the last K chunk"
     if out is None:
+        assert rows_total == 0, "a merged prepared matrix is allocated (zero-filled) by the caller"
         out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     assert out.numel() >= nbytes
     d = L.WPrepDesc(w=ptr(weight), wp=ptr(out), gain_ptr=ptr(gain_ptr), gain=float(gain), w_dtype=dtype_code(weight.dtype),
                     wp_dtype=dtype_code(dtype), Cout=Cout, Cg=Cg, ksize=ksize, groups=groups, CK=CK,
-                    normalize=int(normalize), qk_head_dim=qk_head_dim, in_split=in_split, in_scale0=in_scale0, in_scale1=in_scale1)
+                    normalize=int(normalize), qk_head_dim=qk_head_dim, in_split=in_split, in_scale0=in_scale0, in_scale1=in_scale1,
+                    row_offset=row_offset, rows_total=rows_total)
     check(lib().ddx_mpconv_wprep(C.byref(d), current_stream()), "mpconv_wprep")
-    pw = PreparedWeight(out, Cout, Cg, ksize, groups, CK, dtype, d)
+    pw = PreparedWeight(out, rows_total or Cout, Cg, ksize, groups, CK, dtype, d)
     pw.refs = (weight, gain_ptr)
     return pw
 
@@ -92,7 +94,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
-           path: str = "auto", reflect_w: bool = False) -> torch.Tensor:
+           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0) -> torch.Tensor:
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
@@ -109,7 +111,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
                    res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=1 if force_direct else {"auto": 0, "direct": 1, "mfma": 2, "dma": 3}[path],
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
-                   pad_mode=L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO)
+                   pad_mode=L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO, prologue_rows=prologue_rows)
     check(lib().ddx_mpconv2d_fwd(C.byref(d), current_stream()), "mpconv2d_fwd")
     return out
 
@@ -310,12 +312,15 @@ def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 
 def attention(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None, eps: float = 1e-4,
               out_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qk `[B, H, W, 2C]` (head, {q,k}, d), v `[B, H, W, C]` (head, d) -> `[B, H, W, C]`;
-    with `out_scale` [B, C] fp32 the stored result is mp_silu(o * out_scale) (operand of attn_proj)."""
+    with `out_scale` [B, C] fp32 the stored result is mp_silu(o * out_scale) (operand of attn_proj).
+    qk / v may be channel slices of one wider NHWC tensor (a merged attn_qk | attn_v conv output)."""
     B, H, W, Cn = v.shape
     if out is None:
-        out = torch.empty_like(v)
-    check(lib().ddx_attn_act_fwd(ptr(qk), ptr(v), ptr(out), ptr(out_scale), B, H * W, heads, Cn // heads, eps, dtype_code(v.dtype),
-                                 current_stream()), "attn_fwd")
+        out = torch.empty(B, H, W, Cn, dtype=v.dtype, device=v.device)
+    qk_p, qk_ld = _chan_view(qk, 2 * Cn)
+    v_p, v_ld = _chan_view(v, Cn)
+    check(lib().ddx_attn_act_fwd_ld(qk_p, qk_ld, v_p, v_ld, ptr(out), ptr(out_scale), B, H * W, heads, Cn // heads, eps, dtype_code(v.dtype),
+                                    current_stream()), "attn_fwd")
     return out
 
 

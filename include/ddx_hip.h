@@ -65,6 +65,10 @@ typedef struct {
    *   (size ddx_wprep_bytes(groups*Cg, Ng, ksize, groups, CK, dtype)).  row_scale: [Cout] fp32 workspace (caller-owned). */
   int32_t transpose;
   float* row_scale;
+  /* rows_total > 0: this weight fills rows [row_offset, row_offset + Cout) of a prepared matrix with rows_total rows
+   * (ddx_wprep_bytes(rows_total, ...); zero-filled by the caller once) -- several 1x1 convs on the same input run as ONE
+   * conv (attn_qk | attn_v, unet_edm2_b4.py:139-140).  groups = 1, transpose = 0. */
+  int32_t row_offset, rows_total;
 } ddx_wprep_desc;
 
 size_t ddx_wprep_bytes(int32_t Cout, int32_t Cg, int32_t ksize, int32_t groups, int32_t CK, int32_t dtype);
@@ -118,6 +122,9 @@ typedef struct {
   /* DDX_PAD_ZERO (F.conv2d padding) | DDX_PAD_REFLECT_W: zero rows above / below, mirrored columns left / right -- the
    * ReflectionPad3d((k/2, k/2, 0, 0, ...)) + conv3d(padding=(0, k/2, 0)) of MPConv3D (modules/daes/dae_edm2_d3.py:62-84). */
   int32_t pad_mode;
+  /* > 0: the prologue (chan_scale / mp_silu) only applies to output channels below prologue_rows; the rest read the raw
+   * input (merged attn_qk | attn_v conv: qk = conv(x * c_qk), v = conv(x)).  Must be a multiple of 64. */
+  int32_t prologue_rows;
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
@@ -287,6 +294,10 @@ int ddx_attn_fwd(const void* qk, const void* v, void* out, int32_t B, int32_t T,
 /* Same with the producer-side activation of attn_proj's operand: out = mp_silu(o * out_scale[b][c]) (unet_edm2_b4.py:150-151). */
 int ddx_attn_act_fwd(const void* qk, const void* v, void* out, const float* out_scale, int32_t B, int32_t T, int32_t heads,
                      int32_t head_dim, float eps, int32_t dtype, ddx_stream stream);
+/* Same with explicit row strides (elements): qk rows are qk_ld apart, v rows v_ld -- q|k and v may be channel ranges of one
+ * merged [B][T][3C] tensor written by a single conv. */
+int ddx_attn_act_fwd_ld(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t B,
+                        int32_t T, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-M linear layers on raw master weights (no wprep): out[b][o] = post( sum_k x[b][k] * w'[o][k] )

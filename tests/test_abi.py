@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_descriptor_struct_layout_matches_header():
     """ctypes mirrors of the C descriptors: sizes follow from the field lists in the header (LP64)."""
     from dualdiffusion_amd import _lib
-    assert ctypes.sizeof(_lib.WPrepDesc) == 88  # 3 pointers, float, 10 int32, 2 floats, int32 transpose, pointer row_scale
+    assert ctypes.sizeof(_lib.WPrepDesc) == 96  # 3 pointers, float, 10 int32, 2 floats, int32 transpose, pointer row_scale, 2 int32
     assert ctypes.sizeof(_lib.WgradDesc) == 88  # 5 pointers, 11 int32 (+4 tail padding)
     assert ctypes.sizeof(_lib.MssDesc) == 96    # 7 pointers, 8 int32, float (+4 tail padding)
     assert ctypes.sizeof(_lib.WPathJob) == 112  # 8 pointers, float, 9 int32, 2 floats
