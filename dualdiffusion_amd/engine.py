@@ -29,6 +29,10 @@ def mp_cat_weights(na: int, nb: int, t: float) -> tuple:
 
 
 MERGE_QKV = os.environ.get("DDX_MERGE_QKV", "1") != "0"     # attn_qk | attn_v as one conv (engine.PlanBuilder.block)
+# batched emb_linear on the plan's side lane (PlanBuilder.finalize).  Measured (MI355X, hipGraph, default UNet B=4): 5.14 ms per
+# step with the lane vs 5.055 ms without -- the 130 MB weight stream slows the HBM-bound L0 convs it runs beside by more than
+# the 55 us it hides -> off by default.
+EMB_LANE = os.environ.get("DDX_EMB_LANE", "0") != "0"
 
 
 class PlanBuilder:
@@ -39,6 +43,7 @@ class PlanBuilder:
         self.gains: list = []       # 0-d gain parameters, mirrored into one fp32 vector read by the kernels
         self.convs: list = []       # weight-preparation specs
         self.padded: list = []      # (conv, zero-row-padded weight copy) for convs prepared with cout_pad
+        self.first_cvec_step: Optional[int] = None   # index of the first step that reads a modulation vector (see finalize)
         self.lin_jobs: list = []    # (weight holder, gain slot, out tensor, groups, add_const)
         self.steps: list = []       # closures executed while recording the forward plan
         self.wplan, self.fplan = Plan(), Plan()
@@ -150,9 +155,13 @@ class PlanBuilder:
                 S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
             else:
                 S(lambda: ops.pixelnorm(src0, out=x1, out_act=x1a))
+            if self.first_cvec_step is None:
+                self.first_cvec_step = len(self.steps)     # conv_res0 is the first reader of a modulation vector
             S(lambda: ops.conv2d(x1a, pw_res0, out_act=True, out_scale=c_emb, out=y0))
             S(lambda: ops.conv2d(y0, pw_res1, residual=x1, res_t=res_balance, clip=last_clip, out=xo, **tw_res1))
         else:
+            if self.first_cvec_step is None:
+                self.first_cvec_step = len(self.steps)
             if act0 is not None and (src1 is None or act1 is not None):
                 S(lambda: ops.conv2d(act0, pw_res0, out_hw=(h, w), src1=act1, resample=rs, out_act=True, out_scale=c_emb, out=y0))
             else:   # no twins available: fused prologue on the raw inputs
@@ -242,9 +251,18 @@ class PlanBuilder:
         with self.fplan.record():
             if pre_steps is not None:
                 pre_steps()
+            # the batched emb_linear launch streams every block's modulation weights (~130 MB for the default UNet, ~55 us);
+            # optionally (EMB_LANE) on the plan's side lane next to the front of the network, joined before the first conv_res0
+            lane = EMB_LANE and bool(self.lin_jobs) and self.first_cvec_step is not None and self.first_cvec_step > 0
+            if lane:
+                self._fork()
             if self.lin_jobs:
                 ops.linear_small(self.emb_table, n_jobs, max_o, emb, self.B, wdt, x_stride=emb_stride)
-            for st in self.steps:
+            if lane:
+                self._main()
+            for i, st in enumerate(self.steps):
+                if lane and i == self.first_cvec_step:
+                    self._join()
                 st()
 
     def refresh_weights(self, params) -> None:
