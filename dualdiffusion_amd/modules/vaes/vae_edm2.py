@@ -165,15 +165,29 @@ class AutoencoderKL_EDM2(DualDiffusionVAE):
             eng = self._engines[key] = _VAEEngine(self, kind, B, H, W, self.training)
         return eng
 
+    # A launch plan keeps every activation of its batch alive (~17 GB per 45 s sample for the decoder at the mel resolution):
+    # larger batches run as chunks of this many samples through one plan (config 5: B = 16 -> 4 chunks).
+    max_plan_batch = 4
+
+    def _run_chunked(self, kind: str, x: torch.Tensor, emb: torch.Tensor, format) -> torch.Tensor:
+        B, n = x.shape[0], self.max_plan_batch
+        if B <= n:
+            return self._engine(kind, x.shape).run(x, emb, format, self._use_graph)
+        outs = []
+        for i in range(0, B, n):
+            xc, ec = x[i:i + n], emb[i:i + n]
+            outs.append(self._engine(kind, xc.shape).run(xc, ec, format, self._use_graph, full_batch=B))
+        return torch.cat(outs, dim=0)
+
     def encode(self, x: torch.Tensor, class_embeddings: torch.Tensor, format) -> IsotropicGaussianDistribution:
         """reference vae_edm2.py:259-269."""
-        mean = self._engine("enc", x.shape).run(x, class_embeddings, format, self._use_graph)
+        mean = self._run_chunked("enc", x, class_embeddings, format)
         logvar = torch.tensor(math.log(1 / (self.config.target_snr ** 2 + 1)), device=mean.device, dtype=mean.dtype)
         return IsotropicGaussianDistribution(mean, logvar)
 
     def decode(self, x: torch.Tensor, class_embeddings: torch.Tensor, format) -> torch.Tensor:
         """reference vae_edm2.py:271-279."""
-        return self._engine("dec", x.shape).run(x, class_embeddings, format, self._use_graph)
+        return self._run_chunked("dec", x, class_embeddings, format)
 
     def forward(self, x, class_embeddings, format):
         return self.decode(self.encode(x, class_embeddings, format).mode(), class_embeddings, format)
@@ -227,10 +241,13 @@ class _VAEEngine:
         pb.step(lambda: ops.nhwc_to_nchw(y, out=self.out, channels=cout))
         pb.finalize(self.emb, vae.emb_dim, pre_steps=lambda: ops.unet_input_prep(self.x_in, self.zero_sigma, self.lnf, x0, 1.0))
 
-    def run(self, x, emb, format, use_graph: bool) -> torch.Tensor:
-        lkey = (id(format),)
+    def run(self, x, emb, format, use_graph: bool, full_batch: Optional[int] = None) -> torch.Tensor:
+        # the reference standardises ln_freqs over the WHOLE batch tensor (unbiased std: depends on the element count), so a
+        # chunk of a larger batch asks for the table of the full batch size
+        nb = full_batch or self.B
+        lkey = (id(format), nb)
         if lkey != self._lnf_key:
-            rows = format.get_ln_freqs(torch.empty(self.B, 1, self.H, self.W))[0, 0, :, 0]   # host-side table, same dtype sequence
+            rows = format.get_ln_freqs(torch.empty(nb, 1, self.H, self.W))[0, 0, :, 0]   # host-side table, same dtype sequence
             self.lnf.copy_(rows.float())
             self._lnf_key = lkey
         self.pb.refresh_weights(self.v.parameters())

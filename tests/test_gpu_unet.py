@@ -131,6 +131,13 @@ def test_vae_encode_decode_fp32_and_bf16():
         print(f"vae {dtype}: encode {e1:.3e} decode {e2:.3e}")
         assert e1 < tol and e2 < tol
         assert abs(float(dist.logvar) - float(t["noise_logvar"])) < 1e-6
+        # batches above max_plan_batch run as chunks through one plan (other tile choices at the smaller batch: same tolerance;
+        # the ln_freq table is still the whole batch's)
+        vae.max_plan_batch = 1
+        with torch.no_grad():
+            dist1 = vae.encode(t["x"].cuda(), t["emb"].cuda(), Fmt())
+            rec1 = vae.decode(t["latents"].cuda(), t["emb"].cuda(), Fmt())
+        assert rel_l2(dist1.mode(), t["latents"]) < tol and rel_l2(rec1, t["recon"]) < tol
         assert tuple(vae.get_latent_shape(t["x"].shape)) == (2, 4, 8, 12) and tuple(vae.get_sample_shape((2, 4, 8, 12))) == (2, 2, 32, 48)
 
 
