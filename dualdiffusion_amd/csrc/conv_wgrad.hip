@@ -13,6 +13,7 @@
 //   output = fp32 partial sums per K split (deterministic), summed by a second small kernel.
 // The 1x1 case uses the same code with one tap (waves split 2 x 2 over 64 x 64 channels).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_params.hpp"
@@ -47,6 +48,7 @@ struct WgradParams {
   float* ws;  // [ksplit][Cout][Cg][taps] fp32 partial sums
   int B, H, W, sH, sW, C0, C1, Cin, Cout, G, Cg, Ng, resample;
   int tiles_h, tiles_w, ntile_px, ksplit, n_tiles, c_tiles;
+  int wide;  // 1x1 layers on 128 x 128 channel tiles (conv_wgrad1x1_wide_kernel)
 };
 
 constexpr int kTH = 4, kTW = 32, kPix = kTH * kTW;  // pixel tile = one stage
@@ -226,6 +228,146 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 }
 
+// ---------------------------------------------------------------------------------------------- 1x1, large tiles
+// The 64 x 64 unit of the generic kernel gives every wave ONE accumulator fragment: 4 transpose reads per MFMA (LDS-bound
+// at a quarter of the matrix rate) and both operands are re-read from L2 once per 64-channel tile of the other one.
+// For 1x1 layers whose channel counts are multiples of 128:  unit = 128 output x 128 input channels, each of the 4 waves
+// owns a 64 x 64 quadrant (2 x 2 fragments: 2 reads per MFMA, operands re-read half as often), a stage is 64 FLAT pixels
+// (no halo: the tensor is one long [pixel][channel] matrix) of both operands, 16 KB each, double buffered.
+// LDS image: rows of 256 B; the 16-byte chunk c of row r sits at position c ^ ((r & 3) << 1), applied on the DMA source
+// address, so the 4 rows x 32 B that a 16-lane group of ds_read_b64_tr_b16 touches fall on 32 distinct banks.
+struct Wg1 {
+  static constexpr int BN = 128, BC = 128, PX = 64, RB = 256;
+  static constexpr int PIECES = PX * RB / 1024;             // 16 per operand
+  static constexpr int OP_BYTES = PIECES * 1024, STAGE = 2 * OP_BYTES;
+  static constexpr int ROWP = BC + 4, EPI_BYTES = BN * ROWP * 4;
+  static constexpr int SMEM = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad1x1_wide_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wc = wave & 1;  // this wave's 64 x 64 quadrant
+
+  int u = blockIdx.x;
+  const int ksp = u % p.ksplit; u /= p.ksplit;
+  const int ct = u % p.c_tiles; u /= p.c_tiles;
+  const int nt = u % p.n_tiles;
+  const int g = u / p.n_tiles;
+  const int n0 = nt * Wg1::BN, c0 = ct * Wg1::BC;
+  const int per = (p.ntile_px + p.ksplit - 1) / p.ksplit;
+  const int t_begin = ksp * per, t_end = min(t_begin + per, p.ntile_px);
+  const int total_px = p.B * p.H * p.W;
+
+  const int cabs = g * p.Cg + c0;
+  const bool second = cabs >= p.C0;
+  const rsrc_t rsx = second ? make_rsrc(p.x1, (size_t)total_px * p.C1 * 2) : make_rsrc(p.x0, (size_t)total_px * p.C0 * 2);
+  const rsrc_t rsy = make_rsrc(p.dy, (size_t)total_px * p.Cout * 2);
+  const int xstride2 = (second ? p.C1 : p.C0) * 2;
+  const int xchan2 = (second ? cabs - p.C0 : cabs) * 2;
+  const int ychan2 = (g * p.Ng + n0) * 2;
+  // DMA: piece = 4 rows; lane -> (row in piece, position in row); it fetches the logical chunk that belongs at its position
+  int drow[4], dchunk2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 4 * i) * 4 + (lane >> 4);
+    drow[i] = r;
+    dchunk2[i] = ((lane & 15) ^ ((r & 3) << 1)) * 16;
+  }
+  auto issue = [&](int t, int st) {
+    char* sb = smem + st * Wg1::STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pix = t * Wg1::PX + drow[i];
+      const bool ok = pix < total_px;
+      dma16(rsy, ok ? pix * (p.Cout * 2) + dchunk2[i] : kOob, ychan2, sb + (wave + 4 * i) * 1024);
+      dma16(rsx, ok ? pix * xstride2 + dchunk2[i] : kOob, xchan2, sb + Wg1::OP_BYTES + (wave + 4 * i) * 1024);
+    }
+  };
+
+  // fragment read bases: lane i of a 16-lane group supplies row (i >> 2), 8 bytes (4 channels) at column group (i & 3)
+  const int gq = lane >> 4, li = lane & 15;
+  const int kbase = (gq >> 1) * 8 + (li >> 2);
+  const int sw = ((li >> 2) & 3) << 1;
+  int a_base[2], b_base[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = ((wn * 2 + i) * 4 + (gq & 1) * 2 + ((li & 3) >> 1)) ^ sw;
+    const int cb = ((wc * 2 + i) * 4 + (gq & 1) * 2 + ((li & 3) >> 1)) ^ sw;
+    a_base[i] = kbase * Wg1::RB + ca * 16 + (li & 1) * 8;
+    b_base[i] = Wg1::OP_BYTES + kbase * Wg1::RB + cb * 16 + (li & 1) * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](auto stage_tag) {
+    constexpr int STG = decltype(stage_tag)::value;
+    const char* sb = smem + STG * Wg1::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < Wg1::PX / 16; ++ks) {
+      bf16x8 af[2], xf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = frag8(sb + a_base[i], ks * 16 * Wg1::RB, (ks * 16 + 4) * Wg1::RB);
+        xf[i] = frag8(sb + b_base[i], ks * 16 * Wg1::RB, (ks * 16 + 4) * Wg1::RB);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  if (t_begin < t_end) issue(t_begin, 0);
+  for (int t = t_begin; t < t_end; t += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_end) issue(t + 1, 1);
+    compute(S0{});
+    if (t + 1 >= t_end) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < t_end) issue(t + 2, 0);
+    compute(S1{});
+  }
+
+  // ---- partial sums through an LDS transpose (acc[i][j][4q+e] = dW'[n = 8q + 4*khalf + e][c = lane & 31] of the fragment)
+  const int khalf = lane >> 5, l31 = lane & 31;
+  float* sT = reinterpret_cast<float*>(smem);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sT[(wn * 64 + i * 32 + 8 * q + 4 * khalf + e) * Wg1::ROWP + wc * 64 + j * 32 + l31] = acc[i][j][4 * q + e];
+  __syncthreads();
+  float* wsp = p.ws + (size_t)ksp * p.Cout * p.Cg;
+#pragma unroll
+  for (int i = 0; i < Wg1::BN * (Wg1::BC / 4) / 256; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx / (Wg1::BC / 4), v = idx - row * (Wg1::BC / 4);
+    *reinterpret_cast<f32x4*>(wsp + ((size_t)(g * p.Ng + n0 + row) * p.Cg + c0) + 4 * v) = *reinterpret_cast<const f32x4*>(sT + row * Wg1::ROWP + 4 * v);
+  }
+}
+
+// the wide 1x1 kernel needs whole 128-channel tiles on both sides and, with two sources, the split on a tile boundary
+static bool wgrad1x1_wide_ok(int ks, int Ng, int Cg, int C0, int C1) {
+  return ks == 1 && Ng % 128 == 0 && Cg % 128 == 0 && (C1 == 0 || (C0 % Cg) % 128 == 0);
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int ksplit, int accumulate) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -236,13 +378,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // split-K factor: enough units to fill the chip (512 workgroup slots), but never more partial-sum traffic than ~4x the
 // gradient itself (small-M layers have large weights and few pixel tiles: they run unsplit and write dW directly)
-int wgrad_ksplit(int G, int Ng, int Cg, int ks, int ntile_px) {
-  const int bcw = ks == 3 ? 32 : 64;
-  const long base = (long)G * ceil_div(Ng, 64) * ceil_div(Cg, bcw);
+int wgrad_ksplit(int G, int Ng, int Cg, int ks, int ntile_px, bool wide = false) {
+  const int bcw = wide ? 128 : (ks == 3 ? 32 : 64);
+  const long base = (long)G * ceil_div(Ng, wide ? 128 : 64) * ceil_div(Cg, bcw);
   long want = std::max<long>(1, 768 / base);
   const double dw_mb = (double)G * Ng * Cg * ks * ks * 4.0 / 1e6;
   if (dw_mb * want > 48.0) want = std::max<long>(1, (long)(48.0 / dw_mb));
   return (int)std::min<long>(want, ntile_px);
+}
+
+int launch_wgrad1x1_wide(const WgradParams& p, hipStream_t s) {
+  auto kern = conv_wgrad1x1_wide_kernel;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Wg1::SMEM) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_wgrad1x1_wide)");
+    attr_done = true;
+  }
+  const int units = p.G * p.n_tiles * p.c_tiles * p.ksplit;
+  hipLaunchKernelGGL(kern, dim3(units), dim3(256), Wg1::SMEM, s, p);
+  return check_launch("conv_wgrad1x1_wide");
 }
 
 template <int KS>
@@ -288,9 +443,17 @@ static int wgrad_fill(const ddx_wgrad_desc& d, WgradParams* pp) {
   p.resample = d.resample;
   if ((size_t)p.B * p.H * p.W * std::max(p.Cout, std::max(p.C0, p.C1)) * 2 >= (size_t)0x7fff0000)
     return set_error(DDX_ERR_UNSUPPORTED, "wgrad: tensor too large for 32-bit buffer offsets");
-  p.tiles_h = ceil_div(p.H, kTH); p.tiles_w = ceil_div(p.W, kTW); p.ntile_px = p.B * p.tiles_h * p.tiles_w;
-  p.n_tiles = ceil_div(p.Ng, 64); p.c_tiles = ceil_div(p.Cg, bcw);
-  p.ksplit = wgrad_ksplit(p.G, p.Ng, p.Cg, d.ksize, p.ntile_px);
+  static const bool wide_enabled = []() { const char* e = std::getenv("DDX_WGRAD_WIDE"); return !e || e[0] != '0'; }();
+  // (measured on MI355X: 1.4-1.65x faster from 5.5k pixels up, slower at 1.4k pixels where few, short units remain)
+  p.wide = wide_enabled && d.resample == DDX_RESAMPLE_KEEP && (long)p.B * p.H * p.W >= 4096 && wgrad1x1_wide_ok(d.ksize, p.Ng, p.Cg, p.C0, p.C1) ? 1 : 0;
+  if (p.wide) {
+    p.tiles_h = p.tiles_w = 0; p.ntile_px = ceil_div(p.B * p.H * p.W, Wg1::PX);
+    p.n_tiles = p.Ng / 128; p.c_tiles = p.Cg / 128;
+  } else {
+    p.tiles_h = ceil_div(p.H, kTH); p.tiles_w = ceil_div(p.W, kTW); p.ntile_px = p.B * p.tiles_h * p.tiles_w;
+    p.n_tiles = ceil_div(p.Ng, 64); p.c_tiles = ceil_div(p.Cg, bcw);
+  }
+  p.ksplit = wgrad_ksplit(p.G, p.Ng, p.Cg, d.ksize, p.ntile_px, p.wide != 0);
   *pp = p;
   return 0;
 }
@@ -324,9 +487,9 @@ extern "C" int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* dp, ddx_stream stream) {
     if (p.ksplit == 1 && !accumulate) {  // unsplit: the kernel writes the gradient itself
       WgradParams q = p;
       q.ws = dw;
-      return ks == 3 ? launch_wgrad<3>(q, s) : launch_wgrad<1>(q, s);
+      return q.wide ? launch_wgrad1x1_wide(q, s) : (ks == 3 ? launch_wgrad<3>(q, s) : launch_wgrad<1>(q, s));
     }
-    const int rc = ks == 3 ? launch_wgrad<3>(p, s) : launch_wgrad<1>(p, s);
+    const int rc = p.wide ? launch_wgrad1x1_wide(p, s) : (ks == 3 ? launch_wgrad<3>(p, s) : launch_wgrad<1>(p, s));
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)p.ws, dw, n, p.ksplit, accumulate);
     return check_launch("wgrad_reduce");

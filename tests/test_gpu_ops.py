@@ -387,6 +387,8 @@ WGRAD_CASES = {
     "k3_cat_up": (1, 16, 32, 128, 128, 256, 8, 3, "up"),         # two sources, nearest-up operand
     "k1": (2, 8, 24, 192, 0, 128, 1, 1, "keep"),
     "k1_cat": (1, 6, 50, 128, 64, 72, 1, 1, "keep"),
+    "k1_wide": (2, 45, 47, 256, 0, 384, 1, 1, "keep"),           # 128 x 128 channel tiles (conv_wgrad1x1_wide_kernel), ragged pixel tail
+    "k1_wide_cat": (3, 32, 48, 256, 128, 128, 1, 1, "keep"),     # two sources split on a tile boundary, split-K over 72 pixel tiles
 }
 
 

@@ -19,6 +19,10 @@ CASES = {
     "L4_res0": (4, 2, 43, 1280, 2560, 8, 3),
     "L0_skip": (4, 32, 688, 768, 256, 1, 1),
     "L3_qk": (4, 4, 86, 1024, 2048, 1, 1),
+    "L1_skip": (4, 16, 344, 1280, 512, 1, 1),
+    "L2_skip": (4, 8, 172, 1792, 768, 1, 1),
+    "L0_skip512": (4, 32, 688, 512, 512, 1, 1),
+    "L0_skip_b8": (8, 32, 688, 768, 256, 1, 1),
 }
 
 
