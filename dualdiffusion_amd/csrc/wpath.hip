@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void wpath_multi_kernel(const ddx_wpath_job* _
     normalize_row<float>(reinterpret_cast<float*>(J.w), (int64_t)J.Cg * taps, eps, row, scratch);
   } else if constexpr (PHASE == DDX_WPATH_PREP) {
     wprep_row<float, TP>(w, reinterpret_cast<TP*>(J.wp), J.gain_ptr, J.gain, J.Cout, J.Cg, taps, J.groups, J.CK, J.normalize, J.qk_head_dim, eps,
-                         J.in_split, J.in_scale0, J.in_scale1, row, scratch);
+                         J.in_split, J.in_scale0, J.in_scale1, row, scratch, 0, 0, J.row_scale);
   } else if constexpr (PHASE == DDX_WPATH_ROWSCALE) {
     wprep_rowscale_row<float>(w, J.row_scale, J.gain_ptr, J.gain, J.Cg * taps, J.normalize, eps, row, scratch);
   } else if constexpr (PHASE == DDX_WPATH_TRANSPOSED) {

@@ -17,7 +17,7 @@ __device__ __forceinline__ int wpath_src_row(int od, int qk_d) {
 template <typename TW_, typename TP>
 __device__ __forceinline__ void wprep_row(const TW_* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr, float gain, int Cout, int Cg,
                                           int taps, int G, int CK, int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1,
-                                          int od, float* scratch, int row_off = 0, int rows_total = 0) {
+                                          int od, float* scratch, int row_off = 0, int rows_total = 0, float* row_scale = nullptr) {
   // row_off / rows_total: this weight fills rows [row_off, row_off + Cout) of a wider prepared matrix (merged 1x1 convs, G = 1)
   const int Ng = Cout / G, NgP = ((rows_total > 0 ? rows_total : Ng) + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
   const int g = od / Ng, n = od - g * Ng + row_off;
@@ -34,6 +34,9 @@ __device__ __forceinline__ void wprep_row(const TW_* __restrict__ w, TP* __restr
   float gn = gain;
   if (gain_ptr) gn *= *gain_ptr;
   const float sc = gn / sqrtf((float)fan);
+  // the same factor wprep_rowscale_row computes (source-row indexed): the multi-tensor path takes it from here instead of a
+  // second pass over the weights
+  if (row_scale && threadIdx.x == 0) row_scale[os] = sc / inv;
   for (int i = threadIdx.x; i < fan; i += 256) {
     const int c = i / taps, tap = i - c * taps;
     float x = to_f32<TW_>(wr[i]);

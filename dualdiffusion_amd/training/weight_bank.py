@@ -108,7 +108,8 @@ class WeightBank:
                                  normalize=int(e.normalize), qk_head_dim=e.qk_head_dim, in_split=e.in_split, in_scale0=e.in_scale0,
                                  in_scale1=e.in_scale1)
             part = {L.WPATH_NORMALIZE: g["Cout"] if e.normalize else 0, L.WPATH_PREP: g["Cout"] if e.prep else 0,
-                    L.WPATH_ROWSCALE: g["Cout"] if e.name in self.rs else 0, L.WPATH_TRANSPOSED: g["Cin"] if e.transpose else 0,
+                    # (PREP writes the row scales of the entries it prepares: the ROWSCALE phase only serves the others)
+                    L.WPATH_ROWSCALE: g["Cout"] if (e.name in self.rs and not e.prep) else 0, L.WPATH_TRANSPOSED: g["Cin"] if e.transpose else 0,
                     L.WPATH_BWD: g["Cout"] if e.grad else 0}
             for ph in range(5):
                 rows[ph].append(rows[ph][-1] + part[ph])

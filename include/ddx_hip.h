@@ -242,7 +242,8 @@ int ddx_linear_small_bwd_batched(const ddx_linear_bwd_job* jobs_dev, int32_t njo
  * Replaces, per optimizer step, the per-module calls of MPConv.forward's weight branch under autograd and of
  * MPConv.normalize_weights (mp_tools.py:359-364, :375-378; trainer.py:375-381) for every layer at once.
  * Master weights are fp32.  row_prefix[j] = first workgroup (row) of job j in THIS phase, row_prefix[njobs] = total_rows;
- * a job that takes no part in a phase has zero rows there.  Rows per job: Cout (NORMALIZE, PREP, ROWSCALE, BWD),
+ * a job that takes no part in a phase has zero rows there.  PREP also writes row_scale when the job has one (ROWSCALE is only
+ * needed for jobs without a forward preparation).  Rows per job: Cout (NORMALIZE, PREP, ROWSCALE, BWD),
  * Cg * groups (TRANSPOSED).  BWD accumulates into *dgain with atomics: zero it first.
  * ------------------------------------------------------------------------------------------------ */
 enum { DDX_WPATH_NORMALIZE = 0, DDX_WPATH_PREP = 1, DDX_WPATH_ROWSCALE = 2, DDX_WPATH_TRANSPOSED = 3, DDX_WPATH_BWD = 4 };
