@@ -75,8 +75,9 @@ __device__ __forceinline__ void fft_stage(const cf* __restrict__ x, cf* __restri
     for (int j = 0; j < R; ++j) a[j] = x[q + s * (p + m * j)];
     Butterfly<R, INV>::run(a);
     y[q + s * (R * p)] = a[0];
+    // (twiddle index p*k*tstep <= (n/R - 1)(R - 1) N/n < N: no reduction modulo N needed)
 #pragma unroll
-    for (int k = 1; k < R; ++k) y[q + s * (R * p + k)] = cmul(a[k], twiddle<INV>(tw, (p * k * tstep) % N));
+    for (int k = 1; k < R; ++k) y[q + s * (R * p + k)] = cmul(a[k], twiddle<INV>(tw, p * k * tstep));
   }
 }
 
@@ -92,6 +93,51 @@ __device__ __forceinline__ void fft6400(cf* a, cf* b, const float2* __restrict__
   fft_stage<N, 4, INV, NT>(b, a, 100, 64, tw);   __syncthreads();
   fft_stage<N, 5, INV, NT>(a, b, 25, 256, tw);   __syncthreads();
   fft_stage<N, 5, INV, NT>(b, a, 5, 1280, tw);   __syncthreads();
+}
+
+// ---- single-buffer variant: every thread first pulls ALL its butterfly inputs of the stage into registers, barrier, then
+// writes the outputs over the same array.  Two barriers per stage instead of one, but half the LDS (51 KB for 6400 points),
+// so three workgroups fit a CU and the global-memory phases of one frame overlap the transform of another.
+template <int N, int R, bool INV, int NT>
+__device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int s, const float2* __restrict__ tw) {
+  const int m = n / R;
+  const int tstep = N / n;
+  constexpr int ROUNDS = (N / R + NT - 1) / NT;
+  cf a[ROUNDS][R];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int idx = threadIdx.x + r * NT;
+    if (idx < N / R) {
+      const int p = idx / s, q = idx - p * s;
+#pragma unroll
+      for (int j = 0; j < R; ++j) a[r][j] = x[q + s * (p + m * j)];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int idx = threadIdx.x + r * NT;
+    if (idx < N / R) {
+      const int p = idx / s, q = idx - p * s;
+      Butterfly<R, INV>::run(a[r]);
+      x[q + s * (R * p)] = a[r][0];
+#pragma unroll
+      for (int k = 1; k < R; ++k) x[q + s * (R * p + k)] = cmul(a[r][k], twiddle<INV>(tw, p * k * tstep));
+    }
+  }
+  __syncthreads();
+}
+
+template <bool INV, int NT>
+__device__ __forceinline__ void fft6400_inplace(cf* a, const float2* __restrict__ tw) {
+  constexpr int N = 6400;
+  __syncthreads();
+  fft_stage_inplace<N, 4, INV, NT>(a, 6400, 1, tw);
+  fft_stage_inplace<N, 4, INV, NT>(a, 1600, 4, tw);
+  fft_stage_inplace<N, 4, INV, NT>(a, 400, 16, tw);
+  fft_stage_inplace<N, 4, INV, NT>(a, 100, 64, tw);
+  fft_stage_inplace<N, 5, INV, NT>(a, 25, 256, tw);
+  fft_stage_inplace<N, 5, INV, NT>(a, 5, 1280, tw);
 }
 
 }  // namespace ddx

@@ -18,7 +18,7 @@
 namespace ddx {
 
 constexpr int kFN = 6400;
-constexpr int kFNT = 1024;
+constexpr int kFNT = 640;   // 10 waves; 3 workgroups (3 x 51 KB of LDS) per CU
 
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][NB] state (nullptr: angles = 1)
@@ -30,11 +30,10 @@ struct FglaSynthParams {
   int final_pass, stereo_merge;
 };
 
-__global__ __launch_bounds__(kFNT) void fgla_synth_kernel(const FglaSynthParams p) {
+__global__ __launch_bounds__(kFNT, 3) void fgla_synth_kernel(const FglaSynthParams p) {
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  cf* bufB = bufA + N;
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const size_t sbase = ((size_t)b * p.T + t) * p.C * NB;
   for (int k = tid; k < NB; k += kFNT) {
@@ -62,13 +61,20 @@ __global__ __launch_bounds__(kFNT) void fgla_synth_kernel(const FglaSynthParams 
     bufA[k] = cf{x[0].x - x[1].y, x[0].y + x[1].x};
     if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
   }
-  fft6400<true, kFNT>(bufA, bufB, p.tw);
+  fft6400_inplace<true, kFNT>(bufA, p.tw);
   float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
   const float invn = 1.0f / (float)N;
-  for (int n = tid; n < N; n += kFNT) {
-    const float w = p.window[n] * invn;
-    fr[n] = bufA[n].x * w;
-    if (p.C > 1) fr[N + n] = bufA[n].y * w;
+  for (int n = 4 * tid; n < N; n += 4 * kFNT) {   // 16 bytes per lane: four samples of each channel
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.window + n);
+    f32x4 l4, r4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const cf z = bufA[n + e];
+      l4[e] = z.x * (w4[e] * invn);
+      r4[e] = z.y * (w4[e] * invn);
+    }
+    *reinterpret_cast<f32x4*>(fr + n) = l4;
+    if (p.C > 1) *reinterpret_cast<f32x4*>(fr + N + n) = r4;
   }
 }
 
@@ -76,23 +82,27 @@ __global__ __launch_bounds__(kFNT) void fgla_synth_kernel(const FglaSynthParams 
 __global__ __launch_bounds__(256) void fgla_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
                                                        float* __restrict__ audio, int B, int C, int T, int hop, int Lout) {
   constexpr int N = kFN;
-  const size_t total = (size_t)B * C * Lout;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  // four consecutive samples per lane (hop, N/2 and Lout are multiples of 4, so they share their frame range and every
+  // access is a 16-byte one)
+  const size_t total4 = (size_t)B * C * Lout / 4;
+  for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * 256) {
+    const size_t i = i4 * 4;
     const int j = (int)(i % Lout);
     const int ch = (int)((i / Lout) % C);
     const int b = (int)(i / ((size_t)Lout * C));
     const int jp = j + N / 2;
-    int t0 = (jp - N + hop) / hop;  // ceil((jp - N + 1) / hop) for jp - N + 1 > 0
-    if (jp - N + 1 <= 0) t0 = 0;
+    int t0 = (jp + 3 - N + hop) / hop;  // ceil((jp + 3 - N + 1) / hop): first frame that covers the LAST of the four samples ...
+    if (jp + 3 - N + 1 <= 0) t0 = 0;    // ... and, the group being 4-aligned inside a hop, the first one too
     const int t1 = min(jp / hop, T - 1);
-    float acc = 0.f, env = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, env = {0.f, 0.f, 0.f, 0.f};
     for (int t = t0; t <= t1; ++t) {
       const int n = jp - t * hop;
-      const float w = window[n];
-      acc += frames[(((size_t)b * T + t) * C + ch) * N + n];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(window + n);
+      const f32x4 f = *reinterpret_cast<const f32x4*>(frames + (((size_t)b * T + t) * C + ch) * N + n);
+      acc += f;
       env += w * w;
     }
-    audio[i] = acc / env;
+    *reinterpret_cast<f32x4*>(audio + i) = acc / env;
   }
 }
 
@@ -110,21 +120,33 @@ __device__ __forceinline__ int reflect_idx(int j, int L) {
   return j;
 }
 
-__global__ __launch_bounds__(kFNT) void fgla_analysis_kernel(const FglaAnalysisParams p) {
+__global__ __launch_bounds__(kFNT, 3) void fgla_analysis_kernel(const FglaAnalysisParams p) {
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  cf* bufB = bufA + N;
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* aL = p.audio + (size_t)b * p.C * p.L;
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
   const int base = t * p.hop - N / 2;
-  for (int n = tid; n < N; n += kFNT) {
-    const int j = reflect_idx(base + n, p.L);
-    const float w = p.window[n];
-    bufA[n] = cf{aL[j] * w, aR ? aR[j] * w : 0.f};
+  for (int n = 4 * tid; n < N; n += 4 * kFNT) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.window + n);
+    const int j0 = base + n;
+    f32x4 l4, r4 = {0.f, 0.f, 0.f, 0.f};
+    if (j0 >= 0 && j0 + 3 < p.L && (p.L & 3) == 0) {   // interior: 16-byte loads (base and n are multiples of 4)
+      l4 = *reinterpret_cast<const f32x4*>(aL + j0);
+      if (aR) r4 = *reinterpret_cast<const f32x4*>(aR + j0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = reflect_idx(j0 + e, p.L);
+        l4[e] = aL[j];
+        if (aR) r4[e] = aR[j];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
   }
-  fft6400<false, kFNT>(bufA, bufB, p.tw);
+  fft6400_inplace<false, kFNT>(bufA, p.tw);
   float2* ro = p.u + ((size_t)b * p.T + t) * p.C * NB;
   for (int k = tid; k < NB; k += kFNT) {
     const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
@@ -175,7 +197,7 @@ extern "C" int ddx_fgla_synth(const float* u, const float* mags, const float* wi
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_synth_kernel), &done)) return rc;
-    hipLaunchKernelGGL(fgla_synth_kernel, dim3(p.T, p.B), dim3(kFNT), 2 * kFN * sizeof(cf), s, p);
+    hipLaunchKernelGGL(fgla_synth_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
     return check_launch("fgla_synth");
   }, stream, "fgla_synth");
 }
@@ -184,10 +206,11 @@ extern "C" int ddx_fgla_ola(const float* frames, const float* window, float* aud
                             int32_t hop, ddx_stream stream) {
   if (!frames || !window || !audio || B <= 0 || C <= 0 || T <= 1 || hop <= 0) return set_error(DDX_ERR_ARG, "fgla_ola: bad args");
   if (n_fft != kFN) return set_error(DDX_ERR_UNSUPPORTED, "fgla_ola: only n_fft = 6400 is built");
+  if (hop % 4) return set_error(DDX_ERR_UNSUPPORTED, "fgla_ola: hop must be a multiple of 4 (16-byte accesses)");
   return dispatch([=](hipStream_t s) -> int {
     const int Lout = hop * (T - 1);
     const size_t total = (size_t)B * C * Lout;
-    hipLaunchKernelGGL(fgla_ola_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 65536)), dim3(256), 0, s, frames, window,
+    hipLaunchKernelGGL(fgla_ola_kernel, dim3((unsigned)std::min<size_t>((total / 4 + 255) / 256, 65536)), dim3(256), 0, s, frames, window,
                        audio, B, C, T, hop, Lout);
     return check_launch("fgla_ola");
   }, stream, "fgla_ola");
@@ -201,7 +224,7 @@ extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const 
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_analysis_kernel), &done)) return rc;
-    hipLaunchKernelGGL(fgla_analysis_kernel, dim3(p.T, p.B), dim3(kFNT), 2 * kFN * sizeof(cf), s, p);
+    hipLaunchKernelGGL(fgla_analysis_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
     return check_launch("fgla_analysis");
   }, stream, "fgla_analysis");
 }
