@@ -131,11 +131,11 @@ PROTOTYPES = {
                                           C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_mel_stft": (C.c_int, [C.POINTER(MelStftDesc), C.c_void_p]),
     "ddx_mel_to_amplitude": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
-    "ddx_fgla_synth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+    "ddx_fgla_synth": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_fgla_ola": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_fgla_analysis": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_float, C.c_void_p]),
+                                    C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ddx_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ddx_mpconv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "ddx_silu_scale_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,

@@ -21,11 +21,11 @@ constexpr int kFN = 6400;
 constexpr int kFNT = 640;   // 10 waves; 3 workgroups (3 x 51 KB of LDS) per CU
 
 struct FglaSynthParams {
-  const float2* u;                          // [B][T][C][NB] state (nullptr: angles = 1)
+  const float2* u;                          // [B][T][C][ustride] state, NB valid per row (nullptr: angles = 1)
   const float* mags;                        // [B][C][T][mstride]
   const float* window; const float2* tw;
   float* frames;                            // [B][T][C][N]
-  int B, C, T, mstride;
+  int B, C, T, mstride, ustride;
   float t_lerp;                             // t_lerp <= 0: merged magnitudes; final: the magnitudes themselves
   int final_pass, stereo_merge;
 };
@@ -35,31 +35,43 @@ __global__ __launch_bounds__(kFNT, 3) void fgla_synth_kernel(const FglaSynthPara
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const size_t sbase = ((size_t)b * p.T + t) * p.C * NB;
-  for (int k = tid; k < NB; k += kFNT) {
-    cf x[2] = {cf{0.f, 0.f}, cf{0.f, 0.f}};
-    float mg[2] = {0.f, 0.f};
+  const size_t sbase = ((size_t)b * p.T + t) * p.C * p.ustride;
+  // two bins per lane: rows of the state (ustride even) and of the magnitudes (mstride even) start 16 / 8-byte aligned,
+  // so the state is read as one 16-byte vector per channel; the second bin of the last pair (k = NB) is row padding
+  for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {
+    float mg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [channel][bin]
+    f32x4 uu[2] = {{1.f, 0.f, 1.f, 0.f}, {1.f, 0.f, 1.f, 0.f}};
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
-      if (ch < p.C) mg[ch] = fmaxf(p.mags[(((size_t)b * p.C + ch) * p.T + t) * p.mstride + k], 0.f);  // relu of the un-mel
-    const float merged = 0.5f * (mg[0] + mg[1]);
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      if (ch >= p.C) continue;
-      cf ang = {1.f, 0.f};
-      if (p.u) {
-        const float2 a = p.u[sbase + (size_t)ch * NB + k];
-        const float inv = 1.0f / (sqrtf(a.x * a.x + a.y * a.y) + 1e-16f);
-        ang = cf{a.x * inv, a.y * inv};
+      if (ch < p.C) {
+        const float2 m2 = *reinterpret_cast<const float2*>(p.mags + (((size_t)b * p.C + ch) * p.T + t) * p.mstride + k0);
+        mg[ch][0] = fmaxf(m2.x, 0.f); mg[ch][1] = fmaxf(m2.y, 0.f);            // relu of the un-mel
+        if (p.u) uu[ch] = *reinterpret_cast<const f32x4*>(p.u + sbase + (size_t)ch * p.ustride + k0);
       }
-      float m = mg[ch];
-      if (!p.final_pass && p.stereo_merge) m = p.t_lerp > 0.f ? merged + p.t_lerp * (mg[ch] - merged) : merged;
-      x[ch] = cf{ang.x * m, ang.y * m};
-      if (k == 0 || k == N / 2) x[ch].y = 0.f;  // c2r semantics: DC and Nyquist are real
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = k0 + e;
+      if (k >= NB) break;
+      cf x[2] = {cf{0.f, 0.f}, cf{0.f, 0.f}};
+      const float merged = 0.5f * (mg[0][e] + mg[1][e]);
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        if (ch >= p.C) continue;
+        cf ang = {1.f, 0.f};
+        if (p.u) {
+          const float ax = uu[ch][2 * e], ay = uu[ch][2 * e + 1];
+          const float inv = 1.0f / (sqrtf(ax * ax + ay * ay) + 1e-16f);
+          ang = cf{ax * inv, ay * inv};
+        }
+        float m = mg[ch][e];
+        if (!p.final_pass && p.stereo_merge) m = p.t_lerp > 0.f ? merged + p.t_lerp * (mg[ch][e] - merged) : merged;
+        x[ch] = cf{ang.x * m, ang.y * m};
+        if (k == 0 || k == N / 2) x[ch].y = 0.f;  // c2r semantics: DC and Nyquist are real
+      }
+      // Z = X_L + i X_R ;  Z[N-k] = conj(X_L) + i conj(X_R)
+      bufA[k] = cf{x[0].x - x[1].y, x[0].y + x[1].x};
+      if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
     }
-    // Z = X_L + i X_R ;  Z[N-k] = conj(X_L) + i conj(X_R)
-    bufA[k] = cf{x[0].x - x[1].y, x[0].y + x[1].x};
-    if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
   }
   fft6400_inplace<true, kFNT>(bufA, p.tw);
   float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
@@ -109,8 +121,8 @@ __global__ __launch_bounds__(256) void fgla_ola_kernel(const float* __restrict__
 struct FglaAnalysisParams {
   const float* audio;  // [B][C][L]
   const float* window; const float2* tw;
-  float2* u;           // [B][T][C][NB] state, updated in place: u = rebuilt - momentum * u
-  int B, C, T, L, hop;
+  float2* u;           // [B][T][C][ustride] state (NB valid per row), updated in place: u = rebuilt - momentum * u
+  int B, C, T, L, hop, ustride;
   float momentum;
 };
 
@@ -147,16 +159,23 @@ __global__ __launch_bounds__(kFNT, 3) void fgla_analysis_kernel(const FglaAnalys
     for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
   }
   fft6400_inplace<false, kFNT>(bufA, p.tw);
-  float2* ro = p.u + ((size_t)b * p.T + t) * p.C * NB;
-  for (int k = tid; k < NB; k += kFNT) {
-    const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
-    const cf sl = cadd(zk, zn), sr = csub(zk, zn);
-    const float2 ul = ro[k];
-    ro[k] = make_float2(0.5f * sl.x - p.momentum * ul.x, 0.5f * sl.y - p.momentum * ul.y);   // X_L = (Z[k] + conj Z[N-k]) / 2
-    if (p.C > 1) {
-      const float2 ur = ro[NB + k];
-      ro[NB + k] = make_float2(0.5f * sr.y - p.momentum * ur.x, -0.5f * sr.x - p.momentum * ur.y);  // X_R = (Z[k] - conj Z[N-k]) / (2i)
+  float2* ro = p.u + ((size_t)b * p.T + t) * p.C * p.ustride;
+  for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {   // two bins per lane: 16-byte read-modify-write of the state rows
+    f32x4 ul = *reinterpret_cast<const f32x4*>(ro + k0), ur = {0.f, 0.f, 0.f, 0.f};
+    if (p.C > 1) ur = *reinterpret_cast<const f32x4*>(ro + p.ustride + k0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = k0 + e;
+      if (k >= NB) break;    // (the second bin of the last pair is row padding: written back unchanged)
+      const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
+      const cf sl = cadd(zk, zn), sr = csub(zk, zn);
+      ul[2 * e] = 0.5f * sl.x - p.momentum * ul[2 * e];            // X_L = (Z[k] + conj Z[N-k]) / 2
+      ul[2 * e + 1] = 0.5f * sl.y - p.momentum * ul[2 * e + 1];
+      ur[2 * e] = 0.5f * sr.y - p.momentum * ur[2 * e];            // X_R = (Z[k] - conj Z[N-k]) / (2i)
+      ur[2 * e + 1] = -0.5f * sr.x - p.momentum * ur[2 * e + 1];
     }
+    *reinterpret_cast<f32x4*>(ro + k0) = ul;
+    if (p.C > 1) *reinterpret_cast<f32x4*>(ro + p.ustride + k0) = ur;
   }
 }
 
@@ -187,13 +206,15 @@ static int set_fft_smem(const void* kern, bool* done) {
   return DDX_OK;
 }
 
-extern "C" int ddx_fgla_synth(const float* u, const float* mags, const float* window, const float* twiddle, float* frames, int32_t B,
-                              int32_t C, int32_t T, int32_t n_fft, int32_t mag_stride, float t_lerp, int32_t final_pass,
+extern "C" int ddx_fgla_synth(const float* u, int32_t u_stride, const float* mags, const float* window, const float* twiddle, float* frames,
+                              int32_t B, int32_t C, int32_t T, int32_t n_fft, int32_t mag_stride, float t_lerp, int32_t final_pass,
                               ddx_stream stream) {
   if (!mags || !window || !twiddle || !frames || B <= 0 || (C != 1 && C != 2) || T <= 0) return set_error(DDX_ERR_ARG, "fgla_synth: bad args");
   if (n_fft != kFN || mag_stride < kFN / 2 + 1) return set_error(DDX_ERR_UNSUPPORTED, "fgla_synth: only n_fft = 6400 is built");
+  if (mag_stride < kFN / 2 + 2 || (mag_stride & 1) || (u && (u_stride < kFN / 2 + 2 || (u_stride & 1))))
+    return set_error(DDX_ERR_ARG, "fgla_synth: row strides must be even and >= n_fft/2 + 2 (two bins per 16-byte access)");
   FglaSynthParams p{reinterpret_cast<const float2*>(u), mags, window, reinterpret_cast<const float2*>(twiddle), frames, B, C, T,
-                    mag_stride, t_lerp, final_pass, C == 2};
+                    mag_stride, u_stride, t_lerp, final_pass, C == 2};
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_synth_kernel), &done)) return rc;
@@ -216,11 +237,12 @@ extern "C" int ddx_fgla_ola(const float* frames, const float* window, float* aud
   }, stream, "fgla_ola");
 }
 
-extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t B, int32_t C,
-                                 int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream) {
+extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t u_stride, int32_t B,
+                                 int32_t C, int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream) {
   if (!audio || !window || !twiddle || !u || B <= 0 || (C != 1 && C != 2) || T <= 0 || L <= kFN / 2) return set_error(DDX_ERR_ARG, "fgla_analysis: bad args");
   if (n_fft != kFN) return set_error(DDX_ERR_UNSUPPORTED, "fgla_analysis: only n_fft = 6400 is built");
-  FglaAnalysisParams p{audio, window, reinterpret_cast<const float2*>(twiddle), reinterpret_cast<float2*>(u), B, C, T, L, hop, momentum};
+  if (u_stride < kFN / 2 + 2 || (u_stride & 1)) return set_error(DDX_ERR_ARG, "fgla_analysis: u_stride must be even and >= n_fft/2 + 2");
+  FglaAnalysisParams p{audio, window, reinterpret_cast<const float2*>(twiddle), reinterpret_cast<float2*>(u), B, C, T, L, hop, u_stride, momentum};
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_analysis_kernel), &done)) return rc;

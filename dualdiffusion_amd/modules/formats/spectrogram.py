@@ -179,7 +179,8 @@ class SpectrogramFormat(DualDiffusionFormat):
                                          1.0 / c.abs_exponent, st), "mel_to_amplitude")
         mags = ops.conv2d(amp, self._unmel_weights())                          # [B*C][1][T][nb padded to 4], relu applied on read
         mstride = mags.shape[3]
-        u = torch.zeros(B, T, Cn, nb, 2, device=dev, dtype=f32)   # state: u_i = rebuilt_i - m*u_{i-1} (see fgla.hip)
+        us = (nb + 2) // 2 * 2                                     # state rows padded to an even bin count: 16-byte accesses
+        u = torch.zeros(B, T, Cn, us, 2, device=dev, dtype=f32)   # state: u_i = rebuilt_i - m*u_{i-1} (see fgla.hip)
         frames = torch.empty(B, T, Cn, N, device=dev, dtype=f32)
         Lout = hop * (T - 1)
         audio = torch.empty(B, Cn, Lout, device=dev, dtype=f32)
@@ -187,11 +188,11 @@ class SpectrogramFormat(DualDiffusionFormat):
         W, TW = ptr(self.window), ptr(self.twiddle)
 
         def synth(state, t_lerp, final):
-            check(lib().ddx_fgla_synth(ptr(state), ptr(mags), W, TW, ptr(frames), B, Cn, T, N, mstride, t_lerp, int(final), st), "fgla_synth")
+            check(lib().ddx_fgla_synth(ptr(state), us, ptr(mags), W, TW, ptr(frames), B, Cn, T, N, mstride, t_lerp, int(final), st), "fgla_synth")
             check(lib().ddx_fgla_ola(ptr(frames), W, ptr(audio), B, Cn, T, N, hop, st), "fgla_ola")
 
         for i in range(n_iter):
             synth(None if i == 0 else u, i / n_iter - c.stereo_coherence, False)   # i == 0: angles = 1 (rand_init False)
-            check(lib().ddx_fgla_analysis(ptr(audio), W, TW, ptr(u), B, Cn, T, Lout, N, hop, momentum, st), "fgla_analysis")
+            check(lib().ddx_fgla_analysis(ptr(audio), W, TW, ptr(u), us, B, Cn, T, Lout, N, hop, momentum, st), "fgla_analysis")
         synth(u, 0.0, True)                                                         # waveform = istft(angles * specgram)
         return audio

@@ -407,16 +407,18 @@ int ddx_mel_stft(const ddx_melstft_desc* d, ddx_stream stream);
  *   fgla_analysis    : u[b][t][c][k] <- rfft(window * reflect_pad(audio) frame t)[k] - momentum * u[b][t][c][k]
  *                      (torch.stft + the in-place `angles.sub_(tprev, alpha=momentum)` whose result the reference keeps
  *                      as tprev, phase_recovery.py:110-119)
- * The state u is frame-major [B][T][C][n_fft/2+1] complex64 (re, im pairs), zero before the first iteration.
+ * The state u is frame-major [B][T][C][u_stride] complex64 (re, im pairs; n_fft/2+1 valid bins per row, u_stride even and
+ * >= n_fft/2+2 so that two bins move per 16-byte access; mag_stride likewise), zero before the first iteration.
  * ------------------------------------------------------------------------------------------------ */
 int ddx_mel_to_amplitude(const float* mel, float* amp, int32_t rows, int32_t n_mel, int32_t T, float scale, float mean,
                          float power, ddx_stream stream);
-int ddx_fgla_synth(const float* u, const float* mags, const float* window, const float* twiddle, float* frames, int32_t B,
-                   int32_t C, int32_t T, int32_t n_fft, int32_t mag_stride, float t_lerp, int32_t final_pass, ddx_stream stream);
+int ddx_fgla_synth(const float* u, int32_t u_stride, const float* mags, const float* window, const float* twiddle, float* frames,
+                   int32_t B, int32_t C, int32_t T, int32_t n_fft, int32_t mag_stride, float t_lerp, int32_t final_pass,
+                   ddx_stream stream);
 int ddx_fgla_ola(const float* frames, const float* window, float* audio, int32_t B, int32_t C, int32_t T, int32_t n_fft,
                  int32_t hop, ddx_stream stream);
-int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t B, int32_t C,
-                      int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream);
+int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t u_stride, int32_t B,
+                      int32_t C, int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched bf16 GEMM + row softmax: the pieces of the attention BACKWARD pass (unet_edm2_b4.py:137-148 under autograd;

@@ -57,24 +57,29 @@ def test_fgla_linear_pieces_match_oracle():
     spec = torch.polar(mags, phase)
     ref_wave = M.istft_frames(spec.reshape(-1, nb, T), win, 256).reshape(B, Cn, -1)
     st = current_stream()
-    u = torch.view_as_real(torch.polar(torch.ones_like(mags), phase)).permute(0, 3, 1, 2, 4).contiguous().cuda()   # [B][T][C][nb][2]
+    us = nb + 1                                                            # state / magnitude rows padded to an even bin count
+    u = torch.zeros(B, T, Cn, us, 2)
+    u[:, :, :, :nb] = torch.view_as_real(torch.polar(torch.ones_like(mags), phase)).permute(0, 3, 1, 2, 4)   # [B][T][C][nb][2]
+    u = u.cuda()
     mg = torch.zeros(B, Cn, T, nb + 3)
     mg[..., :nb] = mags.permute(0, 1, 3, 2)
     mg = mg.contiguous().cuda()
     frames = torch.empty(B, T, Cn, 6400, device="cuda")
     audio = torch.empty(B, Cn, 256 * (T - 1), device="cuda")
-    check(lib().ddx_fgla_synth(ptr(u), ptr(mg), ptr(fmt.window), ptr(fmt.twiddle), ptr(frames), B, Cn, T, 6400, nb + 3, 0.0, 1, st))
+    check(lib().ddx_fgla_synth(ptr(u), us, ptr(mg), ptr(fmt.window), ptr(fmt.twiddle), ptr(frames), B, Cn, T, 6400, nb + 3, 0.0, 1, st))
     check(lib().ddx_fgla_ola(ptr(frames), ptr(fmt.window), ptr(audio), B, Cn, T, 6400, 256, st))
     e = rel_l2(audio, ref_wave)
     print(f"istft piece rel-L2 {e:.3e}")
     assert e < 2e-5
     # analysis: u <- stft(audio) - momentum * u  (u = known tensor)
     u0 = torch.randn(B, T, Cn, nb, 2, generator=g)
-    ud = u0.clone().cuda()
-    check(lib().ddx_fgla_analysis(ptr(audio), ptr(fmt.window), ptr(fmt.twiddle), ptr(ud), B, Cn, T, 256 * (T - 1), 6400, 256, 0.25, st))
+    ud = torch.zeros(B, T, Cn, us, 2)
+    ud[:, :, :, :nb] = u0
+    ud = ud.cuda()
+    check(lib().ddx_fgla_analysis(ptr(audio), ptr(fmt.window), ptr(fmt.twiddle), ptr(ud), us, B, Cn, T, 256 * (T - 1), 6400, 256, 0.25, st))
     ref_spec = M.stft_frames(ref_wave, win, 256)                                  # (B, C, nb, T)
     ref_u = torch.view_as_real(ref_spec).permute(0, 3, 1, 2, 4) - 0.25 * u0
-    e = rel_l2(ud, ref_u)
+    e = rel_l2(ud[:, :, :, :nb], ref_u)
     print(f"stft piece rel-L2 {e:.3e}")
     assert e < 2e-5
 
