@@ -22,7 +22,7 @@ struct MssParams {
   float scale;  // abs_loss_scale / (channels * nbh * nbw * w * (w/2+1))
 };
 
-constexpr int kMssNT = 1024;  // 16 waves per workgroup: the LDS-resident FFT passes need the latency hiding (one workgroup per CU)
+constexpr int kMssNT = 1024;  // 16 waves per workgroup, two workgroups (2 x 64 KB of LDS) per CU
 constexpr int kMssPts = 4096;
 
 __device__ __forceinline__ int reflect_pad_index(int j, int n) {
@@ -31,50 +31,70 @@ __device__ __forceinline__ int reflect_pad_index(int j, int n) {
   return j;
 }
 
-// One Stockham stage (radix R) over all lines of the [NBLK][W][W] array, along rows (ROWS) or columns.
-template <int W, int R, bool INV, bool ROWS>
-__device__ __forceinline__ void mss_fft_stage(const cf* __restrict__ x, cf* __restrict__ y, int n, int s, const float2* __restrict__ tw) {
+// One Stockham stage (radix R) over all lines of NARR [NBLK][W][W] arrays, along rows (ROWS) or columns, IN PLACE: every
+// thread pulls the inputs of its butterflies into registers, barrier, then writes the outputs over the same array (two
+// barriers per stage, but no scratch array: 64 KB for sample + target instead of 96 KB, i.e. two workgroups per CU whose
+// load / transform / scatter phases overlap).  Sample and target go through one pass (shared index arithmetic / twiddles).
+template <int W, int R, bool INV, bool ROWS, int NARR>
+__device__ __forceinline__ void mss_fft_stage(cf* __restrict__ x0, cf* __restrict__ x1, int n, int s, const float2* __restrict__ tw) {
   constexpr int BPL = W / R;  // butterflies per line
+  constexpr int ITS = kMssPts / R / kMssNT;
+  constexpr int ES = ROWS ? 1 : W;
   const int m = n / R;
   const int tstep = W / n;
+  cf a[NARR][ITS][R];
+  int base[ITS], pp[ITS], qq[ITS];
 #pragma unroll
-  for (int it = 0; it < kMssPts / R / kMssNT; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const int t = threadIdx.x + it * kMssNT;
     const int line = t / BPL, u = t - line * BPL;
-    const int p = u / s, q = u - p * s;
+    pp[it] = u / s; qq[it] = u - pp[it] * s;
     // rows: line = blk*W + r, element stride 1.  columns: line = blk*W + c, element stride W.
-    const int base = ROWS ? line * W : (line / W) * (W * W) + (line % W);
-    constexpr int ES = ROWS ? 1 : W;
-    cf a[R];
+    base[it] = ROWS ? line * W : (line / W) * (W * W) + (line % W);
 #pragma unroll
-    for (int j = 0; j < R; ++j) a[j] = x[base + ES * (q + s * (p + m * j))];
-    Butterfly<R, INV>::run(a);
-    y[base + ES * (q + s * (R * p))] = a[0];
-#pragma unroll
-    for (int k = 1; k < R; ++k) y[base + ES * (q + s * (R * p + k))] = cmul(a[k], twiddle<INV>(tw, (p * k * tstep) % W));
+    for (int j = 0; j < R; ++j) {
+      const int o = base[it] + ES * (qq[it] + s * (pp[it] + m * j));
+      a[0][it][j] = x0[o];
+      if (NARR > 1) a[NARR - 1][it][j] = x1[o];
+    }
   }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int p = pp[it], q = qq[it];
+#pragma unroll
+    for (int r = 0; r < NARR; ++r) Butterfly<R, INV>::run(a[r][it]);
+    const int o0 = base[it] + ES * (q + s * (R * p));
+    x0[o0] = a[0][it][0];
+    if (NARR > 1) x1[o0] = a[NARR - 1][it][0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+      const cf w = twiddle<INV>(tw, p * k * tstep);   // p*k*tstep <= (n/R - 1)(R - 1) W/n < W
+      const int o = base[it] + ES * (q + s * (R * p + k));
+      x0[o] = cmul(a[0][it][k], w);
+      if (NARR > 1) x1[o] = cmul(a[NARR - 1][it][k], w);
+    }
+  }
+  __syncthreads();
 }
 
-// 1-D transforms of length W along one axis; the result is back in `a` after both axes (even stage count in total)
-template <int W, bool INV, bool ROWS>
-__device__ __forceinline__ void mss_fft_axis(cf*& a, cf*& b, const float2* tw) {
+// 1-D transforms of length W along one axis, in place
+template <int W, bool INV, bool ROWS, int NARR>
+__device__ __forceinline__ void mss_fft_axis(cf* x0, cf* x1, const float2* tw) {
   int n = W, s = 1;
   while (n > 1) {
-    if (n % 4 == 0) { mss_fft_stage<W, 4, INV, ROWS>(a, b, n, s, tw); n /= 4; s *= 4; }
-    else { mss_fft_stage<W, 2, INV, ROWS>(a, b, n, s, tw); n /= 2; s *= 2; }
-    __syncthreads();
-    cf* t = a; a = b; b = t;
+    if (n % 4 == 0) { mss_fft_stage<W, 4, INV, ROWS, NARR>(x0, x1, n, s, tw); n /= 4; s *= 4; }
+    else { mss_fft_stage<W, 2, INV, ROWS, NARR>(x0, x1, n, s, tw); n /= 2; s *= 2; }
   }
 }
-template <int W, bool INV>
-__device__ __forceinline__ void mss_fft2d(cf* a, cf* scratch, const float2* tw) {
-  cf* x = a; cf* y = scratch;
-  mss_fft_axis<W, INV, true>(x, y, tw);
-  mss_fft_axis<W, INV, false>(x, y, tw);  // same number of stages per axis: x == a again
+template <int W, bool INV, int NARR>
+__device__ __forceinline__ void mss_fft2d(cf* x0, cf* x1, const float2* tw) {
+  mss_fft_axis<W, INV, true, NARR>(x0, x1, tw);
+  mss_fft_axis<W, INV, false, NARR>(x0, x1, tw);
 }
 
 template <int W>
-__global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
+__global__ __launch_bounds__(kMssNT, 2) void mss_loss_kernel(const MssParams p) {
   constexpr int NBLK = kMssPts / (W * W);
   constexpr int HB = W / 2 + 1;                                   // rfft2 half-spectrum width
   constexpr int NHALF = NBLK * W * HB;
@@ -82,8 +102,7 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* A = reinterpret_cast<cf*>(smem);
   cf* Bt = A + kMssPts;
-  cf* Cs = Bt + kMssPts;
-  float2* stw = reinterpret_cast<float2*>(Cs + kMssPts);           // W twiddles
+  float2* stw = reinterpret_cast<float2*>(Bt + kMssPts);           // W twiddles
   __shared__ float red[kMssNT / 64];
   const int tid = threadIdx.x;
   const int b = blockIdx.z, by = blockIdx.y, bx0 = blockIdx.x * NBLK;
@@ -111,8 +130,7 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
     Bt[idx] = zt;
   }
   __syncthreads();
-  mss_fft2d<W, false>(A, Cs, stw);
-  mss_fft2d<W, false>(Bt, Cs, stw);
+  mss_fft2d<W, false, 2>(A, Bt, stw);
 
   // ---- loss terms and spectral gradient on the half spectrum
   const float inv_w = 1.0f / (float)W;
@@ -176,6 +194,7 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
     Bt[o] = gr[it];
   }
   __syncthreads();
+  cf pks[kMssPts / kMssNT];
 #pragma unroll
   for (int it = 0; it < kMssPts / kMssNT; ++it) {
     const int idx = tid + it * kMssNT;
@@ -191,10 +210,13 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
       const cf a = A[om], c = Bt[om];
       pk.x += 0.5f * (a.x + c.y); pk.y += 0.5f * (c.x - a.y);
     }
-    Cs[idx] = pk;
+    pks[it] = pk;
   }
+  __syncthreads();  // every thread has read its G entries: the packed spectrum replaces them in A
+#pragma unroll
+  for (int it = 0; it < kMssPts / kMssNT; ++it) A[tid + it * kMssNT] = pks[it];
   __syncthreads();
-  mss_fft2d<W, true>(Cs, A, stw);
+  mss_fft2d<W, true, 1>(A, nullptr, stw);
   float* gL = p.grad + (size_t)b * 2 * plane; float* gR = gL + plane;
 #pragma unroll
   for (int it = 0; it < kMssPts / kMssNT; ++it) {
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
     const int gx = reflect_pad_index(bx * p.step - W / 2 + c, p.Wd);
     const float w = p.window[r * W + c] * inv_w;
     const size_t o = (size_t)gy * p.Wd + gx;
-    const cf v = Cs[idx];
+    const cf v = A[idx];
     unsafeAtomicAdd(gL + o, v.x * w);
     unsafeAtomicAdd(gR + o, v.y * w);
   }
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(kMssNT) void mss_loss_kernel(const MssParams p) {
 template <int W>
 static int launch_mss(const MssParams& p, hipStream_t s) {
   constexpr int NBLK = kMssPts / (W * W);
-  const size_t smem = 3 * kMssPts * sizeof(cf) + W * sizeof(float2);
+  const size_t smem = 2 * kMssPts * sizeof(cf) + W * sizeof(float2);
   auto kern = mss_loss_kernel<W>;
   static bool attr_done = false;
   if (!attr_done) {
