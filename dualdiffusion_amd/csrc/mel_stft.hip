@@ -35,11 +35,12 @@ __device__ __forceinline__ int reflect_index(int j, int L) {
 }
 
 template <int N>
-__global__ __launch_bounds__(kNT) void mel_stft_kernel(const MelStftParams p) {
+__global__ __launch_bounds__(kNT, 2) void mel_stft_kernel(const MelStftParams p) {
+  // LDS: ONE transform buffer (in-place FFT, fft_lds.hpp; the magnitudes later overwrite its first half) + the output
+  // staging: 51 + 16 KB, two workgroups per CU overlap each other's load / transform / filter phases
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  cf* bufB = bufA + N;
-  float* sOut = reinterpret_cast<float*>(bufB + N);   // [C * n_mel][kFPW]
+  float* sOut = reinterpret_cast<float*>(bufA + N);   // [C * n_mel][kFPW]
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * kFPW;
   const int tid = threadIdx.x;
@@ -52,19 +53,45 @@ __global__ __launch_bounds__(kNT) void mel_stft_kernel(const MelStftParams p) {
     if (f >= p.T) break;  // uniform
     // ---- frame load: z[n] = w[n] * (left + i*right), reflect padded by N/2
     const int base = f * p.hop - N / 2;
-    for (int n = tid; n < N; n += kNT) {
-      const int j = reflect_index(base + n, p.L);
-      const float w = p.window[n];
-      bufA[n] = cf{aL[j] * w, aR ? aR[j] * w : 0.f};
+    for (int n = 4 * tid; n < N; n += 4 * kNT) {   // 16-byte loads in the interior (base, n multiples of 4)
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.window + n);
+      const int j0 = base + n;
+      f32x4 l4, r4 = {0.f, 0.f, 0.f, 0.f};
+      if (j0 >= 0 && j0 + 3 < p.L && (p.L & 3) == 0 && (p.hop & 3) == 0) {
+        l4 = *reinterpret_cast<const f32x4*>(aL + j0);
+        if (aR) r4 = *reinterpret_cast<const f32x4*>(aR + j0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = reflect_index(j0 + e, p.L);
+          l4[e] = aL[j];
+          if (aR) r4[e] = aR[j];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
     }
-    fft6400<false, kNT>(bufA, bufB, p.tw);  // result in bufA
-    // ---- magnitudes of both channels -> bufB (as floats)
-    float* mag = reinterpret_cast<float*>(bufB);
-    for (int k = tid; k < NB; k += kNT) {
-      const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
-      const cf sl = cadd(zk, zn), sr = csub(zk, zn);
-      mag[k] = 0.5f * sqrtf(sl.x * sl.x + sl.y * sl.y);
-      mag[NB + k] = 0.5f * sqrtf(sr.x * sr.x + sr.y * sr.y);
+    fft6400_inplace<false, kNT>(bufA, p.tw);
+    // ---- magnitudes of both channels: into registers, barrier, then over the (now consumed) spectrum as floats
+    float* mag = reinterpret_cast<float*>(bufA);
+    constexpr int MI = (N / 2 + 1 + kNT - 1) / kNT;
+    float ml[MI], mr[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int k = tid + i * kNT;
+      ml[i] = mr[i] = 0.f;
+      if (k < NB) {
+        const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
+        const cf sl = cadd(zk, zn), sr = csub(zk, zn);
+        ml[i] = 0.5f * sqrtf(sl.x * sl.x + sl.y * sl.y);
+        mr[i] = 0.5f * sqrtf(sr.x * sr.x + sr.y * sr.y);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int k = tid + i * kNT;
+      if (k < NB) { mag[k] = ml[i]; mag[NB + k] = mr[i]; }
     }
     __syncthreads();
     // ---- banded mel filter bank, exponent, affine
@@ -104,7 +131,7 @@ extern "C" int ddx_mel_stft(const ddx_melstft_desc* dp, ddx_stream stream) {
                   d.B, d.C, d.L, d.T, d.hop, d.n_mel, d.band_stride, d.exponent, d.mean, d.scale};
   return dispatch([p](hipStream_t s) -> int {
     constexpr int N = 6400;
-    const size_t smem = 2 * (size_t)N * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
+    const size_t smem = (size_t)N * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
     if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "mel_stft: too many mel bands for LDS");
     auto kern = mel_stft_kernel<N>;
     static bool attr_done = false;
