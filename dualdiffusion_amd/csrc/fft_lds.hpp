@@ -99,14 +99,14 @@ __device__ __forceinline__ void fft6400(cf* a, cf* b, const float2* __restrict__
 // writes the outputs over the same array.  Two barriers per stage instead of one, but half the LDS (51 KB for 6400 points),
 // so three workgroups fit a CU and the global-memory phases of one frame overlap the transform of another.
 template <int N, int R, bool INV, int NT>
-__device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int s, const float2* __restrict__ tw) {
+__device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int s, const float2* __restrict__ tw, int tid) {
   const int m = n / R;
   const int tstep = N / n;
   constexpr int ROUNDS = (N / R + NT - 1) / NT;
   cf a[ROUNDS][R];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const int idx = threadIdx.x + r * NT;
+    const int idx = tid + r * NT;
     if (idx < N / R) {
       const int p = idx / s, q = idx - p * s;
 #pragma unroll
@@ -116,7 +116,7 @@ __device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const int idx = threadIdx.x + r * NT;
+    const int idx = tid + r * NT;
     if (idx < N / R) {
       const int p = idx / s, q = idx - p * s;
       Butterfly<R, INV>::run(a[r]);
@@ -128,16 +128,20 @@ __device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int
   __syncthreads();
 }
 
+// `tid` = threadIdx.x; kernels that call this inside a loop over frames pass a value laundered through an empty asm so that
+// the compiler does not hoist the (loop-invariant) index arithmetic of all six stages out of that loop and keep it in
+// ~100 registers (which costs the occupancy the single buffer was bought for).
 template <bool INV, int NT>
-__device__ __forceinline__ void fft6400_inplace(cf* a, const float2* __restrict__ tw) {
+__device__ __forceinline__ void fft6400_inplace(cf* a, const float2* __restrict__ tw, int tid) {
   constexpr int N = 6400;
   __syncthreads();
-  fft_stage_inplace<N, 4, INV, NT>(a, 6400, 1, tw);
-  fft_stage_inplace<N, 4, INV, NT>(a, 1600, 4, tw);
-  fft_stage_inplace<N, 4, INV, NT>(a, 400, 16, tw);
-  fft_stage_inplace<N, 4, INV, NT>(a, 100, 64, tw);
-  fft_stage_inplace<N, 5, INV, NT>(a, 25, 256, tw);
-  fft_stage_inplace<N, 5, INV, NT>(a, 5, 1280, tw);
+  fft_stage_inplace<N, 4, INV, NT>(a, 6400, 1, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 1600, 4, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 400, 16, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 100, 64, tw, tid);
+  fft_stage_inplace<N, 5, INV, NT>(a, 25, 256, tw, tid);
+  fft_stage_inplace<N, 5, INV, NT>(a, 5, 1280, tw, tid);
 }
+__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 
 }  // namespace ddx

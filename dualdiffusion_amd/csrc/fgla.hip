@@ -18,7 +18,7 @@
 namespace ddx {
 
 constexpr int kFN = 6400;
-constexpr int kFNT = 640;   // 10 waves; 3 workgroups (3 x 51 KB of LDS) per CU
+constexpr int kFNT = 640;   // 10 waves; 3 workgroups (3 x 51 KB of LDS) per CU.  (__launch_bounds__ second argument = min waves per SIMD: 8 -> <= 64 VGPRs)
 
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][ustride] state, NB valid per row (nullptr: angles = 1)
@@ -30,7 +30,7 @@ struct FglaSynthParams {
   int final_pass, stereo_merge;
 };
 
-__global__ __launch_bounds__(kFNT, 3) void fgla_synth_kernel(const FglaSynthParams p) {
+__global__ __launch_bounds__(kFNT, 8) void fgla_synth_kernel(const FglaSynthParams p) {
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kFNT, 3) void fgla_synth_kernel(const FglaSynthPara
       if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
     }
   }
-  fft6400_inplace<true, kFNT>(bufA, p.tw);
+  fft6400_inplace<true, kFNT>(bufA, p.tw, tid);
   float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
   const float invn = 1.0f / (float)N;
   for (int n = 4 * tid; n < N; n += 4 * kFNT) {   // 16 bytes per lane: four samples of each channel
@@ -132,7 +132,7 @@ __device__ __forceinline__ int reflect_idx(int j, int L) {
   return j;
 }
 
-__global__ __launch_bounds__(kFNT, 3) void fgla_analysis_kernel(const FglaAnalysisParams p) {
+__global__ __launch_bounds__(kFNT, 8) void fgla_analysis_kernel(const FglaAnalysisParams p) {
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kFNT, 3) void fgla_analysis_kernel(const FglaAnalys
 #pragma unroll
     for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
   }
-  fft6400_inplace<false, kFNT>(bufA, p.tw);
+  fft6400_inplace<false, kFNT>(bufA, p.tw, tid);
   float2* ro = p.u + ((size_t)b * p.T + t) * p.C * p.ustride;
   for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {   // two bins per lane: 16-byte read-modify-write of the state rows
     f32x4 ul = *reinterpret_cast<const f32x4*>(ro + k0), ur = {0.f, 0.f, 0.f, 0.f};

@@ -35,7 +35,7 @@ __device__ __forceinline__ int reflect_index(int j, int L) {
 }
 
 template <int N>
-__global__ __launch_bounds__(kNT, 2) void mel_stft_kernel(const MelStftParams p) {
+__global__ __launch_bounds__(kNT, 8) void mel_stft_kernel(const MelStftParams p) {
   // LDS: ONE transform buffer (in-place FFT, fft_lds.hpp; the magnitudes later overwrite its first half) + the output
   // staging: 51 + 16 KB, two workgroups per CU overlap each other's load / transform / filter phases
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,7 +48,9 @@ __global__ __launch_bounds__(kNT, 2) void mel_stft_kernel(const MelStftParams p)
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
   const int NB = N / 2 + 1;
 
+#pragma unroll 1
   for (int fi = 0; fi < kFPW; ++fi) {
+    const int tid = launder(threadIdx.x);   // (fft_lds.hpp: no hoisting of per-thread index arithmetic out of the frame loop)
     const int f = f0 + fi;
     if (f >= p.T) break;  // uniform
     // ---- frame load: z[n] = w[n] * (left + i*right), reflect padded by N/2
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kNT, 2) void mel_stft_kernel(const MelStftParams p)
 #pragma unroll
       for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
     }
-    fft6400_inplace<false, kNT>(bufA, p.tw);
+    fft6400_inplace<false, kNT>(bufA, p.tw, tid);
     // ---- magnitudes of both channels: into registers, barrier, then over the (now consumed) spectrum as floats
     float* mag = reinterpret_cast<float*>(bufA);
     constexpr int MI = (N / 2 + 1 + kNT - 1) / kNT;

@@ -94,7 +94,7 @@ __device__ __forceinline__ void mss_fft2d(cf* x0, cf* x1, const float2* tw) {
 }
 
 template <int W>
-__global__ __launch_bounds__(kMssNT, 2) void mss_loss_kernel(const MssParams p) {
+__global__ __launch_bounds__(kMssNT, 8) void mss_loss_kernel(const MssParams p) {
   constexpr int NBLK = kMssPts / (W * W);
   constexpr int HB = W / 2 + 1;                                   // rfft2 half-spectrum width
   constexpr int NHALF = NBLK * W * HB;
