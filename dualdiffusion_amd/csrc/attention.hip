@@ -53,20 +53,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   const int sv = tid % VPR;        // vector inside the row handled by this thread while staging
   const int sr = tid / VPR;
 
-  // ---- stage Q (normalised, pre-scaled by 1/sqrt(D))
-  for (int r = sr; r < 128; r += RPP) {
-    const int q = q0 + r;
+  // Global loads of a staging phase are ALL issued before the first of them is consumed (Q tile and the first K / V chunk
+  // together, later chunks while the previous one is multiplied): the loops below used to expose one memory latency per
+  // 32-row pass, i.e. 8 in a row for a 128-query tile with one key chunk (the L4 / L3 attention layers are latency-bound).
+  constexpr int NP = 128 / RPP;
+  static_assert(KC == 128, "the staging passes assume 128-row tiles");
+  using VT = decltype(Vec16<T>::v);
+  VT qreg[NP], kreg[NP], vreg[NP];
+  auto issue_kv = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int key = c0 + sr + i * RPP;
+      VT z = {};
+      kreg[i] = z; vreg[i] = z;
+      if (key < Tn) {
+        kreg[i] = *reinterpret_cast<const VT*>(qk + ((size_t)b * Tn + key) * qk_ld + head * 2 * D + D + sv * EV);
+        vreg[i] = *reinterpret_cast<const VT*>(v + ((size_t)b * Tn + key) * v_ld + head * D + sv * EV);
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int q = q0 + sr + i * RPP;
+    VT z = {};
+    qreg[i] = z;
+    if (q < Tn) qreg[i] = *reinterpret_cast<const VT*>(qk + ((size_t)b * Tn + q) * qk_ld + head * 2 * D + sv * EV);
+  }
+  issue_kv(0);
+
+  // ---- stage Q (normalised, pre-scaled by 1/sqrt(D)); rows past the sequence are zero
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int r = sr + i * RPP;
     Vec16<T> x;
+    x.v = qreg[i];
     float f[EV];
     float ss = 0.f;
-    if (q < Tn) {
-      x.v = *reinterpret_cast<const decltype(x.v)*>(qk + ((size_t)b * Tn + q) * qk_ld + head * 2 * D + sv * EV);
 #pragma unroll
-      for (int e = 0; e < EV; ++e) { f[e] = x.get(e); ss += f[e] * f[e]; }
-    } else {
-#pragma unroll
-      for (int e = 0; e < EV; ++e) f[e] = 0.f;
-    }
+    for (int e = 0; e < EV; ++e) { f[e] = x.get(e); ss += f[e] * f[e]; }
 #pragma unroll
     for (int o = VPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float sc = inv_sqrt_d / (eps + sqrtf(ss) * inv_sqrt_d);
@@ -95,23 +119,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 
   for (int c0 = 0; c0 < Tn; c0 += KC) {
     __syncthreads();  // previous chunk fully consumed
-    // ---- stage K (normalised) and V^T (normalised, transposed)
-    for (int r = sr; r < KC; r += RPP) {
-      const int key = c0 + r;
+    // ---- stage K (normalised) and V^T (normalised, transposed) from the registers loaded ahead
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = sr + i * RPP;
       float fk[EV], fv[EV];
       float ssk = 0.f, ssv = 0.f;
-      if (key < Tn) {
-        Vec16<T> xk, xv;
-        xk.v = *reinterpret_cast<const decltype(xk.v)*>(qk + ((size_t)b * Tn + key) * qk_ld + head * 2 * D + D + sv * EV);
-        xv.v = *reinterpret_cast<const decltype(xv.v)*>(v + ((size_t)b * Tn + key) * v_ld + head * D + sv * EV);
+      Vec16<T> xk, xv;
+      xk.v = kreg[i]; xv.v = vreg[i];
 #pragma unroll
-        for (int e = 0; e < EV; ++e) {
-          fk[e] = xk.get(e); ssk += fk[e] * fk[e];
-          fv[e] = xv.get(e); ssv += fv[e] * fv[e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EV; ++e) { fk[e] = 0.f; fv[e] = 0.f; }
+      for (int e = 0; e < EV; ++e) {
+        fk[e] = xk.get(e); ssk += fk[e] * fk[e];
+        fv[e] = xv.get(e); ssv += fv[e] * fv[e];
       }
 #pragma unroll
       for (int o = VPR / 2; o > 0; o >>= 1) { ssk += __shfl_xor(ssk, o, 64); ssv += __shfl_xor(ssv, o, 64); }
@@ -125,6 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
       for (int e = 0; e < EV; ++e) sVt[(sv * EV + e) * VS + r] = from_f32<T>(fv[e] * scv);
     }
     __syncthreads();
+    if (c0 + KC < Tn) issue_kv(c0 + KC);  // the next chunk travels while this one is multiplied
 
     // ---- S^T = K . Q^T for the NKT key tiles of the chunk
     f32x16 s[NKT];
