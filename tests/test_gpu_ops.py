@@ -549,3 +549,39 @@ def test_conv_dgrad_act_fused_matches_unfused(case):
         assert rel_l2(res[True][1], res[False][1]) <= 4e-3
     if res[True][2] is not None:
         assert rel_l2(res[True][2], res[False][2]) <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_merged_qk_v_conv_matches_separate_convs(dtype):
+    """attn_qk | attn_v as ONE conv: row-concatenated prepared weights (wprep row_offset / rows_total), channel-scale prologue
+    only on the q|k output tiles (prologue_rows), attention reading q|k and v as channel ranges of the merged tensor --
+    against the two separate convs + attention on contiguous tensors.  Same kernels, same summation order: equal to rounding."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dev = "cuda"
+    torch.manual_seed(5)
+    B, H, W, Cn, heads = 2, 4, 22, 128, 2
+    x = torch.randn(B, H, W, Cn, device=dev).to(dtype)
+    c_qk = torch.rand(B, Cn, device=dev) + 0.5
+    c_v = torch.rand(B, Cn, device=dev) + 0.5
+    w_qk = torch.randn(2 * Cn, Cn, 1, 1, device=dev)
+    w_v = torch.randn(Cn, Cn, 1, 1, device=dev)
+    npix = B * H * W
+    pw_qk = ops.wprep(w_qk, 1, dtype, normalize=True, qk_head_dim=Cn // heads, npix=npix)
+    pw_v = ops.wprep(w_v, 1, dtype, normalize=True, npix=npix)
+    qk = ops.conv2d(x, pw_qk, prologue=L.PRO_SCALE, chan_scale=c_qk)
+    v = ops.conv2d(x, pw_v)
+    ref = ops.attention(qk, v, heads, out_scale=c_v)
+    CK = pw_qk.CK
+    nbytes = ops.lib().ddx_wprep_bytes(3 * Cn, Cn, 1, 1, CK, ops.dtype_code(dtype))
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    ops.wprep(w_qk, 1, dtype, normalize=True, qk_head_dim=Cn // heads, CK=CK, out=buf, row_offset=0, rows_total=3 * Cn)
+    pw = ops.wprep(w_v, 1, dtype, normalize=True, CK=CK, out=buf, row_offset=2 * Cn, rows_total=3 * Cn)
+    qkv = ops.conv2d(x, pw, prologue=L.PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * Cn)
+    assert qkv.shape[-1] == 3 * Cn
+    out = ops.attention(qkv[..., :2 * Cn], qkv[..., 2 * Cn:], heads, out_scale=c_v)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float32 else 1e-3
+    assert rel_l2(qkv[..., :2 * Cn].float(), qk.float()) <= tol
+    assert rel_l2(qkv[..., 2 * Cn:].float(), v.float()) <= tol
+    assert rel_l2(out.float(), ref.float()) <= tol
