@@ -19,6 +19,7 @@
 //   LDS rows are padded by 16 B: a row stride of CK*sizeof(T)+16 bytes makes the 16-lane groups of ds_read_b128 hit
 //   16 distinct bank slots (stride 80 B -> slot = 5r mod 16, 144 B -> 9r, 272 B -> 17r; all bijective mod 16).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -488,6 +489,9 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
   struct Cand { int BM, BN; };
   const Cand cands[4] = {{256, 64}, {256, 32}, {128, 64}, {128, 32}};
   Choice best{}; double best_score = -1;
+  // experiment knob: DDX_MFMA_FORCE="BM,BN,KSP" restricts the candidates (tools/conv_bench.py sweeps)
+  int fbm = 0, fbn = 0, fksp = 0;
+  if (const char* e = std::getenv("DDX_MFMA_FORCE")) sscanf(e, "%d,%d,%d", &fbm, &fbn, &fksp);
   for (const Cand& c : cands) {
     const int BM = c.BM, BN = c.BN;
     int TH, TW; double um;
@@ -498,6 +502,7 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
     const long wgs = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, BN) * p.G;
     const int ksps[3] = {1, 2, 4};
     for (int ksp : ksps) {
+      if (fbm && (BM != fbm || BN != fbn || ksp != fksp)) continue;
       if (ksp > 1 && (BM != 128 || dtype != DDX_BF16)) continue;       // split-K variants are built for BM=128 bf16
       if (ksp > 1 && p.resample == DDX_RESAMPLE_DOWN) continue;        // the avg-pool gather is only built for KSP=1
       if (ksp > 1 && p.nchunk < 2 * ksp) continue;                      // needs >= 2 iterations per group to pay
@@ -511,6 +516,10 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
       const double fill = std::min(1.0, (double)wgs * 4 * ksp / 2048.0);
       eff *= 0.35 + 0.65 * fill;
       if (ksp > 1 && wgs >= 512) eff *= 0.8;                            // enough workgroups already: plain K loop
+      // 3x3 layers do nine taps of matrix work per staged chunk, which hides the next chunk's latency on its own: measured
+      // (DDX_MFMA_FORCE sweep, L3 / L4 shapes) split-K only pays below one workgroup per CU (160 workgroups: 15.7 -> 13.2 us)
+      // and costs 25-35 % from 320 workgroups up (12.2 -> 16.3, 15.0 -> 20.9 us)
+      if (ksize == 3 && ksp > 1 && wgs >= 256) eff *= 0.7;
       const double score = um * un * eff;
       if (score > best_score) { best_score = score; best = Choice{BM, BN, TH, TW, ksp, smem, group}; }
     }
