@@ -50,6 +50,10 @@ CASES = {
     "L4_qk": (4, 2, 43, 1280, 0, 2560, 1, 1, 0, L.PRO_SCALE, False),
     "L4_proj": (4, 2, 43, 1280, 0, 1280, 1, 1, 0, L.PRO_SCALE_SILU, True),
     "L3_qk": (4, 4, 86, 1024, 0, 2048, 1, 1, 0, L.PRO_SCALE, False),
+    "L3_qkv": (4, 4, 86, 1024, 0, 3072, 1, 1, 0, L.PRO_SCALE, False),
+    "L4_qkv": (4, 2, 43, 1280, 0, 3840, 1, 1, 0, L.PRO_SCALE, False),
+    "L3_skip_dec": (4, 4, 86, 1280, 1024, 1024, 1, 1, 0, L.PRO_NONE, False),
+    "L4_skip_dec": (4, 2, 43, 1280, 1280, 1280, 1, 1, 0, L.PRO_NONE, False),
     "L4_proj_raw": (4, 2, 43, 1280, 0, 1280, 1, 1, 0, L.PRO_NONE, True),
     "L4_v_raw": (4, 2, 43, 1280, 0, 1280, 1, 1, 0, L.PRO_NONE, False),
     "L4_res0_raw": (4, 2, 43, 1280, 0, 2560, 8, 3, 0, L.PRO_NONE, False),
