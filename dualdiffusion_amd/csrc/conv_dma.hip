@@ -515,7 +515,11 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
 
 // 1x1 layers with >= 192 output channels per group run as 256 x 256 GEMM tiles (8 waves) when that still leaves
 // enough units for the 256 CUs
-bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) { return p.Ng >= 192 && pixel_tiles * ceil_div(p.Ng, 256) >= 128; }
+bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
+  static const int knob = std::getenv("DDX_DMA_WIDE") ? atoi(std::getenv("DDX_DMA_WIDE")) : -1;   // experiment knob: 0 never, 1 default rule
+  if (knob == 0) return false;
+  return p.Ng >= 192 && pixel_tiles * ceil_div(p.Ng, 256) >= 128;
+}
 
 // TH x TW with TW a multiple of 32 (fragments never wrap tile rows) and TH*TW = 256
 bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util) {

@@ -50,6 +50,7 @@ CASES = {
     "L4_qk": (4, 2, 43, 1280, 0, 2560, 1, 1, 0, L.PRO_SCALE, False),
     "L4_proj": (4, 2, 43, 1280, 0, 1280, 1, 1, 0, L.PRO_SCALE_SILU, True),
     "L3_qk": (4, 4, 86, 1024, 0, 2048, 1, 1, 0, L.PRO_SCALE, False),
+    "L0_skip_256_raw": (4, 32, 688, 256, 0, 256, 1, 1, 0, L.PRO_NONE, False),
     "L3_qkv": (4, 4, 86, 1024, 0, 3072, 1, 1, 0, L.PRO_SCALE, False),
     "L4_qkv": (4, 2, 43, 1280, 0, 3840, 1, 1, 0, L.PRO_SCALE, False),
     "L3_skip_dec": (4, 4, 86, 1280, 1024, 1024, 1, 1, 0, L.PRO_NONE, False),
