@@ -72,7 +72,7 @@ template <int KS, int SK, int NF, int WN> struct DmaGeom {
 // other's matrix phase instead of both doing the same thing at the same time.
 // EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
 template <int KS, int SK, int NF, int WN, int PD, int EB = 0>
-__global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n) {
+__global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd) {
   using GEO = DmaGeom<KS, SK, NF, WN>;
   constexpr int NW = GEO::NW;
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
@@ -95,12 +95,30 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
   struct Unit { int b, h0, w0, n0, g; };
   const float inv_px = 1.0f / (float)ntile_px, inv_nn = 1.0f / (float)ntile_n;
   const float inv_tw = 1.0f / (float)p.tiles_w, inv_th = 1.0f / (float)p.tiles_h;
+  // XCD-aware order (per_xcd > 0; chosen per layer by the launcher): workgroups are dealt round-robin to the 8 XCDs, so slot
+  // u belongs to XCD u % 8, which walks its own contiguous eighth of a list ordered pixel tile -> channel tile -> group.
+  // All channel slices of a pixel tile (64-byte runs of the same 128-byte lines when Cg = 32) and its halo neighbours then
+  // meet in ONE L2 at about the same time instead of being fetched from HBM once per XCD.
+  const int gn = p.G * ntile_n;
+  const float inv_gn = 1.0f / (float)gn, inv_G = 1.0f / (float)p.G;
+  auto order = [&](int u) { return per_xcd ? (u & 7) * per_xcd + (u >> 3) : u; };
+  auto live = [&](int u) { return per_xcd ? ((u >> 3) < per_xcd && order(u) < total_units) : u < total_units; };
   auto decode = [&](int u) {
     Unit t;
-    const int r = fdiv(u, inv_px);
-    const int tile = u - r * ntile_px;
-    t.g = fdiv(r, inv_nn);
-    t.n0 = (r - t.g * ntile_n) * BN;
+    int tile;
+    if (per_xcd) {
+      const int o = order(u);
+      tile = fdiv(o, inv_gn);
+      const int rem = o - tile * gn;
+      const int nt = fdiv(rem, inv_G);
+      t.g = rem - nt * p.G;
+      t.n0 = nt * BN;
+    } else {
+      const int r = fdiv(u, inv_px);
+      tile = u - r * ntile_px;
+      t.g = fdiv(r, inv_nn);
+      t.n0 = (r - t.g * ntile_n) * BN;
+    }
     const int row = fdiv(tile, inv_tw);
     t.w0 = (tile - row * p.tiles_w) * p.TW;
     t.b = fdiv(row, inv_th);
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     }
   };
   auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
-    if (iu >= total_units) return;
+    if (!live(iu)) return;
     char* sbase = smem + (int)stage * GEO::STAGE;
     const int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
     const int src_id = cabs >= p.C0 ? 1 : 0;
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     if (++iq == nk) {
       iq = 0;
       iu += gridDim.x;
-      if (iu < total_units) issue_setup(iu);
+      if (live(iu)) issue_setup(iu);
     }
   };
 
@@ -242,9 +260,9 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  if (iu < total_units) issue_setup(iu);
+  if (live(iu)) issue_setup(iu);
   issue_next(S0{});
-  for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
+  for (int u = blockIdx.x; live(u); u += gridDim.x) {
     const Unit t = it;  // the issue cursor is still on this unit (it moves on during the last stage)
 #pragma unroll
     for (int i = 0; i < NF; ++i)
@@ -503,8 +521,17 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   }
   const int ntile_n = ceil_div(p.Ng, GEO::BN);
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
-  const int grid = (int)std::min<long>(total, WN == 1 ? 512 : 256);  // persistent: every CU holds 8 waves
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WN), GEO::SMEM, s, p, (int)total, ntile_n);
+  int grid = (int)std::min<long>(total, WN == 1 ? 512 : 256);  // persistent: every CU holds 8 waves
+  // XCD-aware unit order where it was measured to cut HBM fetches: 3x3 layers whose group slice of a pixel is half a cache
+  // line (Cg = 32: -39 % FETCH_SIZE) or whose unit covers a whole group's 32 output channels (-16 %).  Elsewhere the plain
+  // order already keeps a pixel tile on one XCD (B * tiles divisible by 8) and the contiguous order fetched 20-100 % more.
+  static const int xcd_knob = getenv("DDX_DMA_XCD") ? atoi(getenv("DDX_DMA_XCD")) : 1;
+  int per_xcd = 0;
+  if (!EB && KS == 3 && WN == 1 && xcd_knob && total >= 64 && (xcd_knob == 2 || p.Cg <= 32 || p.Ng <= 32)) {
+    grid &= ~7;
+    per_xcd = (int)((total + 7) / 8);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WN), GEO::SMEM, s, p, (int)total, ntile_n, per_xcd);
   if (EB && p.bwd_ws && p.bwd_dc) {
     const int tpi = p.tiles_h * p.tiles_w;
     hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
