@@ -181,3 +181,43 @@ def test_plan_two_lanes_match_single_lane():
     plan.graph_launch()
     torch.cuda.synchronize()
     assert torch.allclose(o1, ref, atol=1e-5)
+
+
+def test_unet_odd_batches_and_ragged_shapes():
+    """Tile selection / ragged edges: UNet forward at odd batch sizes and latent sizes that are not multiples of the kernel
+    tiles, bf16 against the fp32 path of the same kernels (bf16 rounding only: rel-L2 <= 3e-2), outputs finite."""
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+
+    class Fmt:
+        ms_freq_scale = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+    torch.manual_seed(0)
+    cfg = UNetConfig(model_channels=64)
+    sd, outs = None, {}
+    shapes = [(3, 32, 176), (5, 16, 80), (2, 32, 48), (1, 48, 112)]
+    for dt in (torch.float32, torch.bfloat16):
+        unet = UNet(cfg).requires_grad_(False).train(False)
+        if sd is None:
+            sd = {k: v.clone() for k, v in unet.state_dict().items()}
+            for k in sd:
+                if sd[k].ndim == 0:
+                    sd[k].fill_(0.7)
+        unet.load_state_dict(sd)
+        unet = unet.to(device="cuda", dtype=dt)
+        unet.normalize_weights()
+        for (B, H, W) in shapes:
+            g = torch.Generator(device="cuda").manual_seed(B * 1000 + H + W)
+            x = torch.randn(B, 4, H, W, device="cuda", generator=g)
+            sigma = torch.exp(torch.randn(B, device="cuda", generator=g))
+            clap = torch.randn(B, 512, device="cuda", generator=g)
+            with torch.no_grad():
+                emb = unet.get_embeddings(clap, torch.ones(B, dtype=torch.bool, device="cuda"))
+                y = unet(x * (sigma.view(-1, 1, 1, 1) ** 2 + 1).sqrt(), sigma, Fmt(), emb)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all(), (dt, B, H, W)
+            outs[(dt, B, H, W)] = y.float()
+    for (B, H, W) in shapes:
+        e = rel_l2(outs[(torch.bfloat16, B, H, W)], outs[(torch.float32, B, H, W)])
+        print(f"B={B} (4,{H},{W}): bf16 vs fp32 {e:.3e}")
+        assert e < 3e-2
