@@ -178,11 +178,14 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   const int ks = d.ksize, dt = d.dtype;
   // d.force_direct selects the kernel: 0 = automatic, 1 = scalar reference kernel, 2 = register-staged MFMA kernel,
   // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)
+  // >= 16: the register-staged kernel with tile / split-K configuration (force_direct - 16), see ConvParams::force_cfg
+  if (d.force_direct >= 16) p.force_cfg = d.force_direct - 16 + 1;
   const bool mfma = d.force_direct != 1 && conv_mfma_supported(p, ks, dt);
   static const bool dma_enabled = []() { const char* e = std::getenv("DDX_CONV_DMA"); return !e || e[0] != '0'; }();
   if (d.force_direct == 3 && !conv_dma_supported(p, ks, dt, /*any_size=*/true))
     return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the LDS-DMA kernel");
   const bool dma = d.force_direct == 3 || (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
+  if (d.force_direct >= 16 && !mfma) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the register-staged MFMA kernel");
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double es = (double)dtype_size(dt);
   const double bytes = es * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) +

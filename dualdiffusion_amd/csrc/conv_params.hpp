@@ -38,6 +38,7 @@ struct ConvParams {
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;
   int group_smem;  // LDS bytes of one split-K group's staging region
+  int force_cfg;   // register-staged kernel: 0 = heuristic choice, else 1 + 3 * tile (0..3: 256x64, 256x32, 128x64, 128x32) + split-K index (1, 2, 4)
 };
 
 // index into the prepared weight tensor wp[g][chunk][tap][NgP][CK]

@@ -33,6 +33,10 @@ MERGE_QKV = os.environ.get("DDX_MERGE_QKV", "1") != "0"     # attn_qk | attn_v a
 # step with the lane vs 5.055 ms without -- the 130 MB weight stream slows the HBM-bound L0 convs it runs beside by more than
 # the 55 us it hides -> off by default.
 EMB_LANE = os.environ.get("DDX_EMB_LANE", "0") != "0"
+# plan-time kernel selection by measurement (ops.tuning): every conv of an inference plan times its kernel candidates once.
+# Measured (default UNet, hipGraph): B=1 2.77 -> 2.66 ms, B=4 4.99 -> 4.98 ms, B=8 8.44 -> 8.40 ms -- the built-in heuristics were
+# tuned at B=4/8 and leave little there, so it is opt-in (adds ~1-2 s to the first call, run-to-run choices may differ).
+AUTOTUNE = os.environ.get("DDX_AUTOTUNE", "0") != "0"
 
 
 class PlanBuilder:
@@ -248,6 +252,19 @@ class PlanBuilder:
                           normalize=self.training and not conv.disable_weight_norm, qk_head_dim=sp["qk"], CK=sp["CK"],
                           cg_pad=sp["cg_pad"], out=sp["buf"], in_split=sp["in_split"], in_scale0=sp["in_scale0"],
                           in_scale1=sp["in_scale1"], row_offset=sp.get("row_offset", 0), rows_total=sp.get("rows_total", 0))
+        if AUTOTUNE and not self.training and self.dt == torch.bfloat16:
+            # one eager pass over the steps in which every conv times its kernel candidates on the plan's own buffers
+            # (ops.tuning); the recording below then asks for the winners.  Weights must be prepared for it.
+            self.wplan.run()
+            with ops.tuning():
+                if pre_steps is not None:
+                    pre_steps()
+                if self.lin_jobs:
+                    ops.linear_small(self.emb_table, n_jobs, max_o, emb, self.B, wdt, x_stride=emb_stride)
+                for st in self.steps:
+                    if st not in (self._fork, self._main, self._join):
+                        st()
+            torch.cuda.current_stream().synchronize()
         with self.fplan.record():
             if pre_steps is not None:
                 pre_steps()

@@ -89,6 +89,64 @@ def normalize_weights_(weight: torch.Tensor) -> None:
           "normalize_weights")
 
 
+# ---- plan-time kernel selection by measurement.  Inside `with tuning():` every conv2d call times the kernel candidates on
+# its real operands (heuristic choice, LDS-DMA kernel, every built tile / split-K configuration of the register-staged kernel)
+# and remembers the fastest per layer signature; later calls (the plan recording) ask for that kernel.  The heuristic stays
+# unless a candidate is at least 4 % faster.
+_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3}
+_conv_choice: dict = {}
+_tuning = False
+
+
+class tuning:
+    def __enter__(self):
+        global _tuning
+        self.prev, _tuning = _tuning, True
+        return self
+
+    def __exit__(self, *exc):
+        global _tuning
+        _tuning = self.prev
+        return False
+
+
+def _conv_signature(d: "L.ConvDesc") -> tuple:
+    return (d.B, d.H, d.W, d.C0, d.C1, d.Cout, d.groups, d.ksize, d.CK, d.resample, d.prologue, d.epilogue, d.dtype, d.out_act,
+            bool(d.chan_scale), bool(d.out_scale), bool(d.out2), d.pad_mode, d.prologue_rows, d.scale0 == 1.0, d.scale1 == 1.0, d.clip > 0)
+
+
+def _tune_conv(d: "L.ConvDesc") -> int:
+    st = current_stream()
+
+    def run(code: int, n: int) -> bool:
+        d.force_direct = code
+        for _ in range(n):
+            if lib().ddx_mpconv2d_fwd(C.byref(d), st) != 0:
+                return False
+        return True
+
+    def timed(code: int) -> float:
+        if not run(code, 2):
+            return float("inf")
+        best = float("inf")
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(code, 8)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 8)
+        return best
+
+    t_auto = timed(0)
+    best_code, best_t = 0, t_auto
+    for code in [3] + [16 + i for i in range(12)]:
+        t = timed(code)
+        if t < best_t:
+            best_code, best_t = code, t
+    return best_code if best_t < 0.96 * t_auto else 0
+
+
 def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = None, src1: Optional[torch.Tensor] = None,
            scale0: float = 1.0, scale1: float = 1.0, resample: int = L.RESAMPLE_KEEP, prologue: int = L.PRO_NONE,
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
@@ -109,9 +167,14 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
                    B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
                    prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
-                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=1 if force_direct else {"auto": 0, "direct": 1, "mfma": 2, "dma": 3}[path],
+                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=1 if force_direct else _PATH_CODE[path],
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO, prologue_rows=prologue_rows)
+    if d.force_direct == 0 and (_tuning or _conv_choice):
+        sig = _conv_signature(d)
+        if _tuning and sig not in _conv_choice:
+            _conv_choice[sig] = _tune_conv(d)
+        d.force_direct = _conv_choice.get(sig, 0)
     check(lib().ddx_mpconv2d_fwd(C.byref(d), current_stream()), "mpconv2d_fwd")
     return out
 

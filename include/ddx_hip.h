@@ -107,7 +107,10 @@ typedef struct {
   float res_t;              /* t of mp_sum(residual, y, t) */
   float clip;               /* <= 0: none */
   int32_t dtype;            /* activations and wp */
-  int32_t force_direct;     /* kernel choice: 0 automatic, 1 scalar reference kernel, 2 register-staged MFMA, 3 LDS-DMA MFMA */
+  int32_t force_direct;     /* kernel choice: 0 automatic, 1 scalar reference kernel, 2 register-staged MFMA, 3 LDS-DMA MFMA,
+                             * 16 + 3 * tile + k: register-staged MFMA with tile 0..3 = 256x64, 256x32, 128x64, 128x32 (pixels x
+                             * channels) and split-K 1 << k (k = 0..2); DDX_ERR_UNSUPPORTED when the combination is not built.
+                             * Used by plan-time autotuning (the host times the candidates once per layer shape). */
   /* producer-side activation (so that the CONSUMER conv needs no prologue and stages its operand untouched):
    *   out_act = 1: the stored output is mp_silu(y * out_scale[b][cout]) (out_scale NULL: mp_silu(y))  -- conv_res0 feeding
    *                conv_res1 (unet_edm2_b4.py:119-122);
