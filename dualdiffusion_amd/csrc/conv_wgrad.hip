@@ -381,9 +381,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 int wgrad_ksplit(int G, int Ng, int Cg, int ks, int ntile_px, bool wide = false) {
   const int bcw = wide ? 128 : (ks == 3 ? 32 : 64);
   const long base = (long)G * ceil_div(Ng, wide ? 128 : 64) * ceil_div(Cg, bcw);
-  long want = std::max<long>(1, 768 / base);
+  static const long want_units = std::getenv("DDX_WGRAD_WANT") ? atol(std::getenv("DDX_WGRAD_WANT")) : 768;      // experiment knobs
+  static const double cap_mb = std::getenv("DDX_WGRAD_CAP_MB") ? atof(std::getenv("DDX_WGRAD_CAP_MB")) : 48.0;
+  long want = std::max<long>(1, want_units / base);
   const double dw_mb = (double)G * Ng * Cg * ks * ks * 4.0 / 1e6;
-  if (dw_mb * want > 48.0) want = std::max<long>(1, (long)(48.0 / dw_mb));
+  if (dw_mb * want > cap_mb) want = std::max<long>(1, (long)(cap_mb / dw_mb));
   return (int)std::min<long>(want, ntile_px);
 }
 

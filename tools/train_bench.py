@@ -40,11 +40,13 @@ def main():
     mask = torch.ones(B, dtype=torch.bool, device="cuda")
     out = ts.step(samples, clap, sigma, noise, mask)       # warm-up (kernel attributes, allocator)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    times = []
+    for _ in range(steps):          # every step ends with a host read of the gradient norm: time them one by one, report the MEDIAN
+        t0 = time.perf_counter()    # (the GPU boxes are shared: host-side jitter of a loaded machine shows up as outlier steps)
         out = ts.step(samples, clap, sigma, noise, mask)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     # phases
     tr = ts.trainer
     torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -55,7 +57,7 @@ def main():
     unet.normalize_weights()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     fl = 3 * 489.3e9 * B
-    print(f"UNet train step B={B} (4,{H},{W}) bf16 compute / fp32 master: {dt * 1e3:.1f} ms/step = {B / dt:.1f} samples/s, "
+    print(f"UNet train step B={B} (4,{H},{W}) bf16 compute / fp32 master: {dt * 1e3:.1f} ms/step (median of {steps}; min {min(times) * 1e3:.1f}, max {max(times) * 1e3:.1f}) = {B / dt:.1f} samples/s, "
           f"{fl / dt / 1e12:.0f} TFLOP/s (3 x forward FLOPs); train batch {1e3 * (t2 - t1):.1f} ms (host enqueue {1e3 * t_host:.1f} ms), optimizer + weight norm {1e3 * (t3 - t2):.1f} ms; "
           f"loss {float(out['loss'].mean()):.4f} grad_norm {out['grad_norm']:.2f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
