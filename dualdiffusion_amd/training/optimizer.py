@@ -90,6 +90,9 @@ class FusedAdamW:
         self.grad_norm_logvar = self.grad_norm_logvar * c.grad_norm_std_ema_beta + (1 - c.grad_norm_std_ema_beta) * math.log(grad_var)
 
     def _table(self, grads: dict) -> torch.Tensor:
+        key = tuple(grads[k].data_ptr() for k in self._names)      # the trainer's gradients live in one persistent bucket:
+        if getattr(self, "_table_key", None) == key:               # the table is built once, no host->device copy per step
+            return self._table_dev
         arr = (L.OptimJob * len(self._names))()
         for i, k in enumerate(self._names):
             g = grads[k]
@@ -97,7 +100,9 @@ class FusedAdamW:
                 raise L.DDXError(f"FusedAdamW: gradient of {k} must be contiguous float32 with the parameter's size")
             arr[i] = L.OptimJob(p=ptr(self.params[k]), g=ptr(g), m=ptr(self.m[k]), v=ptr(self.v[k]),
                                 ema=ptr(self.ema[k]) if self.ema is not None else None, n=g.numel())
-        return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self._ws.device)
+        self._table_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self._ws.device)
+        self._table_key = key
+        return self._table_dev
 
     def step(self, grads: dict, lr: float, grad_scale: Optional[float] = None) -> float:
         """grads: d mean(loss) / d parameter (summed over ranks when distributed; pass grad_scale = loss_scale / world_size).

@@ -41,20 +41,56 @@ def allreduce_gradients(grads: dict, names: Optional[list] = None) -> dict:
 class UNetTrainStep:
 
     def __init__(self, unet, format, optimizer: OptimizerConfig = OptimizerConfig(), lr_schedule: LRScheduleConfig = LRScheduleConfig(),
-                 ema: Optional[dict] = None, ema_beta: float = 0.0, input_perturbation: float = 0.0) -> None:
+                 ema: Optional[dict] = None, ema_beta: float = 0.0, input_perturbation: float = 0.0, use_graph: bool = False) -> None:
+        """use_graph: capture the whole train batch (forward, loss, backward: ~1900 launches) into one hipGraph on first use and
+        replay it afterwards (static input buffers).  The eager loop needs ~20 ms of host time per step and every host hiccup of
+        a shared machine lands in the step time; the replay needs the host for the input copies, one graph launch, the
+        all-reduce and the four optimizer launches."""
         self.unet, self.format, self.lr_cfg = unet, format, lr_schedule
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
         self.trainer = UNetTrainer(unet)
         self.params = {k: p.data for k, p in unet.named_parameters()}
         self.opt = FusedAdamW(self.params, optimizer, ema, ema_beta)
         self.input_perturbation = input_perturbation
         self.global_step = 0
 
+    def _train_batch_graph(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation):
+        dev = self.unet.device
+        ins = [samples.to(dev, torch.float32), audio_embeddings.to(dev, torch.float32), sigma.flatten().to(dev, torch.float32),
+               noise.to(dev, torch.float32), conditioning_mask.to(dev), perturbation.to(dev, torch.float32) if perturbation is not None else None]
+        key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in ins)
+        if self._graph is None or key != self._graph_key:
+            self._static = [t.clone() if t is not None else None for t in ins]
+            st = self._static
+            run = lambda: self.trainer.train_batch(st[0], st[1], st[2], st[3], st[4], self.format, st[5], self.input_perturbation)   # noqa: E731
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):          # eager warm-up on a side stream: weight bank, job tables, kernel attributes
+                run()
+                run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_out = run()
+            self._graph_key = key
+        for d, t in zip(self._static, ins):
+            if d is not None:
+                d.copy_(t)
+        self._graph.replay()
+        return self._graph_out
+
     def step(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
              conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:
         """One optimizer step on this rank's batch (the random draws are inputs: the caller owns the generators)."""
         world = _world_size()
-        loss, grads = self.trainer.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation,
-                                               self.input_perturbation)
+        if self.use_graph:
+            loss, grads = self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation)
+        else:
+            loss, grads = self.trainer.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation,
+                                                   self.input_perturbation)
         missing = [k for k in self.params if k not in grads]
         if missing:
             raise RuntimeError(f"UNetTrainStep: no gradient for {missing[:4]}")

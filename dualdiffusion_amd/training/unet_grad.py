@@ -59,6 +59,24 @@ class UNetTrainer:
         self._scalar_tail = self.grad_flat[sum(sizes[k] for k in order if len(shapes[k]) > 0):]
         self.bank: Optional[WeightBank] = None
         self._bank_key = None
+        # persistent small buffers / job tables (keyed by name and batch size): nothing on the per-step path copies host memory
+        # to the device, so a whole train batch can be captured into a hipGraph (training.train_step, use_graph)
+        self._bufs: dict = {}
+        self._tables: dict = {}
+        self._lnf: dict = {}
+
+    def _buf(self, key, shape, dtype=torch.float32) -> torch.Tensor:
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=self.u.device)
+        return t
+
+    def _lin_table(self, key, jobs: list) -> torch.Tensor:
+        """Device job table of ops.linear_small for jobs whose weights / outputs are persistent tensors (built once per key)."""
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = ops.make_linear_jobs(jobs, self.u.device)
+        return t
 
     # ------------------------------------------------------------------------------------------------ weight bank
     def _build_bank(self, B: int, H: int, W: int) -> None:
@@ -167,7 +185,10 @@ class UNetTrainer:
         x_pre = perturbed_input.to(dev, torch.float32).contiguous() if perturbed_input is not None else x_in
         sig = sigma.flatten().to(dev, torch.float32).contiguous()
         emb_in = embeddings.to(dev, torch.float32).contiguous()
-        lnf = u.get_ln_freqs_rows(format, B, H, W).to(dev)
+        lkey = (id(getattr(format, "ms_freq_scale", format)), B, H, W)
+        lnf = self._lnf.get(lkey)
+        if lnf is None:
+            lnf = self._lnf[lkey] = u.get_ln_freqs_rows(format, B, H, W).to(dev)
         if self._bank_key != (B, H, W):
             self._build_bank(B, H, W)
         bank = self.bank
@@ -177,9 +198,9 @@ class UNetTrainer:
         ops.unet_input_prep(x_pre, sig, lnf, x0, cfg.sigma_data)
         four = torch.empty(B, u.cnoise, dtype=torch.float32, device=dev)
         ops.mpfourier(sig, u.emb_fourier.freqs.float().contiguous(), u.emb_fourier.phases.float().contiguous(), four, True)
-        e0 = torch.empty(B, u.cemb, dtype=torch.float32, device=dev)
+        e0 = self._buf(("e0", B), (B, u.cemb))
         w_noise = u.emb_noise.weight.data
-        ops.linear_small(ops.make_linear_jobs([(w_noise, None, e0, 1.0, 0.0, 1, True)], dev), 1, u.cemb, four, B, w_noise.dtype)
+        ops.linear_small(self._lin_table(("emb_noise", B), [(w_noise, None, e0, 1.0, 0.0, 1, True)]), 1, u.cemb, four, B, w_noise.dtype)
         pre, emb = torch.empty_like(e0), torch.empty_like(e0)
         ops.mpsum_rows(e0, emb_in, pre, t=cfg.label_balance, silu=False)
         ops.mpsum_rows(e0, emb_in, emb, t=cfg.label_balance, silu=True)
@@ -302,12 +323,13 @@ class UNetTrainer:
         mask = conditioning_mask.to(dev, torch.float32).contiguous()
         # get_embeddings (unet_edm2_b4.py:232-235) -- kept here with its intermediates for the backward
         xn = ops.pixelnorm(audio_embeddings.to(dev, torch.float32).contiguous())
-        ones = torch.ones(1, 1, device=dev, dtype=torch.float32)
-        uemb = torch.empty(1, u.cemb, device=dev, dtype=torch.float32)
-        cemb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
+        ones = self._buf("ones", (1, 1))
+        ones.fill_(1.0)
+        uemb = self._buf("uemb", (1, u.cemb))
+        cemb = self._buf(("cemb", B), (B, u.cemb))
         w_u, w_c = u.emb_label_unconditional.weight.data, u.emb_label.weight.data
-        ops.linear_small(ops.make_linear_jobs([(w_u, None, uemb, 1.0, 0.0, 1, True)], dev), 1, u.cemb, ones, 1, w_u.dtype)
-        ops.linear_small(ops.make_linear_jobs([(w_c, None, cemb, 1.0, 0.0, 1, True)], dev), 1, u.cemb, xn, B, w_c.dtype)
+        ops.linear_small(self._lin_table("emb_label_unconditional", [(w_u, None, uemb, 1.0, 0.0, 1, True)]), 1, u.cemb, ones, 1, w_u.dtype)
+        ops.linear_small(self._lin_table(("emb_label", B), [(w_c, None, cemb, 1.0, 0.0, 1, True)]), 1, u.cemb, xn, B, w_c.dtype)
         emb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
         ops.mpsum_rows(uemb, cemb, emb, t_rows=mask)
         # model inputs (unet_trainer.py:249-259)
@@ -318,9 +340,9 @@ class UNetTrainer:
         # learned per-sigma log-variance (unet_edm2_b4.py:237-238; no weight norm on logvar_linear)
         f_lv = torch.empty(B, cfg.logvar_channels, device=dev, dtype=torch.float32)
         ops.mpfourier(sig, u.logvar_fourier.freqs.float().contiguous(), u.logvar_fourier.phases.float().contiguous(), f_lv, True)
-        logvar = torch.empty(B, 1, device=dev, dtype=torch.float32)
+        logvar = self._buf(("logvar", B), (B, 1))
         w_lv = u.logvar_linear.weight.data
-        ops.linear_small(ops.make_linear_jobs([(w_lv, None, logvar, 1.0, 0.0, 1, False)], dev), 1, 1, f_lv, B, w_lv.dtype)
+        ops.linear_small(self._lin_table(("logvar_linear", B), [(w_lv, None, logvar, 1.0, 0.0, 1, False)]), 1, 1, f_lv, B, w_lv.dtype)
         loss, dD, dlv = ops.edm2_loss(denoised, samples, sig, logvar.view(-1), cfg.sigma_data)
         grads = self.backward(dD)
         grads["logvar_linear.weight"], _ = ops.linear_small_bwd(dlv.view(B, 1), f_lv, w_lv, 1, None, False, None)
