@@ -1,4 +1,4 @@
-"""Per-op profile of the default VAE's decode plan at the 45 s mel size (GPU box only)."""
+"""Per-op profile of the default VAE's decode and encode plans at the 45 s mel size (GPU box only)."""
 import os, sys
 import collections
 import torch
@@ -13,9 +13,11 @@ for n, p in vae.named_parameters():
     if p.ndim == 0: p.data.fill_(0.7)
 fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
 lat = torch.randn(B, 4, 32, 688, device="cuda")
+mel = torch.randn(B, 2, 256, 5504, device="cuda")
 with torch.no_grad():
     emb = vae.get_embeddings(torch.randn(B, 512, device="cuda"))
     for _ in range(2): out = vae.decode(lat.bfloat16(), emb, fmt)
+    for _ in range(2): enc = vae.encode(mel.bfloat16(), emb, fmt)
 torch.cuda.synchronize()
 for key, eng in vae._engines.items():
     prof = eng.pb.fplan.profile(reps=3)
