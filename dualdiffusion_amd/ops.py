@@ -154,7 +154,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
            path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0) -> torch.Tensor:
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
-    path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only).
+    path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
+    | an integer force_direct code (16 + 3 * tile + k: one tile / split-K configuration of the register-staged kernel).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
     (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y))."""
     B, sH, sW, C0 = src0.shape
@@ -167,7 +168,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
                    B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
                    prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
-                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype), force_direct=1 if force_direct else _PATH_CODE[path],
+                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype),
+                   force_direct=1 if force_direct else (path if isinstance(path, int) else _PATH_CODE[path]),
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO, prologue_rows=prologue_rows)
     if d.force_direct == 0 and (_tuning or _conv_choice):

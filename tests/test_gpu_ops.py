@@ -585,3 +585,39 @@ def test_merged_qk_v_conv_matches_separate_convs(dtype):
     assert rel_l2(qkv[..., :2 * Cn].float(), qk.float()) <= tol
     assert rel_l2(qkv[..., 2 * Cn:].float(), v.float()) <= tol
     assert rel_l2(out.float(), ref.float()) <= tol
+
+
+def test_conv_autotune_choice_is_consistent():
+    """ops.tuning(): a conv times its kernel candidates once per layer signature (ddx_conv_desc.force_direct >= 16 selects the
+    tile / split-K configuration of the register-staged kernel); whatever wins computes the same conv (bf16: 2e-3)."""
+    ops = _ops()
+    dev, dt = "cuda", torch.bfloat16
+    torch.manual_seed(7)
+    B, H, W, Cin, Cout = 2, 4, 86, 256, 512            # a small-M 1x1 layer: several split-K candidates are built for it
+    x = torch.randn(B, H, W, Cin, device=dev).to(dt)
+    w = torch.randn(Cout, Cin, 1, 1, device=dev)
+    pw = ops.wprep(w, 1, dt, normalize=True, npix=B * H * W)
+    ref = ops.conv2d(x, pw, path="mfma").float()
+    n0 = len(ops._conv_choice)
+    try:
+        with ops.tuning():
+            y1 = ops.conv2d(x, pw).float()
+        assert len(ops._conv_choice) == n0 + 1
+        code = list(ops._conv_choice.values())[-1]
+        assert code == 0 or code == 3 or 16 <= code < 28
+        y2 = ops.conv2d(x, pw).float()                  # outside the context the remembered choice is used
+    finally:
+        ops._conv_choice.clear()
+    torch.cuda.synchronize()
+    assert rel_l2(y1, ref) < 2e-3 and rel_l2(y2, ref) < 2e-3
+    # every explicit configuration either runs (same result) or is refused with DDX_ERR_UNSUPPORTED
+    from dualdiffusion_amd import _lib as L
+    ran = 0
+    for code in range(16, 28):
+        try:
+            y = ops.conv2d(x, pw, path=code).float()
+        except L.DDXError:
+            continue
+        ran += 1
+        assert rel_l2(y, ref) < 2e-3, code
+    assert ran >= 4
