@@ -9,6 +9,7 @@ small ones) and averaged through the optimizer's gradient scale.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -20,6 +21,11 @@ from .unet_grad import UNetTrainer
 def _world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _dist_ready() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def allreduce_gradients(grads: dict, names: Optional[list] = None) -> dict:
@@ -36,6 +42,38 @@ def allreduce_gradients(grads: dict, names: Optional[list] = None) -> dict:
         out[k] = flat[off:off + n].view(grads[k].shape)
         off += n
     return out
+
+
+class GradientExchange:
+    """Data-parallel gradient SUM over one flat fp32 bucket in two pieces (reference: accelerate's DDP wrapper buckets the
+    gradients and all-reduces each bucket as soon as it is complete: src/training/trainer.py:375 accelerator.prepare, :1016
+    accelerator.backward).
+    `flat[:early_numel]` holds the gradients that are final first (the decoder's, back-propagated before the encoder):
+    start_early() sends them asynchronously on RCCL's stream while the rest of the backward pass runs; finish() sends the tail
+    and waits for both.  xGMI rings are per-link bound (~150 GB/s): 0.6 GB per bucket keeps each collective bandwidth-bound,
+    not latency-bound."""
+
+    def __init__(self, flat: torch.Tensor, early_numel: int) -> None:
+        if not 0 <= early_numel <= flat.numel():
+            raise ValueError("GradientExchange: early_numel outside the bucket")
+        self.flat, self.early_numel, self._pending = flat, early_numel, None
+
+    def start_early(self) -> None:
+        import torch.distributed as dist
+        if self._pending is not None:
+            raise RuntimeError("GradientExchange: start_early twice in one step")
+        if self.early_numel > 0:
+            self._pending = dist.all_reduce(self.flat[:self.early_numel], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self) -> None:
+        import torch.distributed as dist
+        if self._pending is None:            # start_early never ran (graph replay, or nothing early): one collective over everything
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            return
+        if self.early_numel < self.flat.numel():
+            dist.all_reduce(self.flat[self.early_numel:], op=dist.ReduceOp.SUM)
+        self._pending.wait()
+        self._pending = None
 
 
 class UNetTrainStep:
@@ -86,6 +124,12 @@ class UNetTrainStep:
              conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:
         """One optimizer step on this rank's batch (the random draws are inputs: the caller owns the generators)."""
         world = _world_size()
+        tr = self.trainer
+        # DDX_DDP_BUCKETS=1 runs the two-bucket exchange on any initialised process group (world_size 1 included: single-GPU check)
+        exchange = world > 1 or (os.environ.get("DDX_DDP_BUCKETS", "0") == "1" and _dist_ready())
+        ex = GradientExchange(tr.grad_flat, tr.early_numel) if exchange else None
+        # eager: the decoder's bucket travels while the encoder is back-propagated; graph replay: one collective after the replay
+        tr.bucket_hook = ex.start_early if (ex is not None and not self.use_graph) else None
         if self.use_graph:
             loss, grads = self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation)
         else:
@@ -94,9 +138,8 @@ class UNetTrainStep:
         missing = [k for k in self.params if k not in grads]
         if missing:
             raise RuntimeError(f"UNetTrainStep: no gradient for {missing[:4]}")
-        if world > 1:                       # every gradient already lives in the trainer's flat bucket: one all-reduce, no gather
-            import torch.distributed as dist
-            dist.all_reduce(self.trainer.grad_flat, op=dist.ReduceOp.SUM)
+        if ex is not None:                  # every gradient already lives in the trainer's flat bucket: no gather copies
+            ex.finish()
         lr = self.lr_cfg.learning_rate * lr_multiplier(self.lr_cfg, self.global_step)
         grad_norm = self.opt.step(grads, lr, self.opt.cfg.loss_scale / world)
         # trainer.py:375-381: forced weight normalisation after every optimizer step (one launch over the weight bank)

@@ -12,6 +12,7 @@ master weights fp32.  Not yet here: get_embeddings / logvar backward (tiny linea
 from __future__ import annotations
 
 from typing import Optional
+import ctypes as C
 
 import torch
 
@@ -47,8 +48,12 @@ class UNetTrainer:
         self.tape: Optional[dict] = None
         # one flat fp32 gradient bucket for every parameter (tensors first, the scalar gains at the end): the weight bank writes
         # the master-weight gradients straight into it, the all-reduce and the optimizer read it without a gather copy
+        # Order: decoder tensors (their gradients are complete first: `early` bucket), then everything else, scalars last.
         named = list(unet.named_parameters())
-        order = [k for k, p in named if p.ndim > 0] + [k for k, p in named if p.ndim == 0]
+        tens = [k for k, p in named if p.ndim > 0]
+        order = [k for k in tens if k.startswith("dec.")] + [k for k in tens if not k.startswith("dec.")] + [k for k, p in named if p.ndim == 0]
+        self.early_numel = sum(p.numel() for k, p in named if p.ndim > 0 and k.startswith("dec."))
+        self.bucket_hook = None            # called (no arguments) once grad_flat[:early_numel] is final (UNetTrainStep: async all-reduce)
         sizes = {k: p.numel() for k, p in named}
         self.grad_flat = torch.zeros(sum(sizes.values()), dtype=torch.float32, device=unet.device)
         self.grad_views, off = {}, 0
@@ -137,7 +142,7 @@ class UNetTrainer:
         for mname, m in u.named_modules():
             if hasattr(m, "disable_weight_norm") and hasattr(m, "weight") and mname + ".weight" not in seen and not m.disable_weight_norm:
                 entries.append(BankEntry(name=mname + ".weight", weight=m.weight.data, prep=False, transpose=False, grad=False))
-        self.bank = WeightBank(entries, torch.bfloat16, self.grad_views)
+        self.bank = WeightBank(entries, torch.bfloat16, self.grad_views, early={e.name for e in entries if e.name.startswith("dec.")})
         self._bank_key = (B, H, W)
         # every emb_linear* (all read emb): persistent outputs / output gradients, one job table for the forward and one for the backward
         lin = [e for e in entries if ".emb_linear" in e.name]
@@ -146,6 +151,8 @@ class UNetTrainer:
         self.c_pool = torch.empty(B * total, dtype=torch.float32, device=dev)
         self.dc_pool = torch.zeros(B * total, dtype=torch.float32, device=dev)
         self.cvecs: dict = {}
+        lin = [e for e in lin if e.name.startswith("dec.")] + [e for e in lin if not e.name.startswith("dec.")]   # decoder jobs first
+        self.lin_n_early = sum(1 for e in lin if e.name.startswith("dec."))
         fwd, bwd, off = [], (L.LinearBwdJob * len(lin))(), 0
         for i, e in enumerate(lin):
             O = e.weight.shape[0]
@@ -276,8 +283,25 @@ class UNetTrainer:
         demb = torch.zeros_like(t["emb"])
         dskip: dict = {}
         enc_index = t["n_enc"] - 1
+        E, K = t["emb"], t["emb"].shape[1]
+        job_bytes = C.sizeof(L.LinearBwdJob)
+
+        def linear_bwd(first: int, count: int) -> None:     # emb_linear* jobs [first, first + count): dwp from the dc buffers, demb += dc @ w'
+            if count > 0:
+                check(lib().ddx_linear_small_bwd_batched(self.lin_bwd.data_ptr() + first * job_bytes, count, self.lin_max_O, ptr(E), E.stride(0),
+                                                         ptr(demb), B, K, current_stream()), "linear_small_bwd_batched")
+
+        early_done = False
         for name, blk, tape, si in reversed(t["tapes"]):
             if name.startswith("enc."):
+                if not early_done:
+                    # the decoder is through: its weight gradients are final once its emb_linear* and weight-path backward ran --
+                    # the first gradient bucket can travel (RCCL all-reduce) while the encoder is back-propagated
+                    linear_bwd(0, self.lin_n_early)
+                    self.bank.backward("early")
+                    early_done = True
+                    if self.bucket_hook is not None:
+                        self.bucket_hook()
                 if enc_index in dskip:
                     dx = ops.add3(dx, dskip.pop(enc_index))
                 enc_index -= 1
@@ -290,9 +314,7 @@ class UNetTrainer:
                     grads[f"{name}.{k[3:]}.weight"] = v
                 elif k.startswith("demb_gain"):
                     grads[f"{name}.emb_gain{k[len('demb_gain'):]}"] = v.reshape(())
-        # every emb_linear*: dwp from the blocks' dc buffers, demb += dc @ w'
-        check(lib().ddx_linear_small_bwd_batched(ptr(self.lin_bwd), self.lin_n, self.lin_max_O, ptr(t["emb"]), t["emb"].stride(0), ptr(demb), B,
-                                                 t["emb"].shape[1], current_stream()), "linear_small_bwd_batched")
+        linear_bwd(self.lin_n_early, self.lin_n - self.lin_n_early)
         # conv_in: its output is skip 0 and the first block's input
         if 0 in dskip:
             dx = ops.add3(dx, dskip.pop(0))
@@ -306,7 +328,7 @@ class UNetTrainer:
         de0 = ops.lincomb3(torch.empty_like(dpre), dpre, (1 - tb) / nrm)
         grads["embeddings"] = ops.lincomb3(torch.empty_like(dpre), dpre, tb / nrm)
         grads["emb_noise.weight"], _ = ops.linear_small_bwd(de0, t["four"], u.emb_noise.weight.data, 1, None, True, None)
-        self.bank.backward()               # weight-path backward of every block layer at once (fills the bucket views handed out above)
+        self.bank.backward("late")         # weight-path backward of the remaining layers (fills the bucket views handed out above)
         return self.store_grads(grads)
 
     # ------------------------------------------------------------------------------------------------ one training batch

@@ -47,8 +47,11 @@ def _align(n: int, a: int = 256) -> int:
 
 class WeightBank:
 
-    def __init__(self, entries: list, dtype: torch.dtype, grad_views: dict) -> None:
-        """grad_views: {parameter name: fp32 view} the master-weight gradients (and gain gradients) are written to."""
+    def __init__(self, entries: list, dtype: torch.dtype, grad_views: dict, early: Optional[set] = None) -> None:
+        """grad_views: {parameter name: fp32 view} the master-weight gradients (and gain gradients) are written to.
+        early: names of the entries whose gradients are complete first (the decoder, back-propagated before the encoder):
+        backward("early") / backward("late") run the weight-path backward for the two parts separately, so that the first
+        gradient bucket can be all-reduced while the rest of the backward pass runs."""
         self.entries, self.dtype = entries, dtype
         dev = entries[0].weight.device
         self.dev = dev
@@ -117,6 +120,15 @@ class WeightBank:
         self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         self.prefix = {ph: torch.tensor(rows[ph], dtype=torch.int32).to(dev) for ph in range(5)}
         self.total = {ph: rows[ph][-1] for ph in range(5)}
+        # BWD restricted to one part: the same job table with zero rows for the other part's entries
+        self.part_prefix, self.part_total = {}, {}
+        if early is not None:
+            for part, want in (("early", True), ("late", False)):
+                r = [0]
+                for e, g in zip(entries, geo):
+                    r.append(r[-1] + (g["Cout"] if (e.grad and ((e.name in early) == want)) else 0))
+                self.part_prefix[part] = torch.tensor(r, dtype=torch.int32).to(dev)
+                self.part_total[part] = r[-1]
 
     def _run(self, phase: int) -> None:
         check(lib().ddx_wpath_multi(ptr(self.jobs), ptr(self.prefix[phase]), self.njobs, self.total[phase], phase, dtype_code(self.dtype),
@@ -128,9 +140,14 @@ class WeightBank:
         self._run(L.WPATH_ROWSCALE)
         self._run(L.WPATH_TRANSPOSED)
 
-    def backward(self) -> None:
-        """dw[name] (and dgain) from dwp[name] for every entry; the gain-gradient slots must be zero on entry."""
-        self._run(L.WPATH_BWD)
+    def backward(self, part: Optional[str] = None) -> None:
+        """dw[name] (and dgain) from dwp[name] for every entry (part None) or for the "early" / "late" entries only; the
+        gain-gradient slots must be zero on entry."""
+        if part is None:
+            self._run(L.WPATH_BWD)
+        else:
+            check(lib().ddx_wpath_multi(ptr(self.jobs), ptr(self.part_prefix[part]), self.njobs, self.part_total[part], L.WPATH_BWD,
+                                        dtype_code(self.dtype), current_stream()), "wpath_multi")
 
     def normalize(self) -> None:
         self._run(L.WPATH_NORMALIZE)

@@ -45,6 +45,23 @@ def _worker(rank: int, ws: int, port: int, out_dir: str):
     red = allreduce_gradients(grads)
     assert torch.equal(red["w"], torch.full((3, 2), 3.0)) and float(red["gain"]) == 30.0 and torch.equal(red["b"], torch.arange(4.0) * 3)
     assert red["w"].shape == (3, 2) and red["gain"].shape == ()
+    # two-bucket exchange: the early part travels asynchronously while the tail is still being written
+    from dualdiffusion_amd.training.train_step import GradientExchange
+    flat = torch.zeros(10)
+    flat[:6] = float(rank + 1)
+    ex = GradientExchange(flat, 6)
+    ex.start_early()
+    flat[6:] = torch.arange(4.0) * (rank + 1)          # "encoder" gradients arrive after the early bucket left
+    ex.finish()
+    assert torch.equal(flat[:6], torch.full((6,), 3.0)) and torch.equal(flat[6:], torch.arange(4.0) * 3)
+    ex.finish()                                         # no early part this time: one collective over the whole bucket
+    assert torch.equal(flat[:6], torch.full((6,), 6.0)) and torch.equal(flat[6:], torch.arange(4.0) * 6)
+    for early in (0, 10):                               # degenerate splits
+        f2 = torch.full((10,), float(rank + 1))
+        e2 = GradientExchange(f2, early)
+        e2.start_early()
+        e2.finish()
+        assert torch.equal(f2, torch.full((10,), 3.0)), early
     # every rank derives the same learning rate from the global step (host schedule, reference trainer.py:653-663)
     c = LRScheduleConfig()
     assert lr_multiplier(c, 2500) == 0.5 and lr_multiplier(c, 70000) == 1.0 and abs(lr_multiplier(c, 280000) - 0.5) < 1e-12

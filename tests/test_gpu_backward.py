@@ -354,3 +354,57 @@ def test_unet_train_step_hipgraph_matches_eager():
     e = rel_l2(res[True][1], res[False][1])
     print(f"hipGraph vs eager: weights after 3 steps rel-L2 {e:.2e}")
     assert e < 2e-3
+
+
+def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
+    """The two-bucket gradient exchange (decoder bucket all-reduced asynchronously over RCCL while the encoder is
+    back-propagated, tail afterwards) on a world_size-1 `nccl` group: SUM over one rank is the identity, so losses / norms /
+    weights must match the plain step (same tolerance as eager-vs-graph: float atomics) -- checks the bucket boundary, the hook
+    placement (no decoder gradient written after its bucket left) and the stream ordering against RCCL's stream."""
+    import socket
+    import torch.distributed as dist
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.training.optimizer import LRScheduleConfig, OptimizerConfig
+    from dualdiffusion_amd.training.train_step import UNetTrainStep
+    over = dict(model_channels=256, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=64, num_layers_per_block=1, in_channels_emb=64,
+                logvar_channels=32)
+    cfg = O.unet_cfg(**over)
+    sd = O.random_unet_state(cfg, seed=9, gain_value=0.3)
+    g = torch.Generator().manual_seed(35)
+    B, H, W = 2, 16, 32
+    batches = [(torch.randn(B, 4, H, W, generator=g), torch.randn(B, 64, generator=g), torch.rand(B, generator=g) * 2 + 0.2,
+                torch.randn(B, 4, H, W, generator=g), torch.tensor([True, False])) for _ in range(3)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = {}
+    try:
+        for bucketed in (False, True):
+            if bucketed:
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+                monkeypatch.setenv("DDX_DDP_BUCKETS", "1")
+            unet = UNet(UNetConfig(**over)).requires_grad_(False)
+            unet.load_state_dict(sd, strict=True)
+            unet = unet.to(device="cuda", dtype=torch.float32).train(True)
+            ts = UNetTrainStep(unet, _Fmt(), OptimizerConfig(), LRScheduleConfig(learning_rate=5e-4, lr_warmup_steps=1, lr_reference_steps=1000))
+            ts.global_step = 1
+            tr = ts.trainer
+            assert 0 < tr.early_numel < tr.grad_flat.numel()
+            # the early bucket is exactly the decoder's tensors
+            n_dec = sum(p.numel() for k, p in unet.named_parameters() if k.startswith("dec.") and p.ndim > 0)
+            assert tr.early_numel == n_dec
+            outs = []
+            for (samples, clap, sigma, noise, mask) in batches:
+                o = ts.step(samples, clap, sigma, noise, mask)
+                outs.append((o["loss"].clone().cpu(), o["grad_norm"]))
+            res[bucketed] = (outs, unet.dec["block0_layer0"].conv_res0.weight.data.clone().cpu(),
+                             unet.enc["block0_layer0"].conv_res0.weight.data.clone().cpu())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    for (l0, n0), (l1, n1) in zip(res[False][0], res[True][0]):
+        assert rel_l2(l1, l0) < 1e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)
+    e_dec, e_enc = rel_l2(res[True][1], res[False][1]), rel_l2(res[True][2], res[False][2])
+    print(f"bucketed exchange (world 1, rccl) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
+    assert e_dec < 2e-3 and e_enc < 2e-3

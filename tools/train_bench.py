@@ -30,6 +30,9 @@ def main():
         if p.ndim == 0:
             p.data.fill_(0.7)
     use_graph = os.environ.get("DDX_TRAIN_GRAPH", "0") != "0"
+    if os.environ.get("DDX_DDP_BUCKETS", "0") == "1":    # single-GPU check of the two-bucket RCCL exchange: world_size-1 group
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1)
     ts = UNetTrainStep(unet, Fmt(), OptimizerConfig(), LRScheduleConfig(), use_graph=use_graph)
     ts.global_step = 100
     H, W = 32, 688
@@ -58,7 +61,7 @@ def main():
     unet.normalize_weights()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     fl = 3 * 489.3e9 * B
-    print(("[hipGraph replay] " if use_graph else "") + f"UNet train step B={B} (4,{H},{W}) bf16 compute / fp32 master: {dt * 1e3:.1f} ms/step (median of {steps}; min {min(times) * 1e3:.1f}, max {max(times) * 1e3:.1f}) = {B / dt:.1f} samples/s, "
+    print(("[hipGraph replay] " if use_graph else "") + ("[bucketed rccl exchange, world 1] " if os.environ.get("DDX_DDP_BUCKETS", "0") == "1" else "") + f"UNet train step B={B} (4,{H},{W}) bf16 compute / fp32 master: {dt * 1e3:.1f} ms/step (median of {steps}; min {min(times) * 1e3:.1f}, max {max(times) * 1e3:.1f}) = {B / dt:.1f} samples/s, "
           f"{fl / dt / 1e12:.0f} TFLOP/s (3 x forward FLOPs); train batch {1e3 * (t2 - t1):.1f} ms (host enqueue {1e3 * t_host:.1f} ms), optimizer + weight norm {1e3 * (t3 - t2):.1f} ms; "
           f"loss {float(out['loss'].mean()):.4f} grad_norm {out['grad_norm']:.2f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
