@@ -45,14 +45,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 constexpr int kBM = 256;
 
-template <int KS, int SK, int NF, int WN> struct DmaGeom {
+// WM waves along the pixels (MF fragments of 32 pixels each) x WN waves along the output channels (NF fragments of 32 channels)
+template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom {
   static constexpr int TAPS = KS * KS, PAD = KS / 2;
-  static constexpr int NW = 4 * WN;          // waves: 4 along the pixels x WN along the output channels
+  static constexpr int NW = WM * WN;
+  static constexpr int BM = WM * MF * 32;    // output pixels of a unit
   static constexpr int BN = 32 * NF * WN;
   static constexpr int RB = SK * 2;          // bytes per LDS row
   static constexpr int LPR = RB / 16;        // lanes (16-byte slots) per row
   static constexpr int RPW = 1024 / RB;      // rows per DMA wave-instruction
-  static constexpr int AROWS = KS == 3 ? 352 : kBM;  // halo rows a tile may stage (8x32 -> 340)
+  // halo rows a tile may stage (256 pixels: 8x32 -> 340; 512: 8x64 -> 660; 1024: 16x64 -> 1188)
+  static constexpr int AROWS = KS == 3 ? (BM == 256 ? 352 : BM == 512 ? 672 : 1216) : BM;
   static constexpr int APIECES = (AROWS + RPW - 1) / RPW;
   static constexpr int BPIECES = (TAPS * BN + RPW - 1) / RPW;
   static constexpr int A_BYTES = APIECES * 1024, B_BYTES = BPIECES * 1024;
@@ -60,7 +63,10 @@ template <int KS, int SK, int NF, int WN> struct DmaGeom {
   static constexpr int NST = 2;  // (a 3-stage ring with counted vmcnt was measured on the 1x1 variant: no gain)
   static constexpr int AI = (APIECES + NW - 1) / NW, BI = (BPIECES + NW - 1) / NW;
   static constexpr int EPI_WAVE = 32 * 36 * 4;  // one 32 pixel x 32 channel fp32 patch, rows padded to 36 floats
-  static constexpr int SMEM = NST * STAGE + NW * EPI_WAVE;
+  // 8-fragment waves in 4-wave workgroups: two workgroups per CU only fit when the epilogue patches reuse stage 1 (idle between
+  // the last matrix phase of a unit and the second stage of the next one) -- at the price of one barrier before the epilogue
+  static constexpr bool EPI_OVERLAY = MF > 2 && NW == 4;
+  static constexpr int SMEM = NST * STAGE + (EPI_OVERLAY ? 0 : NW * EPI_WAVE);
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
   static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
 };
@@ -71,14 +77,14 @@ template <int KS, int SK, int NF, int WN> struct DmaGeom {
 // starts half a unit late so that one workgroup's memory phases (epilogue stores, first-stage latency) fall into the
 // other's matrix phase instead of both doing the same thing at the same time.
 // EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
-template <int KS, int SK, int NF, int WN, int PD, int EB = 0>
-__global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd) {
-  using GEO = DmaGeom<KS, SK, NF, WN>;
+template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd) {
+  using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
   constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
   constexpr int KSTEPS = SK / 16;
-  constexpr int MF = 2;
+  constexpr bool LATE_RES = NF > 2 || MF > 2;  // too many fragments to hold every residual row during the last matrix phase
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -128,22 +134,29 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
 
   // ---- DMA source bookkeeping (per lane): this wave moves pieces wave, wave+4, ...
   const int lrow = lane / LPR, lslot = lane % LPR;
-  int ahh[AI], aww[AI], aslot[AI];  // tile-independent halo coordinates of this lane's rows
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int r = (wave + NW * i) * RPW + lrow;
+  // tile-independent halo coordinates of this lane's rows: a table for the 4-fragment variants; recomputed per unit (from a
+  // laundered lane row, so that the compiler does not turn it back into a table) where the registers go to accumulators
+  constexpr bool DMA_TABLE = MF <= 2;
+  auto a_row = [&](int i, int lr, int& hh_out, int& ww_out, int& slot_out) {
+    const int r = (wave + NW * i) * RPW + lr;
     const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
-    ahh[i] = r < R ? hh - PAD : -(1 << 20);
-    aww[i] = r - hh * TWP - PAD;
-    aslot[i] = (lslot ^ GEO::swz(r)) * 8;
-  }
-  int btap[BI], bn[BI], bslot[BI];
+    hh_out = r < R ? hh - PAD : -(1 << 20);
+    ww_out = r - hh * TWP - PAD;
+    slot_out = (lslot ^ GEO::swz(r)) * 8;
+  };
+  auto b_row = [&](int i, int lr, int& tap_out, int& n_out, int& slot_out) {
+    const int r = min((wave + NW * i) * RPW + lr, TAPS * BN - 1);
+    tap_out = r / BN;
+    n_out = r - tap_out * BN;
+    slot_out = (lslot ^ GEO::swz(r)) * 8;
+  };
+  int ahh[DMA_TABLE ? AI : 1], aww[DMA_TABLE ? AI : 1], aslot[DMA_TABLE ? AI : 1];
+  int btap[DMA_TABLE ? BI : 1], bn[DMA_TABLE ? BI : 1], bslot[DMA_TABLE ? BI : 1];
+  if constexpr (DMA_TABLE) {
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int r = min((wave + NW * i) * RPW + lrow, TAPS * BN - 1);
-    btap[i] = r / BN;
-    bn[i] = r - btap[i] * BN;
-    bslot[i] = (lslot ^ GEO::swz(r)) * 8;
+    for (int i = 0; i < AI; ++i) a_row(i, lrow, ahh[i], aww[i], aslot[i]);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) b_row(i, lrow, btap[i], bn[i], bslot[i]);
   }
   const rsrc_t rs0 = make_rsrc(p.src0, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
   const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
@@ -154,13 +167,19 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
   int iu = blockIdx.x, iq = 0, isrc = -1;
   Unit it{};
   int apix[AI], avoff[AI], bvoff[BI];
+  [[maybe_unused]] int aslot_u[DMA_TABLE ? 1 : AI];
   auto issue_setup = [&](int u) {
     it = decode(u);
     isrc = -1;
+    int lr = lrow;
+    if constexpr (!DMA_TABLE) asm volatile("" : "+v"(lr));
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int ih = it.h0 + ahh[i];
-      int iw = it.w0 + aww[i];
+      int hh, ww, sl;
+      if constexpr (DMA_TABLE) { hh = ahh[i]; ww = aww[i]; sl = aslot[i]; }
+      else { a_row(i, lr, hh, ww, sl); aslot_u[i] = sl; }
+      const int ih = it.h0 + hh;
+      int iw = it.w0 + ww;
       if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W && iw < p.W + PAD ? 2 * (p.W - 1) - iw : iw);  // only the true border mirrors
       const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
       const int pix = p.resample == DDX_RESAMPLE_UP ? (it.b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (it.b * p.sH + ih) * p.sW + iw;
@@ -168,8 +187,11 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int n = min(it.n0 + bn[i], p.NgP - 1);  // rows past NgP only feed outputs that are never stored
-      bvoff[i] = (((btap[i] * p.NgP + n) << ck_shift) + bslot[i]) * 2;
+      int tp, nn, sl;
+      if constexpr (DMA_TABLE) { tp = btap[i]; nn = bn[i]; sl = bslot[i]; }
+      else b_row(i, lr, tp, nn, sl);
+      const int n = min(it.n0 + nn, p.NgP - 1);  // rows past NgP only feed outputs that are never stored
+      bvoff[i] = (((tp * p.NgP + n) << ck_shift) + sl) * 2;
     }
   };
   auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
       isrc = src_id;
       const int cs2 = (src_id ? p.C1 : p.C0) * 2;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * cs2 + aslot[i] * 2 : kOobOffset;
+      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
     }
     const int soff_a = (src_id ? cabs - p.C0 : cabs) * 2;
     const rsrc_t rsa = src_id ? rs1 : rs0;
@@ -205,19 +227,34 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
   };
 
   // ---- fragment read addresses (bytes inside a stage); the tile geometry is the same for every unit
-  int aoff[MF][TAPS];
+  // (MF > 2: only the halo row of tap 0 is kept per fragment and the tap offsets are added at the read -- 5 VALU per read
+  // against 4 * 9 address registers the 8-fragment variant does not have)
+  constexpr bool AOFF_TABLE = MF <= 2;
+  int aoff[AOFF_TABLE ? MF : 1][AOFF_TABLE ? TAPS : 1];
+  int abase[MF];
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
     const int ml = (wm * MF + j) * 32 + l31;
     const int th = (int)(((float)ml + 0.5f) * inv_TW);
     const int tw = ml - th * TW;
-    const int base = th * TWP + tw;
+    abase[j] = th * TWP + tw;
+    if constexpr (AOFF_TABLE) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int r = base + (t / KS) * TWP + (t % KS);
-      aoff[j][t] = r * RB + ((khalf ^ GEO::swz(r)) << 4);  // k-step ks adds (2*ks) to the slot: XOR commutes below
+      for (int t = 0; t < TAPS; ++t) {
+        const int r = abase[j] + (t / KS) * TWP + (t % KS);
+        aoff[j][t] = r * RB + ((khalf ^ GEO::swz(r)) << 4);  // k-step ks adds (2*ks) to the slot: XOR commutes below
+      }
     }
   }
+  auto a_addr = [&](int j, int tap) {
+    if constexpr (AOFF_TABLE) return aoff[j][tap];
+    else {
+      int b = abase[j];
+      asm volatile("" : "+v"(b));  // (loop-invariant otherwise: the compiler would hoist all 36 addresses out of the unit loop and spill them)
+      const int r = b + (tap / KS) * TWP + (tap % KS);
+      return r * RB + ((khalf ^ GEO::swz(r)) << 4);
+    }
+  };
   // weight rows tap*BN + i*32 + l31: the swizzle only depends on l31
   const int bsw = GEO::swz(l31);
   const int boff_r = l31 * RB;
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
         wf[buf][i] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + (wn * NF + i) * 32) * RB + boff_r + (((2 * ks + khalf) ^ bsw) << 4));
 #pragma unroll
       for (int j = 0; j < MF; ++j)
-        xf[buf][j] = *reinterpret_cast<const bf16x8*>(sA + (aoff[j][tap] ^ (ks << 5)));
+        xf[buf][j] = *reinterpret_cast<const bf16x8*>(sA + (a_addr(j, tap) ^ (ks << 5)));
     };
 #pragma unroll
     for (int s0 = 0; s0 < PD && s0 < SLOTS; ++s0) load_frags(s0, s0 % RING);
@@ -254,7 +291,8 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     }
   };
 
-  float* sE = reinterpret_cast<float*>(smem + NST * GEO::STAGE + wave * GEO::EPI_WAVE);
+  static_assert(!GEO::EPI_OVERLAY || NW * GEO::EPI_WAVE <= GEO::STAGE, "epilogue patches overlay stage 1");
+  float* sE = reinterpret_cast<float*>(smem + (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE) + wave * GEO::EPI_WAVE);
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
@@ -295,21 +333,25 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     }
     // epilogue addressing: items of a 32 pixel x 32 channel patch are (pixel, 8-channel run); 128 items, 2 per lane
     long eoff[MF][2];
+    auto epilogue_offsets = [&]() {
 #pragma unroll
-    for (int j = 0; j < MF; ++j)
+      for (int j = 0; j < MF; ++j)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int idx = lane + 64 * tt;
-        const int ml = (wm * MF + j) * 32 + (idx >> 2);
-        const int th = (int)(((float)ml + 0.5f) * inv_TW);
-        const int tw = ml - th * TW;
-        const int h = t.h0 + th, w = t.w0 + tw;
-        const bool ok = h < p.H && w < p.W;
-        const int pix = (t.b * p.H + h) * p.W + w;
-        eoff[j][tt] = ok ? (long)((size_t)pix * ld_u + (size_t)t.g * p.Ng + t.n0 - cofs + wn * (NF * 32) + (idx & 3) * 8) : -1;
-        if constexpr (EB) epix[j][tt] = ok ? pix : -1;
-      }
-    u32x4 rres[NF > 2 ? 2 : NF][MF][2];
+        for (int tt = 0; tt < 2; ++tt) {
+          const int idx = lane + 64 * tt;
+          const int ml = (wm * MF + j) * 32 + (idx >> 2);
+          const int th = (int)(((float)ml + 0.5f) * inv_TW);
+          const int tw = ml - th * TW;
+          const int h = t.h0 + th, w = t.w0 + tw;
+          const bool ok = h < p.H && w < p.W;
+          const int pix = (t.b * p.H + h) * p.W + w;
+          eoff[j][tt] = ok ? (long)((size_t)pix * ld_u + (size_t)t.g * p.Ng + t.n0 - cofs + wn * (NF * 32) + (idx & 3) * 8) : -1;
+          if constexpr (EB) epix[j][tt] = ok ? pix : -1;
+        }
+    };
+    if constexpr (!LATE_RES) epilogue_offsets();  // needed by the residual prefetch inside the last matrix phase
+    u32x4 rres[NF > 2 ? 2 : (MF > 2 ? 1 : NF)][MF][2];
+    auto rslot = [](int i) { return NF > 2 ? (i & 1) : (MF > 2 ? 0 : i); };
 
     {
       // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
@@ -321,7 +363,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         issue_next(S0{});
-        if (NF <= 2 && q + 2 == nk && (EB || p.epilogue == DDX_EPI_MPSUM)) {  // residual (EB: y) rows ride along with the last matrix phase
+        if (!LATE_RES && q + 2 == nk && (EB || p.epilogue == DDX_EPI_MPSUM)) {  // residual (EB: y) rows ride along with the last matrix phase
 #pragma unroll
           for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -337,15 +379,17 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
     }
 
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
+    if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
+    if constexpr (GEO::EPI_OVERLAY) __builtin_amdgcn_s_barrier();  // every wave is done reading stage 1: the patches live there
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-      if (NF > 2 && p.epilogue == DDX_EPI_MPSUM) {  // wide tiles: no registers to prefetch all residual rows, load per column
+      if (LATE_RES && p.epilogue == DDX_EPI_MPSUM) {  // wide tiles: no registers to prefetch all residual rows, load per column
 #pragma unroll
         for (int j = 0; j < MF; ++j)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
             const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
-            rres[i & 1][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
+            rres[rslot(i)][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
           }
       }
 #pragma unroll
@@ -405,7 +449,7 @@ __global__ __launch_bounds__(256 * WN, (WN == 1 ? 2 : 1)) void conv_dma_kernel(c
           }
           if (p.epilogue == DDX_EPI_MPSUM) {
             Vec16<bf16> rv;
-            rv.v = __builtin_bit_cast(bf16x8, rres[NF > 2 ? (i & 1) : i][j][tt]);
+            rv.v = __builtin_bit_cast(bf16x8, rres[rslot(i)][j][tt]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = rv.get(e) * p.res_a + y[e] * p.res_b;
           }
@@ -507,12 +551,12 @@ __global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __rest
   }
 }
 
-template <int KS, int SK, int NF, int WN, int EB = 0>
+template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
-  using GEO = DmaGeom<KS, SK, NF, WN>;
-  static_assert(GEO::SMEM <= (WN == 1 ? 80 : 160) * 1024, "LDS budget");
-  static_assert(!EB || (NF <= 2 && WN == 1), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, 1, EB>;
+  using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
+  static_assert(GEO::SMEM <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
+  static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, (MF > 2 ? 0 : 1), EB, WM, MF>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::SMEM) != hipSuccess)
@@ -521,7 +565,7 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   }
   const int ntile_n = ceil_div(p.Ng, GEO::BN);
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
-  int grid = (int)std::min<long>(total, WN == 1 ? 512 : 256);  // persistent: every CU holds 8 waves
+  int grid = (int)std::min<long>(total, GEO::NW == 4 ? 512 : 256);  // persistent: every CU holds 8 waves
   // XCD-aware unit order where it was measured to cut HBM fetches: 3x3 layers whose group slice of a pixel is half a cache
   // line (Cg = 32: -39 % FETCH_SIZE) or whose unit covers a whole group's 32 output channels (-16 %).  Elsewhere the plain
   // order already keeps a pixel tile on one XCD (B * tiles divisible by 8) and the contiguous order fetched 20-100 % more.
@@ -531,7 +575,7 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
     grid &= ~7;
     per_xcd = (int)((total + 7) / 8);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WN), GEO::SMEM, s, p, (int)total, ntile_n, per_xcd);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), GEO::SMEM, s, p, (int)total, ntile_n, per_xcd);
   if (EB && p.bwd_ws && p.bwd_dc) {
     const int tpi = p.tiles_h * p.tiles_w;
     hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
@@ -549,15 +593,15 @@ bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
 }
 
 // TH x TW with TW a multiple of 32 (fragments never wrap tile rows) and TH*TW = 256
-bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util) {
+bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util, int bm = kBM, int max_rows_3x3 = DmaGeom<3, 16, 2, 1>::AROWS) {
   const int pad = ksize / 2;
-  const int max_rows = ksize == 3 ? DmaGeom<3, 16, 2, 1>::AROWS : kBM;
+  const int max_rows = ksize == 3 ? max_rows_3x3 : bm;
   double best = -1;
   const int tws[4] = {32, 64, 128, 256};
   for (int tw : tws) {
-    const int th = kBM / tw;
-    if ((th + 2 * pad) * (tw + 2 * pad) > max_rows) continue;
-    const double u = (double)p.H * p.W / ((double)ceil_div(p.H, th) * ceil_div(p.W, tw) * kBM);
+    const int th = bm / tw;
+    if (th < 1 || (th + 2 * pad) * (tw + 2 * pad) > max_rows) continue;
+    const double u = (double)p.H * p.W / ((double)ceil_div(p.H, th) * ceil_div(p.W, tw) * bm);
     if (u > best + 1e-9) { best = u; *TH = th; *TW = tw; }
   }
   *util = best;
@@ -621,6 +665,24 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     const bool narrow = dma_bwd_bn(p) == 32;
     if (ksize == 3) return narrow ? launch_dma_t<3, 16, 1, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 1>(p, s);
     return narrow ? launch_dma_t<1, 32, 1, 1, 1>(p, s) : launch_dma_t<1, 32, 2, 1, 1>(p, s);
+  }
+  if (ksize == 3 && p.Ng > 32) {
+    // 512 pixel x 64 channel units, 4 waves with 4 x 2 fragments each: 6 fragment reads per 8 MFMAs instead of 4 per 4 (the
+    // matrix phase of the 4-fragment variant is bound by LDS read bandwidth), and the weight slices are staged once per 512
+    // pixels instead of once per 256.  Still two workgroups per CU (epilogue patches overlaid on stage 1).
+    static const int big_knob = std::getenv("DDX_DMA_BIG") ? atoi(std::getenv("DDX_DMA_BIG")) : 0;  // 0 never, 1 rule, 2 wherever it fits
+    using BIG = DmaGeom<3, 16, 2, 1, 4, 4>;
+    int bth = 0, btw = 0; double butil = 0;
+    if (big_knob && dma_tile(p, 3, &bth, &btw, &butil, BIG::BM, BIG::AROWS)) {
+      const long units = (long)p.B * ceil_div(p.H, bth) * ceil_div(p.W, btw) * p.G * ceil_div(p.Ng, BIG::BN);
+      if (big_knob == 2 || (butil >= 0.9 && units >= 640)) {
+        p.TH = bth; p.TW = btw;
+        p.tiles_h = ceil_div(p.H, bth); p.tiles_w = ceil_div(p.W, btw);
+        p.arows_alloc = (bth + 2) * (btw + 2);
+        p.inv_TWP = 1.0f / (float)(btw + 2);
+        return launch_dma_t<3, 16, 2, 1, 0, 4, 4>(p, s);
+      }
+    }
   }
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
