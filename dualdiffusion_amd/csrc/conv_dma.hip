@@ -566,6 +566,8 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   const int ntile_n = ceil_div(p.Ng, GEO::BN);
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
   int grid = (int)std::min<long>(total, GEO::NW == 4 ? 512 : 256);  // persistent: every CU holds 8 waves
+  static const int grid_knob = getenv("DDX_DMA_GRID") ? atoi(getenv("DDX_DMA_GRID")) : 0;   // experiment knob: persistent grid size
+  if (grid_knob > 0) grid = (int)std::min<long>(total, grid_knob);
   // XCD-aware unit order where it was measured to cut HBM fetches: 3x3 layers whose group slice of a pixel is half a cache
   // line (Cg = 32: -39 % FETCH_SIZE) or whose unit covers a whole group's 32 output channels (-16 %).  Elsewhere the plain
   // order already keeps a pixel tile on one XCD (B * tiles divisible by 8) and the contiguous order fetched 20-100 % more.

@@ -21,6 +21,14 @@ CASES = {
     "L0 64->64 x8": (4, 32, 688, 512, 0, 512, 8, 0, True, False, True),
     "L0 96->64 x8 cat": (4, 32, 688, 512, 256, 512, 8, 0, False, True, False),
     "L0 64->128 x8 up": (4, 32, 688, 512, 0, 1024, 8, 1, False, True, False),
+    "L0 64->64 x8 plain": (4, 32, 688, 512, 0, 512, 8, 0, False, False, False),
+    "L0 64->64 x8 res": (4, 32, 688, 512, 0, 512, 8, 0, True, False, False),
+    "L0 64->64 x8 act": (4, 32, 688, 512, 0, 512, 8, 0, False, True, False),
+    "L0 64->64 x8 twin": (4, 32, 688, 512, 0, 512, 8, 0, False, False, True),
+    "L0 32->64 x8 plain": (4, 32, 688, 256, 0, 512, 8, 0, False, False, False),
+    "L0 64->32 x8 plain": (4, 32, 688, 512, 0, 256, 8, 0, False, False, False),
+    "L0 64->32 x8 res twin": (4, 32, 688, 512, 0, 256, 8, 0, True, False, True),
+    "L0 128->64 x8 plain": (4, 32, 688, 1024, 0, 512, 8, 0, False, False, False),
     "L0 128->64 x8 res": (4, 32, 688, 1024, 0, 512, 8, 0, True, False, True),
     "L1 128->64 x8 res": (4, 16, 344, 1024, 0, 512, 8, 0, True, False, False),
     "L1 96->128 x8": (4, 16, 344, 768, 0, 1024, 8, 0, False, True, False),
@@ -34,11 +42,14 @@ def main():
     ap.add_argument("--save")
     ap.add_argument("--check")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--cases", default="", help="comma-separated substrings; empty = all")
     a = ap.parse_args()
     dt, dev = torch.bfloat16, "cuda"
     saved = torch.load(a.check) if a.check else {}
     outs = {}
     for name, (B, H, W, C0, C1, Cout, G, rs, has_res, act, twin) in CASES.items():
+        if a.cases and not any(c == name for c in a.cases.split(",")):
+            continue
         g = torch.Generator(device=dev).manual_seed(hash(name) % 1000 if False else len(name) * 7 + B)
         sh, sw = (H // 2, W // 2) if rs == 1 else (H, W)
         a0 = torch.randn(B, sh, sw, C0, device=dev, generator=g).to(dt)
