@@ -78,7 +78,7 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
 // other's matrix phase instead of both doing the same thing at the same time.
 // EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
 template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd, const int tile_order) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
@@ -125,10 +125,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
       t.g = fdiv(r, inv_nn);
       t.n0 = (r - t.g * ntile_n) * BN;
     }
-    const int row = fdiv(tile, inv_tw);
-    t.w0 = (tile - row * p.tiles_w) * p.TW;
-    t.b = fdiv(row, inv_th);
-    t.h0 = (row - t.b * p.tiles_h) * p.TH;
+    // tile -> (image, tile row, tile column).  tile_order 0: row-major.  1: column-major inside an image (the XCD-contiguous
+    // order walks consecutive tiles, so vertical neighbours -- which share 2 of the 10 halo rows -- run back to back in one L2).
+    // 2: plain order, where tile T runs on XCD T % 8 at time T / 8: columns of tiles_h tiles are dealt to the XCDs as runs
+    // (run r = image * tiles_w + column -> XCD r % 8), so a column's tiles are resident together in one L2.
+    if (tile_order == 0) {
+      const int row = fdiv(tile, inv_tw);
+      t.w0 = (tile - row * p.tiles_w) * p.TW;
+      t.b = fdiv(row, inv_th);
+      t.h0 = (row - t.b * p.tiles_h) * p.TH;
+    } else {
+      int run, th;
+      if (tile_order == 1) {
+        run = fdiv(tile, inv_th);
+        th = tile - run * p.tiles_h;
+      } else {
+        const int k = tile >> 3;
+        const int kr = fdiv(k, inv_th);
+        th = k - kr * p.tiles_h;
+        run = kr * 8 + (tile & 7);
+      }
+      t.b = fdiv(run, inv_tw);
+      t.w0 = (run - t.b * p.tiles_w) * p.TW;
+      t.h0 = th * p.TH;
+    }
     return t;
   };
 
@@ -577,7 +597,16 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
     grid &= ~7;
     per_xcd = (int)((total + 7) / 8);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), GEO::SMEM, s, p, (int)total, ntile_n, per_xcd);
+  // vertical halo sharing (see `decode`): column-major tiles for the XCD-contiguous order; run-dealt columns for the plain
+  // order when tiles and columns split evenly over the 8 XCDs
+  static const int col_knob = getenv("DDX_DMA_COL") ? atoi(getenv("DDX_DMA_COL")) : 0;  // measured neutral: off
+  int tile_order = 0;
+  if (!EB && KS == 3 && col_knob && p.tiles_h > 1) {  // (EB: the dc reduction relies on image-major unit rows)
+    const int ntile_px = p.B * p.tiles_h * p.tiles_w;
+    if (per_xcd) tile_order = 1;
+    else if (ntile_px % 8 == 0 && (p.B * p.tiles_w) % 8 == 0 && grid % 8 == 0) tile_order = 2;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), GEO::SMEM, s, p, (int)total, ntile_n, per_xcd, tile_order);
   if (EB && p.bwd_ws && p.bwd_dc) {
     const int tpi = p.tiles_h * p.tiles_w;
     hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
