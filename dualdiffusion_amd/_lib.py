@@ -18,7 +18,7 @@ DDX_F32, DDX_BF16 = 0, 1
 RESAMPLE_KEEP, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
 RESAMPLE_UP_BWD, RESAMPLE_DOWN_BWD = 3, 4
 PRO_NONE, PRO_SILU, PRO_SCALE, PRO_SCALE_SILU = 0, 1, 2, 3
-PAD_ZERO, PAD_REFLECT_W = 0, 1
+PAD_ZERO, PAD_REFLECT_W, PAD_SWAP_SRC1 = 0, 1, 2
 EPI_STORE, EPI_MPSUM = 0, 1
 
 
@@ -160,6 +160,7 @@ PROTOTYPES = {
                                   C.c_int32, C.c_float, C.c_void_p]),
     "ddx_ddec_input_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "ddx_cat2_act": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_cat2_swap": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "ddx_ddec_output_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),

@@ -163,8 +163,11 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;
   p.clip = d.clip;
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
-  p.reflect_w = d.pad_mode == DDX_PAD_REFLECT_W ? 1 : 0;
-  if (p.reflect_w && (d.W < 2 || d.resample != DDX_RESAMPLE_KEEP)) return set_error(DDX_ERR_UNSUPPORTED, "conv: reflect padding needs W >= 2 and no fused resample");
+  p.reflect_w = (d.pad_mode & DDX_PAD_REFLECT_W) ? 1 : 0;
+  p.swap1 = (d.pad_mode & DDX_PAD_SWAP_SRC1) ? 1 : 0;
+  if (d.pad_mode & ~3) return set_error(DDX_ERR_ARG, "conv: pad_mode");
+  if (p.reflect_w && (d.W < 2 || d.resample == DDX_RESAMPLE_DOWN)) return set_error(DDX_ERR_UNSUPPORTED, "conv: reflect padding needs W >= 2 and no fused 2x2 average");
+  if (p.swap1 && (!d.src1 || (d.B & 1))) return set_error(DDX_ERR_ARG, "conv: DDX_PAD_SWAP_SRC1 needs src1 and an even image count");
   *pp = p;
   return 0;
 }

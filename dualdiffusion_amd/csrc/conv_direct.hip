@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
     size_t pix = idx / p.Cout;
     const int w = (int)(pix % p.W); pix /= p.W;
     const int h = (int)(pix % p.H);
-    const int b = (int)(pix / p.H);
+    const int bo = (int)(pix / p.H);
     const int g = o / p.Ng, n = o - g * p.Ng;
     float acc = 0.f;
     for (int tap = 0; tap < taps; ++tap) {
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
         const T* src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
         const int Cs = first ? p.C0 : p.C1;
         const int cc = first ? cabs : cabs - p.C0;
+        const int b = (!first && p.swap1) ? (bo ^ 1) : bo;
         float x;
         if (p.resample == DDX_RESAMPLE_DOWN) {
           const size_t base = (((size_t)b * p.sH + 2 * ih) * p.sW + 2 * iw) * Cs + cc;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
         }
         x *= first ? p.scale0 : p.scale1;
         const int pro = (p.pro_rows > 0 && o >= p.pro_rows) ? DDX_PRO_NONE : p.prologue;
-        if (pro & DDX_PRO_SCALE) x *= p.cscale[(size_t)b * p.Cin + cabs];
+        if (pro & DDX_PRO_SCALE) x *= p.cscale[(size_t)bo * p.Cin + cabs];
         if (pro & DDX_PRO_SILU) x = mp_silu_f(x);
         x = to_f32<T>(from_f32<T>(x));  // the MFMA path rounds the operand to T in LDS
         acc += x * to_f32<T>(wp[wp_index(g, n, tap, c, p.nchunk, taps, p.NgP, p.CK)]);
@@ -50,10 +51,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
     if (p.epilogue == DDX_EPI_MPSUM) acc = to_f32<T>(reinterpret_cast<const T*>(p.res)[idx]) * p.res_a + acc * p.res_b;
     if (p.clip > 0.f) acc = fminf(fmaxf(acc, -p.clip), p.clip);
     if (p.out2) {  // twin: with a channel scale and a raw main output the scale belongs to the twin (training forward)
-      const float tc = (p.out_cs && !p.out_act) ? p.out_cs[(size_t)b * p.Cout + o] : 1.0f;
+      const float tc = (p.out_cs && !p.out_act) ? p.out_cs[(size_t)bo * p.Cout + o] : 1.0f;
       reinterpret_cast<T*>(p.out2)[idx] = from_f32<T>(mp_silu_f(acc * tc * p.out2_scale));
     }
-    if (p.out_act) acc = mp_silu_f(p.out_cs ? acc * p.out_cs[(size_t)b * p.Cout + o] : acc);
+    if (p.out_act) acc = mp_silu_f(p.out_cs ? acc * p.out_cs[(size_t)bo * p.Cout + o] : acc);
     reinterpret_cast<T*>(p.out)[idx] = from_f32<T>(acc);
   }
 }

@@ -222,8 +222,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     if (src_id != isrc) {  // (re)compute the per-lane row offsets for this source's channel stride
       isrc = src_id;
       const int cs2 = (src_id ? p.C1 : p.C0) * 2;
+      const int dpix = (src_id && p.swap1) ? ((it.b ^ 1) - it.b) * p.sH * p.sW : 0;   // pair-swapped image of the second source
 #pragma unroll
-      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
     }
     const int soff_a = (src_id ? cabs - p.C0 : cabs) * 2;
     const rsrc_t rsa = src_id ? rs1 : rs0;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     if (DN) pix = (b * p.sH + 2 * ih) * p.sW + 2 * iw;
     else if (p.resample == DDX_RESAMPLE_UP) pix = (b * p.sH + (ih >> 1)) * p.sW + (iw >> 1);
     else pix = (b * p.sH + ih) * p.sW + iw;
-    apix[i] = ok ? pix : 0;
+    apix[i] = ok ? pix : b * p.sH * p.sW;   // (invalid items read the image's first pixel: in bounds for the swapped source too)
     avalid |= (ok ? 1u : 0u) << i;
   }
 
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     const bool first = cabs < p.C0;
     a_src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
     a_cs = first ? p.C0 : p.C1;
+    if (!first && p.swap1) a_src += (ptrdiff_t)((b ^ 1) - b) * p.sH * p.sW * p.C1;   // pair-swapped image
     a_cc = first ? cabs : cabs - p.C0;
     cvalid_cur = cvalid;
     sscale_cur = first ? p.scale0 : p.scale1;

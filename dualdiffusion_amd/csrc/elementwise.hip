@@ -456,25 +456,59 @@ template <typename T>
 __global__ __launch_bounds__(256) void ddec_input_prep_kernel(const float* __restrict__ x, const float* __restrict__ xref, const float* __restrict__ sigma,
                                                               T* __restrict__ out, T* __restrict__ out_sw, int B, int H, int W, int ppf, int Cpad,
                                                               float sd, int add_const) {
+  // one thread per pixel: the fp32 planes are read along W (coalesced per channel), the NHWC row leaves as whole 16-byte vectors
+  // (consecutive threads write consecutive rows: one contiguous run per wave)
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int nv = Cpad / EV;
   const size_t total = (size_t)B * 2 * H * W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int w = (int)(i % W);
     size_t r = i / W;
     const int h = (int)(r % H); r /= H;
     const int z = (int)(r & 1), b = (int)(r >> 1);
-    const float sg = sigma[b];
-    const float c_in = rsqrtf(sd * sd + sg * sg);
+    const float c_in = rsqrtf(sd * sd + sigma[b] * sigma[b]);
+    const float* xr = xref + (((size_t)b * 2 + z) * H * ppf + (size_t)h * ppf) * W + w;
     T* o = out + i * Cpad;
-    T* os = out_sw + ((((size_t)b * 2 + (1 - z)) * H + h) * W + w) * Cpad;
-    const T v0 = from_f32<T>(c_in * x[(((size_t)b * 2 + z) * H + h) * W + w]);
-    o[0] = v0; os[0] = v0;
-    for (int p = 0; p < ppf; ++p) {
-      const T v = from_f32<T>(xref[(((size_t)b * 2 + z) * H * ppf + (size_t)h * ppf + p) * W + w]);
-      o[1 + p] = v; os[1 + p] = v;
+    T* os = out_sw ? out_sw + ((((size_t)b * 2 + (1 - z)) * H + h) * W + w) * Cpad : nullptr;
+    for (int v = 0; v < nv; ++v) {
+      Vec16<T> ov;
+#pragma unroll
+      for (int e = 0; e < EV; ++e) {
+        const int c = v * EV + e;
+        float val = 0.f;
+        if (c == 0) val = c_in * x[i];
+        else if (c <= ppf) val = xr[(size_t)(c - 1) * W];
+        else if (c == ppf + 1 && add_const) val = 1.f;
+        ov.set(e, val);
+      }
+      *reinterpret_cast<decltype(ov.v)*>(o + v * EV) = ov.v;
+      if (os) *reinterpret_cast<decltype(ov.v)*>(os + v * EV) = ov.v;
     }
-    int c = 1 + ppf;
-    if (add_const) { o[c] = from_f32<T>(1.f); os[c] = from_f32<T>(1.f); ++c; }
-    for (; c < Cpad; ++c) { o[c] = from_f32<T>(0.f); os[c] = from_f32<T>(0.f); }
+  }
+}
+
+// out = [sa * a | sb * b] on channels (mp_cat), out_act = mp_silu(out)
+template <typename T>
+__global__ __launch_bounds__(256) void cat2_act_kernel(const T* __restrict__ a, float sa, const T* __restrict__ b, float sb, T* __restrict__ out,
+                                                       T* __restrict__ out_act, size_t nrows, int C0, int C1) {
+  constexpr int EV = 16 / (int)sizeof(T);
+  const int nv0 = C0 / EV, nv = (C0 + C1) / EV;
+  const size_t total = nrows * nv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / nv;
+    const int v = (int)(i - row * nv);
+    Vec16<T> x, o, oa;
+    float s;
+    if (v < nv0) { x.v = *reinterpret_cast<const decltype(x.v)*>(a + row * C0 + (size_t)v * EV); s = sa; }
+    else { x.v = *reinterpret_cast<const decltype(x.v)*>(b + row * C1 + (size_t)(v - nv0) * EV); s = sb; }
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const float c = to_f32<T>(from_f32<T>(x.get(e) * s));   // wa * a rounded in the tensor dtype, as mp_cat does
+      o.set(e, c);
+      oa.set(e, mp_silu_f(c));
+    }
+    *reinterpret_cast<decltype(o.v)*>(out + row * (C0 + C1) + (size_t)v * EV) = o.v;
+    *reinterpret_cast<decltype(o.v)*>(out_act + row * (C0 + C1) + (size_t)v * EV) = oa.v;
   }
 }
 
@@ -517,7 +551,7 @@ __global__ __launch_bounds__(256) void ddec_output_combine_kernel(const T* __res
 
 extern "C" int ddx_ddec_input_prep(const float* x, const float* x_ref, const float* sigma, void* out, void* out_swapped, int32_t B, int32_t H,
                                    int32_t W, int32_t ppf, int32_t Cpad, float sigma_data, int32_t add_const, int32_t dtype, ddx_stream stream) {
-  if (!x || !x_ref || !sigma || !out || !out_swapped || Cpad < 1 + ppf + (add_const ? 1 : 0)) return set_error(DDX_ERR_ARG, "ddec_input_prep: bad args");
+  if (!x || !x_ref || !sigma || !out || Cpad < 1 + ppf + (add_const ? 1 : 0) || Cpad % (dtype == DDX_BF16 ? 8 : 4)) return set_error(DDX_ERR_ARG, "ddec_input_prep: bad args");
   return dispatch([=](hipStream_t s) -> int {
     const int blocks = grid_for((size_t)B * 2 * H * W);
     if (dtype == DDX_BF16)
@@ -543,6 +577,21 @@ extern "C" int ddx_cat2_swap(const void* a, float scale_a, const void* b, float 
       hipLaunchKernelGGL(cat2_swap_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)a, scale_a, (const float*)b, scale_b, (float*)out, (float*)out_swapped, (size_t)rows_per_image, nrows, C0, C1);
     return check_launch("cat2_swap");
   }, stream, "cat2_swap", 0.0, (double)images * rows_per_image * (C0 + C1) * (double)dtype_size(dtype) * (out ? 3.0 : 2.0));
+}
+
+extern "C" int ddx_cat2_act(const void* a, float scale_a, const void* b, float scale_b, void* out, void* out_act, int64_t rows, int32_t C0,
+                            int32_t C1, int32_t dtype, ddx_stream stream) {
+  if (!a || !b || !out || !out_act || rows <= 0 || C0 <= 0 || C1 <= 0) return set_error(DDX_ERR_ARG, "cat2_act: bad args");
+  const int ev = dtype == DDX_BF16 ? 8 : 4;
+  if (C0 % ev || C1 % ev) return set_error(DDX_ERR_UNSUPPORTED, "cat2_act: channel counts must fill 16-byte vectors");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)rows * ((C0 + C1) / ev));
+    if (dtype == DDX_BF16)
+      hipLaunchKernelGGL(cat2_act_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)a, scale_a, (const bf16*)b, scale_b, (bf16*)out, (bf16*)out_act, (size_t)rows, C0, C1);
+    else
+      hipLaunchKernelGGL(cat2_act_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)a, scale_a, (const float*)b, scale_b, (float*)out, (float*)out_act, (size_t)rows, C0, C1);
+    return check_launch("cat2_act");
+  }, stream, "cat2_act", 0.0, (double)rows * (C0 + C1) * (double)dtype_size(dtype) * 3.0);
 }
 
 extern "C" int ddx_ddec_output_combine(const void* y, int32_t y_channels, const float* x_in, const float* sigma, float* out, int32_t B,

@@ -20,7 +20,7 @@ from typing import Optional, Union
 import torch
 
 from ... import ops
-from ..._lib import DDXError, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_UP, check, current_stream, dtype_code, lib, ptr
+from ..._lib import DDXError, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, check, current_stream, dtype_code, lib, ptr
 from ...engine import mp_cat_weights
 from .unet import DualDiffusionUNet, DualDiffusionUNetConfig
 
@@ -190,39 +190,58 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         w8[:w_out.shape[0]] = w_out
         self._out_gain = self.out_gain.data.float().reshape(1)
         P["conv_out"] = ops.wprep(pair(w8), 1, dt, gain_ptr=self._out_gain)
+        # emb_linear of every block in ONE launch: gains as device scalars, job tables cached per image count
+        self._blocks = [(f"{side}.{n}", b) for side in ("enc", "dec") for n, b in getattr(self, side).items() if n != "conv_in"]
+        self._gain32 = {pre: b.emb_gain.data.float().reshape(1) for pre, b in self._blocks}
+        self._emb_tables: dict = {}
         self._prepared, self._prepared_key = P, key
         return P
 
+    def _emb_scales(self, emb2: torch.Tensor) -> dict:
+        """c = emb_linear(emb) * emb_gain + 1 of every block (unet_edm2_ddec_mclt_b1.py:104-105), {block: [N, Cmid] fp32}."""
+        N = emb2.shape[0]
+        if N not in self._emb_tables:
+            outs = {pre: torch.empty(N, b.conv_res0.out_channels, dtype=torch.float32, device=emb2.device) for pre, b in self._blocks}
+            table = ops.make_linear_jobs([(b.emb_linear.weight, self._gain32[pre], outs[pre], 1.0, 1.0, self.config.emb_linear_groups, False)
+                                          for pre, b in self._blocks], emb2.device)
+            self._emb_tables[N] = (table, outs, max(b.conv_res0.out_channels for _, b in self._blocks))
+        table, outs, max_o = self._emb_tables[N]
+        ops.linear_small(table, len(self._blocks), max_o, emb2, N, self._blocks[0][1].emb_linear.weight.dtype)
+        return outs
+
     # ------------------------------------------------------------------ forward
-    def _block(self, P: dict, pre: str, blk: DDecBlockWeights, x: torch.Tensor, emb2: torch.Tensor, skip: Optional[torch.Tensor] = None,
-               wa: float = 1.0, wb: float = 1.0) -> torch.Tensor:
-        """x (| skip: mp_cat with weights wa, wb) -> block output.  conv_skip mixes the stereo pair: its second source is the
-        pair-swapped copy of its input."""
+    def _block(self, P: dict, pre: str, blk: DDecBlockWeights, x: torch.Tensor, x_act: Optional[torch.Tensor], c: torch.Tensor,
+               skip: Optional[torch.Tensor] = None, wa: float = 1.0, wb: float = 1.0, want_twin: bool = False):
+        """x (| skip: mp_cat with weights wa, wb) -> (block output, mp_silu(output) | None).
+
+        Every operand is consumed as stored (activations are applied by the PRODUCER: pixel-norm / mp_cat / the previous conv
+        write the mp_silu'd twin the 3x3 convs read), so all convs run on the LDS-DMA kernel; the (2,1,1) skip conv mixes the
+        stereo pair through DDX_PAD_SWAP_SRC1 (second source = the same tensor, image b ^ 1) and a nearest upsample is folded
+        into the source addressing of both convs -- no swapped copies, no upsampled tensor.
+        x_act: mp_silu(x) when the producer wrote it (decoder blocks without a skip input); None otherwise."""
         cfg = self.config
+        rs = RESAMPLE_KEEP
         if skip is not None:
             assert blk.resample_mode == "keep"
-            x, x_sw = ops.cat2_swap(x, wa, skip, wb)                  # mp_cat materialised once, with its swapped twin
-        else:
-            x_sw = None
-        if blk.resample_mode != "keep":
+            x, x_act = ops.cat2_act(x, wa, skip, wb)                  # mp_cat materialised once, with its activated twin
+        if blk.resample_mode == "up":
+            rs = RESAMPLE_UP
+        elif blk.resample_mode == "down":
             N, H, W, Cn = x.shape
-            out = torch.empty((N, H * 2, W * 2, Cn) if blk.resample_mode == "up" else (N, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device)
-            x = ops.resample2d(x, out, RESAMPLE_UP if blk.resample_mode == "up" else RESAMPLE_DOWN)
-        if x_sw is None:
-            _, x_sw = ops.cat2_swap(x, want_cat=False)
-        N = x.shape[0]
-        Cmid = blk.conv_res0.out_channels
-        c = torch.empty(N, Cmid, dtype=torch.float32, device=x.device)
-        w_e = blk.emb_linear.weight
-        table = ops.make_linear_jobs([(w_e, self._gain32[pre], c, 1.0, 1.0, cfg.emb_linear_groups, False)], x.device)
-        ops.linear_small(table, 1, Cmid, emb2, N, w_e.dtype)
-        self._keep.append(table)
+            x = ops.resample2d(x, torch.empty((N, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device), RESAMPLE_DOWN)
         if blk.flavor == "enc":
-            x = ops.pixelnorm(ops.conv2d(x, P[pre + ".skip"], src1=x_sw))
-        y = ops.conv2d(x, P[pre + ".res0"], prologue=PRO_SILU, reflect_w=True)
-        if blk.flavor == "dec":
-            x = ops.conv2d(x, P[pre + ".skip"], src1=x_sw)
-        return ops.conv2d(y, P[pre + ".res1"], prologue=PRO_SCALE_SILU, chan_scale=c, residual=x, res_t=cfg.res_balance, clip=256.0, reflect_w=True)
+            xs = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True)
+            x_act = torch.empty_like(xs)
+            x = ops.pixelnorm(xs, out_act=x_act)
+            y = ops.conv2d(x_act, P[pre + ".res0"], reflect_w=True, out_act=True, out_scale=c)
+        else:
+            if x_act is None:
+                raise DDXError("DDec block: decoder blocks read a pre-activated operand")
+            y = ops.conv2d(x_act, P[pre + ".res0"], resample=rs, reflect_w=True, out_act=True, out_scale=c)
+            x = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True, resample=rs)
+        twin = torch.empty_like(x) if want_twin else None
+        out = ops.conv2d(y, P[pre + ".res1"], residual=x, res_t=cfg.res_balance, clip=256.0, reflect_w=True, out2=twin)
+        return out, twin
 
     @torch.no_grad()
     def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: Optional[torch.Tensor] = None,
@@ -236,9 +255,6 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         if H != cfg.in_num_freqs:
             raise DDXError(f"x_in has {H} frequency rows, the config says in_num_freqs = {cfg.in_num_freqs}")
         P = self._prep()
-        self._keep: list = []
-        self._gain32 = {f"{side}.{n}": b.emb_gain.data.float().reshape(1) for side in ("enc", "dec") for n, b in getattr(self, side).items()
-                        if n != "conv_in"}
         x_in = x_in.to(dev, torch.float32).contiguous()
         sig = sigma.flatten().to(dev, torch.float32).contiguous()
         src = perturbed_input.to(dev, torch.float32).contiguous() if perturbed_input is not None else x_in
@@ -246,10 +262,9 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         ppf = self.psd_freqs_per_freq
         if tuple(xr.shape) != (B, 2, H * ppf, W):
             raise DDXError(f"x_ref must be [B, 2, {H * ppf}, W], got {tuple(xr.shape)}")
-        # ---- input assembly: channels [c_in * x, psd chunk 0..ppf-1, 1] of image n = 2b + z (zero padded to 8k), + swapped twin
+        # ---- input assembly: channels [c_in * x, psd chunk 0..ppf-1, 1] of image n = 2b + z (zero padded to 8k)
         x0 = torch.empty(B * 2, H, W, self._cin_pad, dtype=dt, device=dev)
-        x0_sw = torch.empty_like(x0)
-        check(lib().ddx_ddec_input_prep(ptr(src), ptr(xr), ptr(sig), ptr(x0), ptr(x0_sw), B, H, W, ppf, self._cin_pad, cfg.sigma_data,
+        check(lib().ddx_ddec_input_prep(ptr(src), ptr(xr), ptr(sig), ptr(x0), None, B, H, W, ppf, self._cin_pad, cfg.sigma_data,
                                         int(cfg.add_constant_channel), dtype_code(dt), current_stream()), "ddec_input_prep")
         # ---- embedding: emb_noise(fourier(ln sigma / 4)) (no label path), one row per image
         four = torch.empty(B, self.cnoise, dtype=torch.float32, device=dev)
@@ -261,25 +276,31 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         if dt == torch.bfloat16:
             emb = emb.to(dt).float()            # the reference casts emb to bfloat16 before the emb_linear layers (:305)
         emb2 = emb.repeat_interleave(2, dim=0).contiguous()
-        # ---- encoder / decoder
-        x = ops.conv2d(x0, P["conv_in"], src1=x0_sw, reflect_w=True)
+        cs = self._emb_scales(emb2)
+        # ---- encoder / decoder.  Twins (mp_silu of a block output) are written where the next block reads one: the decoder
+        # blocks without a skip input (in0 / in1 / up); blocks with a skip get theirs from the mp_cat pass.
+        enc_names = [n for n in self.enc if n != "conv_in"]
+        dec_names = list(self.dec)
+        x = ops.conv2d(x0, P["conv_in"], src1=x0, swap_src1=True, reflect_w=True)
         skips = [x]
-        for name, blk in self.enc.items():
-            if name == "conv_in":
-                continue
-            x = self._block(P, "enc." + name, blk, x, emb2)
+        x_act = None
+        for i, name in enumerate(enc_names):
+            last = i == len(enc_names) - 1
+            x, x_act = self._block(P, "enc." + name, self.enc[name], x, None, cs["enc." + name], want_twin=last and "layer" not in dec_names[0])
             skips.append(x)
-        for name, blk in self.dec.items():
+        for i, name in enumerate(dec_names):
+            blk = self.dec[name]
+            nxt = dec_names[i + 1] if i + 1 < len(dec_names) else None
+            want = nxt is not None and "layer" not in nxt
             if "layer" in name:
                 sk = skips.pop()
                 wa, wb = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
-                x = self._block(P, "dec." + name, blk, x, emb2, sk, wa, wb)
+                x, x_act = self._block(P, "dec." + name, blk, x, None, cs["dec." + name], sk, wa, wb, want_twin=want)
             else:
-                x = self._block(P, "dec." + name, blk, x, emb2)
-        _, x_sw = ops.cat2_swap(x, want_cat=False)
-        y8 = ops.conv2d(x, P["conv_out"], src1=x_sw, reflect_w=True)
+                x, x_act = self._block(P, "dec." + name, blk, x, x_act, cs["dec." + name], want_twin=want)
+        y8 = ops.conv2d(x, P["conv_out"], src1=x, swap_src1=True, reflect_w=True)
         out = torch.empty(B, 2, H, W, dtype=torch.float32, device=dev)
         check(lib().ddx_ddec_output_combine(ptr(y8), y8.shape[-1], ptr(x_in), ptr(sig), ptr(out), B, 2 * H * W, cfg.sigma_data, dtype_code(dt),
                                             current_stream()), "ddec_output_combine")
-        torch.cuda.current_stream().synchronize()    # job tables of this call are temporaries
+        torch.cuda.current_stream().synchronize()    # the emb_noise job table of this call is a temporary
         return out

@@ -152,12 +152,13 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
-           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0) -> torch.Tensor:
+           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False) -> torch.Tensor:
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | an integer force_direct code (16 + 3 * tile + k: one tile / split-K configuration of the register-staged kernel).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
-    (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y))."""
+    (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y)).
+    swap_src1: src1 is read from the pair-swapped image (b ^ 1): second depth tap of a (2,k,k) conv on a folded stereo pair."""
     B, sH, sW, C0 = src0.shape
     if out_hw is None:
         out_hw = {L.RESAMPLE_KEEP: (sH, sW), L.RESAMPLE_UP: (sH * 2, sW * 2), L.RESAMPLE_DOWN: (sH // 2, sW // 2)}[resample]
@@ -171,7 +172,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype),
                    force_direct=1 if force_direct else (path if isinstance(path, int) else _PATH_CODE[path]),
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
-                   pad_mode=L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO, prologue_rows=prologue_rows)
+                   pad_mode=(L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO) | (L.PAD_SWAP_SRC1 if swap_src1 else 0), prologue_rows=prologue_rows)
     if d.force_direct == 0 and (_tuning or _conv_choice):
         sig = _conv_signature(d)
         if _tuning and sig not in _conv_choice:
@@ -350,6 +351,16 @@ def edm2_loss(denoised: torch.Tensor, target: torch.Tensor, sigma: torch.Tensor,
     check(lib().ddx_edm2_loss(ptr(denoised), ptr(target), ptr(sigma), ptr(logvar), float(sigma_data), ptr(loss), ptr(dd), ptr(dlv), ptr(ws), B, n,
                               current_stream()), "edm2_loss")
     return loss, dd, dlv
+
+
+def cat2_act(a: torch.Tensor, scale_a: float, b: torch.Tensor, scale_b: float):
+    """(cat, mp_silu(cat)) with cat = [scale_a * a | scale_b * b] on the channel axis (mp_cat), NHWC, one pass."""
+    C0, C1 = a.shape[-1], b.shape[-1]
+    out = torch.empty(*a.shape[:-1], C0 + C1, dtype=a.dtype, device=a.device)
+    out_act = torch.empty_like(out)
+    check(lib().ddx_cat2_act(ptr(a), float(scale_a), ptr(b), float(scale_b), ptr(out), ptr(out_act), a.numel() // C0, C0, C1,
+                             dtype_code(a.dtype), current_stream()), "cat2_act")
+    return out, out_act
 
 
 def cat2_swap(a: torch.Tensor, scale_a: float = 1.0, b: Optional[torch.Tensor] = None, scale_b: float = 1.0, want_cat: bool = True):

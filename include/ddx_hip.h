@@ -90,7 +90,11 @@ enum { DDX_RESAMPLE_KEEP = 0, DDX_RESAMPLE_UP = 1, DDX_RESAMPLE_DOWN = 2,
        DDX_RESAMPLE_UP_BWD = 3, DDX_RESAMPLE_DOWN_BWD = 4 };
 enum { DDX_PRO_NONE = 0, DDX_PRO_SILU = 1, DDX_PRO_SCALE = 2, DDX_PRO_SCALE_SILU = 3 };
 enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1, DDX_EPI_SILU_BWD = 2 /* internal: ddx_mpconv2d_dgrad_act */ };
-enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1 };
+enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1,
+       /* flag, OR-ed in: src1 is read from the pair-swapped image (index b ^ 1; B even) -- the second depth tap of a (2,k,k)
+        * MPConv3D on a stereo pair folded into the batch (modules/daes/dae_edm2_d3.py:62-84: the reflected depth row of a depth
+        * of two IS the other slice), without materialising the swapped copy */
+       DDX_PAD_SWAP_SRC1 = 2 };
 
 typedef struct {
   const void* src0;         /* NHWC [B][sH][sW][C0] */
@@ -122,7 +126,7 @@ typedef struct {
   void* out2;               /* NHWC [B][H][W][Cout] or NULL */
   int32_t out_act;
   float out2_scale;
-  /* DDX_PAD_ZERO (F.conv2d padding) | DDX_PAD_REFLECT_W: zero rows above / below, mirrored columns left / right -- the
+  /* bit 0: DDX_PAD_ZERO (F.conv2d padding) | DDX_PAD_REFLECT_W: zero rows above / below, mirrored columns left / right -- the
    * ReflectionPad3d((k/2, k/2, 0, 0, ...)) + conv3d(padding=(0, k/2, 0)) of MPConv3D (modules/daes/dae_edm2_d3.py:62-84). */
   int32_t pad_mode;
   /* > 0: the prologue (chan_scale / mp_silu) only applies to output channels below prologue_rows; the rest read the raw
@@ -365,7 +369,7 @@ int ddx_nhwc_to_nchw_ld(const void* x, int32_t ld, float* y, int32_t B, int32_t 
  * Layout glue of the diffusion decoder (modules/unets/unet_edm2_ddec_mclt_b1.py:295-326).  The 5-D (B, C, 2, H, W) tensors of the
  * reference are NHWC images ordered n = 2*b + z; "pair-swapped" = the same rows stored at image n ^ 1 (the reflected depth row of
  * MPConv3D, i.e. the other stereo channel), which the depth-2 kernels read as the conv's second source.
- *   ddx_ddec_input_prep    : x [B][2][H][W], x_ref [B][2][H*ppf][W] fp32 -> out / out_swapped [2B][H][W][Cpad] with channels
+ *   ddx_ddec_input_prep    : x [B][2][H][W], x_ref [B][2][H*ppf][W] fp32 -> out / out_swapped (may be NULL) [2B][H][W][Cpad] with channels
  *                            [x / sqrt(sd^2 + sigma^2), psd chunk 0..ppf-1, 1 (add_const), 0 ...]
  *   ddx_cat2_swap          : out = [scale_a * a | scale_b * b] on channels (mp_cat; b / out may be NULL: plain copy) and the same
  *                            rows pair-swapped into out_swapped
@@ -375,6 +379,10 @@ int ddx_ddec_input_prep(const float* x, const float* x_ref, const float* sigma, 
                         int32_t W, int32_t ppf, int32_t Cpad, float sigma_data, int32_t add_const, int32_t dtype, ddx_stream stream);
 int ddx_cat2_swap(const void* a, float scale_a, const void* b, float scale_b, void* out, void* out_swapped, int64_t images,
                   int64_t rows_per_image, int32_t C0, int32_t C1, int32_t dtype, ddx_stream stream);
+/* out = [scale_a * a | scale_b * b] (mp_cat, rounded in the tensor dtype) and out_act = mp_silu(out): the operand of the
+ * skip conv and the pre-activated operand of conv_res0 of a decoder block in one pass (unet_edm2_ddec_mclt_b1.py:107-116). */
+int ddx_cat2_act(const void* a, float scale_a, const void* b, float scale_b, void* out, void* out_act, int64_t rows, int32_t C0, int32_t C1,
+                 int32_t dtype, ddx_stream stream);
 int ddx_ddec_output_combine(const void* y, int32_t y_channels, const float* x_in, const float* sigma, float* out, int32_t B,
                             int64_t per_sample, float sigma_data, int32_t dtype, ddx_stream stream);
 

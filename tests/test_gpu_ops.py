@@ -506,6 +506,57 @@ def test_conv_reflect_w_padding(path, dtype):
     assert rel_l2(to_nchw(ops.conv2d(to_nhwc(x, dtype), pw, path=path)), ref) > 1e-2
 
 
+@pytest.mark.parametrize("path,dtype,ks,up", [("direct", torch.float32, 3, False), ("mfma", torch.float32, 3, False), ("mfma", torch.bfloat16, 1, False),
+                                              ("dma", torch.bfloat16, 1, False), ("dma", torch.bfloat16, 3, False), ("dma", torch.bfloat16, 1, True),
+                                              ("mfma", torch.float32, 1, True), ("dma", torch.bfloat16, 3, True)])
+def test_conv_swap_src1(path, dtype, ks, up):
+    """DDX_PAD_SWAP_SRC1: the second source read from the pair-swapped image (b ^ 1) equals a conv over an explicitly swapped
+    copy (the (2,k,k) MPConv3D depth taps of the diffusion decoder); also with reflect-W padding and the fused nearest
+    upsample (reflect + upsample was refused before this round)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(97 + ks)
+    B, H, W, Cin, Cout = 4, 10, 70, 32, 64
+    sh, sw = (H // 2, W // 2) if up else (H, W)
+    x = _round(torch.randn(B, Cin, sh, sw, generator=g), dtype)
+    w = torch.randn(Cout, 2 * Cin, ks, ks, generator=g)
+    wp_ref = O.prepared_weight(w)
+    if dtype == torch.bfloat16:
+        wp_ref = _round(wp_ref, dtype)
+    x_sw = x.reshape(B // 2, 2, Cin, sh, sw).flip(1).reshape(B, Cin, sh, sw)
+    xc = torch.cat([x, x_sw], dim=1)
+    if up:
+        xc = torch.nn.functional.interpolate(xc, scale_factor=2, mode="nearest")
+    pad = ks // 2
+    xp = torch.nn.functional.pad(xc, (pad, pad, 0, 0), mode="reflect") if pad else xc
+    ref = torch.nn.functional.conv2d(xp, wp_ref, padding=(pad, 0))
+    pw = ops.wprep(w.cuda(), 1, dtype)
+    xn = to_nhwc(x, dtype)
+    from dualdiffusion_amd import _lib as L
+    out = ops.conv2d(xn, pw, src1=xn, swap_src1=True, reflect_w=ks == 3, path=path, resample=L.RESAMPLE_UP if up else L.RESAMPLE_KEEP)
+    torch.cuda.synchronize()
+    e = rel_l2(to_nchw(out), ref)
+    assert e < TOL[dtype], (path, ks, up, e)
+    # not vacuous: without the swap the result differs
+    e0 = rel_l2(to_nchw(ops.conv2d(xn, pw, src1=xn, reflect_w=ks == 3, path=path, resample=L.RESAMPLE_UP if up else L.RESAMPLE_KEEP)), ref)
+    assert e0 > 1e-2
+    with pytest.raises(Exception):      # odd image count: no pairs
+        ops.conv2d(xn[:3].contiguous(), pw, src1=xn[:3].contiguous(), swap_src1=True, path=path)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cat2_act(dtype):
+    """ddx_cat2_act: mp_cat materialised with its mp_silu'd twin in one pass."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    a = _round(torch.randn(3, 7, 9, 32, generator=g), dtype).cuda().to(dtype)
+    b = _round(torch.randn(3, 7, 9, 64, generator=g), dtype).cuda().to(dtype)
+    out, act = ops.cat2_act(a, 0.8, b, 1.3)
+    ref = torch.cat([(a.float() * 0.8).to(dtype), (b.float() * 1.3).to(dtype)], dim=-1)
+    assert torch.equal(out, ref)
+    ref_act = torch.nn.functional.silu(ref.float()) / 0.596
+    assert rel_l2(act.float(), ref_act) < (5e-3 if dtype == torch.bfloat16 else 1e-6)
+
+
 @pytest.mark.parametrize("case", ["chan_scale", "two_parts_add", "two_parts_ng96", "scale_only"])
 def test_conv_dgrad_act_fused_matches_unfused(case):
     """ddx_mpconv2d_dgrad_act (activation backward in the data-gradient conv's epilogue, LDS-DMA kernel) against the conv
