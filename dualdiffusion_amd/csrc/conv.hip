@@ -140,7 +140,7 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   if (!d.src0 || !d.wp || !d.out) return set_error(DDX_ERR_ARG, "conv: null buffer");
   if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.C0 <= 0 || d.Cout <= 0 || d.groups <= 0) return set_error(DDX_ERR_ARG, "conv: bad size");
   if ((d.C1 > 0) != (d.src1 != nullptr)) return set_error(DDX_ERR_ARG, "conv: src1/C1 mismatch");
-  const int Cin = d.C0 + d.C1;
+  const int Cin = (d.C0 + d.C1) * ((d.pad_mode & DDX_PAD_SWAP_PAIRED) ? 2 : 1);
   if (Cin % d.groups || d.Cout % d.groups) return set_error(DDX_ERR_ARG, "conv: channels not divisible by groups");
   if (d.ksize != 1 && d.ksize != 3) return set_error(DDX_ERR_UNSUPPORTED, "conv: ksize must be 1 or 3");
   if ((d.prologue & DDX_PRO_SCALE) && !d.chan_scale) return set_error(DDX_ERR_ARG, "conv: chan_scale missing");
@@ -165,7 +165,10 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   p.reflect_w = (d.pad_mode & DDX_PAD_REFLECT_W) ? 1 : 0;
   p.swap1 = (d.pad_mode & DDX_PAD_SWAP_SRC1) ? 1 : 0;
-  if (d.pad_mode & ~3) return set_error(DDX_ERR_ARG, "conv: pad_mode");
+  p.paired = (d.pad_mode & DDX_PAD_SWAP_PAIRED) ? 1 : 0;
+  if (d.pad_mode & ~7) return set_error(DDX_ERR_ARG, "conv: pad_mode");
+  if (p.paired && (p.swap1 || !d.src1 || (d.B & 1) || d.groups != 1 || d.chan_scale))
+    return set_error(DDX_ERR_ARG, "conv: DDX_PAD_SWAP_PAIRED needs src1, an even image count, one group and no channel scale");
   if (p.reflect_w && (d.W < 2 || d.resample == DDX_RESAMPLE_DOWN)) return set_error(DDX_ERR_UNSUPPORTED, "conv: reflect padding needs W >= 2 and no fused 2x2 average");
   if (p.swap1 && (!d.src1 || (d.B & 1))) return set_error(DDX_ERR_ARG, "conv: DDX_PAD_SWAP_SRC1 needs src1 and an even image count");
   *pp = p;

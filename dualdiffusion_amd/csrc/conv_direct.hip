@@ -25,11 +25,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
       if (ih < 0 || ih >= p.H || iw < 0 || iw >= p.W) continue;
       for (int c = 0; c < p.Cg; ++c) {
         const int cabs = g * p.Cg + c;
-        const bool first = cabs < p.C0;
+        const bool second_half = p.paired && cabs >= p.C0 + p.C1;
+        const int cpart = second_half ? cabs - (p.C0 + p.C1) : cabs;
+        const bool first = cpart < p.C0;
         const T* src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
         const int Cs = first ? p.C0 : p.C1;
-        const int cc = first ? cabs : cabs - p.C0;
-        const int b = (!first && p.swap1) ? (bo ^ 1) : bo;
+        const int cc = first ? cpart : cpart - p.C0;
+        const int b = (second_half || (!first && p.swap1)) ? (bo ^ 1) : bo;
         float x;
         if (p.resample == DDX_RESAMPLE_DOWN) {
           const size_t base = (((size_t)b * p.sH + 2 * ih) * p.sW + 2 * iw) * Cs + cc;

@@ -217,12 +217,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
     if (!live(iu)) return;
     char* sbase = smem + (int)stage * GEO::STAGE;
-    const int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
+    int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
+    const int half = p.C0 + p.C1;
+    const int swapped = (p.paired && cabs >= half) ? 1 : 0;   // [src0 | src1 | src0' | src1']: second half from image b ^ 1
+    if (swapped) cabs -= half;
     const int src_id = cabs >= p.C0 ? 1 : 0;
-    if (src_id != isrc) {  // (re)compute the per-lane row offsets for this source's channel stride
-      isrc = src_id;
+    if (src_id + 2 * swapped != isrc) {  // (re)compute the per-lane row offsets for this source's channel stride
+      isrc = src_id + 2 * swapped;
       const int cs2 = (src_id ? p.C1 : p.C0) * 2;
-      const int dpix = (src_id && p.swap1) ? ((it.b ^ 1) - it.b) * p.sH * p.sW : 0;   // pair-swapped image of the second source
+      const int dpix = (swapped || (src_id && p.swap1)) ? ((it.b ^ 1) - it.b) * p.sH * p.sW : 0;   // pair-swapped image
 #pragma unroll
       for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
     }
@@ -656,6 +659,7 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   if (p.resample == DDX_RESAMPLE_DOWN) return false;
   const int SK = ksize == 3 ? 16 : 32;
   if (p.Cg % (2 * SK) || p.C0 % SK || (p.src1 && p.C1 % 8)) return false;  // stages are processed in pairs
+  if (p.paired && p.C1 % SK) return false;                                   // (no stage may straddle two of the four parts)
   if (p.CK % SK) return false;
   if (p.Ng % 8 || p.Cout % 8) return false;
   if (p.epilogue == DDX_EPI_MPSUM && p.out_act && p.out_cs && (p.Cout % 4)) return false;

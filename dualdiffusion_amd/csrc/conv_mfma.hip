@@ -152,11 +152,13 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     const int cg = ch * CK + v * EV;  // channel inside the group
     const bool cvalid = cg < p.Cg && ch < p.nchunk;  // (split-K groups may run past the last chunk: zero operand)
     const int cabs = cvalid ? g * p.Cg + cg : 0;   // channel of the (virtually concatenated) input
-    const bool first = cabs < p.C0;
+    const bool second_half = p.paired && cabs >= p.C0 + p.C1;   // [src0 | src1 | src0' | src1']
+    const int cpart = second_half ? cabs - (p.C0 + p.C1) : cabs;
+    const bool first = cpart < p.C0;
     a_src = reinterpret_cast<const T*>(first ? p.src0 : p.src1);
     a_cs = first ? p.C0 : p.C1;
-    if (!first && p.swap1) a_src += (ptrdiff_t)((b ^ 1) - b) * p.sH * p.sW * p.C1;   // pair-swapped image
-    a_cc = first ? cabs : cabs - p.C0;
+    if (second_half || (!first && p.swap1)) a_src += (ptrdiff_t)((b ^ 1) - b) * p.sH * p.sW * a_cs;   // pair-swapped image
+    a_cc = first ? cpart : cpart - p.C0;
     cvalid_cur = cvalid;
     sscale_cur = first ? p.scale0 : p.scale1;
     if (pro & DDX_PRO_SCALE) {  // raw per-(b, channel) factors; folded with the source scale at commit time

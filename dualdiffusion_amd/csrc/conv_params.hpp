@@ -27,6 +27,7 @@ struct ConvParams {
   float out2_scale;
   int reflect_w;        // columns outside the image are mirrored (ReflectionPad on W) instead of zero
   int swap1;            // src1 is read from image b ^ 1 (DDX_PAD_SWAP_SRC1)
+  int paired;           // input = [src0 | src1 | src0' | src1'], ' = image b ^ 1 (DDX_PAD_SWAP_PAIRED); Cin = 2 * (C0 + C1)
   // DDX_EPI_SILU_BWD (data-gradient conv fused with the backward of the producer-side activation; `res` = y of the first part)
   const void* bwd_y1;   // y of the second channel part (or null)
   void* bwd_out1;       // output of the second channel part

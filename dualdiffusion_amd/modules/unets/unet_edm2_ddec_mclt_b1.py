@@ -171,6 +171,7 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
                 a, b = torch.cat([a, z], 1), torch.cat([b, z], 1)
             return torch.cat([a, b], dim=1).contiguous()
 
+        cat = self._cat_plan()
         w_in = self.enc["conv_in"].weight.data
         cin = w_in.shape[1]
         self._cin_pad = (cin + 7) // 8 * 8
@@ -184,7 +185,12 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
                 pre = f"{side}.{name}"
                 P[pre + ".res0"] = ops.wprep(blk.conv_res0.weight.data[:, :, 0].contiguous(), G, dt)
                 P[pre + ".res1"] = ops.wprep(blk.conv_res1.weight.data[:, :, 0].contiguous(), G, dt)
-                P[pre + ".skip"] = ops.wprep(pair(blk.conv_skip.weight.data), 1, dt)
+                w_skip = blk.conv_skip.weight.data
+                if pre in cat:      # mp_cat operand never materialised: its weights wa | wb go into the columns of both depth taps
+                    Cx, Cs, wa, wb, _ = cat[pre]
+                    col = torch.cat([torch.full((Cx,), wa), torch.full((Cs,), wb)]).to(device=w_skip.device, dtype=torch.float32)
+                    w_skip = w_skip.float() * col[None, :, None, None, None]     # (fp32 master for the preparation: no extra rounding)
+                P[pre + ".skip"] = ops.wprep(pair(w_skip), 1, dt)
         w_out = self.conv_out.weight.data
         w8 = torch.zeros(8, *w_out.shape[1:], dtype=w_out.dtype, device=w_out.device)   # 1 output channel -> one 16-byte NHWC vector
         w8[:w_out.shape[0]] = w_out
@@ -196,6 +202,18 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         self._emb_tables: dict = {}
         self._prepared, self._prepared_key = P, key
         return P
+
+    def _cat_plan(self) -> dict:
+        """{decoder block with a skip input: (Cx, Cskip, wa, wb, index of the skip in encoder order)} (forward :317-322)."""
+        skips = [m.out_channels for m in self.enc.values()]
+        plan, cout = {}, skips[-1]
+        for name, blk in self.dec.items():
+            if "layer" in name:
+                cs = skips.pop()
+                wa, wb = mp_cat_weights(cout, cs, self.config.concat_balance)
+                plan["dec." + name] = (cout, cs, float(wa), float(wb), len(skips))
+            cout = blk.out_channels
+        return plan
 
     def _emb_scales(self, emb2: torch.Tensor) -> dict:
         """c = emb_linear(emb) * emb_gain + 1 of every block (unet_edm2_ddec_mclt_b1.py:104-105), {block: [N, Cmid] fp32}."""
@@ -211,22 +229,18 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
 
     # ------------------------------------------------------------------ forward
     def _block(self, P: dict, pre: str, blk: DDecBlockWeights, x: torch.Tensor, x_act: Optional[torch.Tensor], c: torch.Tensor,
-               skip: Optional[torch.Tensor] = None, wa: float = 1.0, wb: float = 1.0, want_twin: bool = False):
-        """x (| skip: mp_cat with weights wa, wb) -> (block output, mp_silu(output) | None).
+               skip: Optional[torch.Tensor] = None, skip_act: Optional[torch.Tensor] = None, twin_scale: Optional[float] = None):
+        """x (| skip: mp_cat operand, never materialised) -> (block output, mp_silu(twin_scale * output) | None).
 
-        Every operand is consumed as stored (activations are applied by the PRODUCER: pixel-norm / mp_cat / the previous conv
-        write the mp_silu'd twin the 3x3 convs read), so all convs run on the LDS-DMA kernel; the (2,1,1) skip conv mixes the
-        stereo pair through DDX_PAD_SWAP_SRC1 (second source = the same tensor, image b ^ 1) and a nearest upsample is folded
-        into the source addressing of both convs -- no swapped copies, no upsampled tensor.
-        x_act: mp_silu(x) when the producer wrote it (decoder blocks without a skip input); None otherwise."""
+        Every operand is consumed as stored: activations are applied by the PRODUCER (pixel-norm and the previous convs write
+        the mp_silu'd twins the 3x3 convs read, with the consumer's mp_cat weight inside the activation), so all convs run on
+        the LDS-DMA kernel.  The (2,1,1) skip conv mixes the stereo pair through DDX_PAD_SWAP_SRC1 / _PAIRED (second depth tap =
+        the same tensors, image b ^ 1; the mp_cat weights live in its prepared weights) and a nearest upsample is folded into
+        the source addressing of both convs -- no swapped copies, no concatenated or upsampled tensor.
+        x_act: mp_silu(x) (blocks without skip) / mp_silu(wa * x) (with skip); skip_act: mp_silu(wb * skip)."""
         cfg = self.config
-        rs = RESAMPLE_KEEP
-        if skip is not None:
-            assert blk.resample_mode == "keep"
-            x, x_act = ops.cat2_act(x, wa, skip, wb)                  # mp_cat materialised once, with its activated twin
-        if blk.resample_mode == "up":
-            rs = RESAMPLE_UP
-        elif blk.resample_mode == "down":
+        rs = RESAMPLE_UP if blk.resample_mode == "up" else RESAMPLE_KEEP
+        if blk.resample_mode == "down":
             N, H, W, Cn = x.shape
             x = ops.resample2d(x, torch.empty((N, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device), RESAMPLE_DOWN)
         if blk.flavor == "enc":
@@ -235,12 +249,16 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
             x = ops.pixelnorm(xs, out_act=x_act)
             y = ops.conv2d(x_act, P[pre + ".res0"], reflect_w=True, out_act=True, out_scale=c)
         else:
-            if x_act is None:
-                raise DDXError("DDec block: decoder blocks read a pre-activated operand")
-            y = ops.conv2d(x_act, P[pre + ".res0"], resample=rs, reflect_w=True, out_act=True, out_scale=c)
-            x = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True, resample=rs)
-        twin = torch.empty_like(x) if want_twin else None
-        out = ops.conv2d(y, P[pre + ".res1"], residual=x, res_t=cfg.res_balance, clip=256.0, reflect_w=True, out2=twin)
+            if x_act is None or (skip is not None and skip_act is None):
+                raise DDXError("DDec block: decoder blocks read pre-activated operands")
+            y = ops.conv2d(x_act, P[pre + ".res0"], src1=skip_act, resample=rs, reflect_w=True, out_act=True, out_scale=c)
+            if skip is not None:
+                x = ops.conv2d(x, P[pre + ".skip"], src1=skip, swap_paired=True)
+            else:
+                x = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True, resample=rs)
+        twin = torch.empty_like(x) if twin_scale is not None else None
+        out = ops.conv2d(y, P[pre + ".res1"], residual=x, res_t=cfg.res_balance, clip=256.0, reflect_w=True, out2=twin,
+                         out2_scale=twin_scale if twin_scale is not None else 1.0)
         return out, twin
 
     @torch.no_grad()
@@ -277,27 +295,30 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
             emb = emb.to(dt).float()            # the reference casts emb to bfloat16 before the emb_linear layers (:305)
         emb2 = emb.repeat_interleave(2, dim=0).contiguous()
         cs = self._emb_scales(emb2)
-        # ---- encoder / decoder.  Twins (mp_silu of a block output) are written where the next block reads one: the decoder
-        # blocks without a skip input (in0 / in1 / up); blocks with a skip get theirs from the mp_cat pass.
+        # ---- encoder / decoder.  Every tensor is written once raw and once as the activated twin its 3x3 consumer reads:
+        # encoder outputs as mp_silu(wb * skip) for the decoder block that concatenates them, decoder outputs as mp_silu(x) or
+        # mp_silu(wa * x) for the next block.
+        cat = self._cat_plan()
+        skip_scale = {idx: wb for (_, _, _, wb, idx) in cat.values()}
         enc_names = [n for n in self.enc if n != "conv_in"]
         dec_names = list(self.dec)
-        x = ops.conv2d(x0, P["conv_in"], src1=x0, swap_src1=True, reflect_w=True)
-        skips = [x]
-        x_act = None
-        for i, name in enumerate(enc_names):
-            last = i == len(enc_names) - 1
-            x, x_act = self._block(P, "enc." + name, self.enc[name], x, None, cs["enc." + name], want_twin=last and "layer" not in dec_names[0])
+        tw0 = torch.empty(B * 2, H, W, self.enc["conv_in"].out_channels, dtype=dt, device=dev)
+        x = ops.conv2d(x0, P["conv_in"], src1=x0, swap_src1=True, reflect_w=True, out2=tw0, out2_scale=skip_scale[0])
+        skips, skip_acts = [x], [tw0]
+        for name in enc_names:
+            x, tw = self._block(P, "enc." + name, self.enc[name], x, None, cs["enc." + name], twin_scale=skip_scale[len(skips)])
             skips.append(x)
+            skip_acts.append(tw)
+        # the last encoder output is also the first decoder block's input: that block reads the unit-scale twin
+        x_act = ops.silu_scale_fwd(x, None, 1.0)
         for i, name in enumerate(dec_names):
-            blk = self.dec[name]
-            nxt = dec_names[i + 1] if i + 1 < len(dec_names) else None
-            want = nxt is not None and "layer" not in nxt
-            if "layer" in name:
-                sk = skips.pop()
-                wa, wb = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
-                x, x_act = self._block(P, "dec." + name, blk, x, None, cs["dec." + name], sk, wa, wb, want_twin=want)
+            pre = "dec." + name
+            nxt = "dec." + dec_names[i + 1] if i + 1 < len(dec_names) else None
+            tws = None if nxt is None else (cat[nxt][2] if nxt in cat else 1.0)
+            if pre in cat:
+                x, x_act = self._block(P, pre, self.dec[name], x, x_act, cs[pre], skips.pop(), skip_acts.pop(), twin_scale=tws)
             else:
-                x, x_act = self._block(P, "dec." + name, blk, x, x_act, cs["dec." + name], want_twin=want)
+                x, x_act = self._block(P, pre, self.dec[name], x, x_act, cs[pre], twin_scale=tws)
         y8 = ops.conv2d(x, P["conv_out"], src1=x, swap_src1=True, reflect_w=True)
         out = torch.empty(B, 2, H, W, dtype=torch.float32, device=dev)
         check(lib().ddx_ddec_output_combine(ptr(y8), y8.shape[-1], ptr(x_in), ptr(sig), ptr(out), B, 2 * H * W, cfg.sigma_data, dtype_code(dt),

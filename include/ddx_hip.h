@@ -94,7 +94,10 @@ enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1,
        /* flag, OR-ed in: src1 is read from the pair-swapped image (index b ^ 1; B even) -- the second depth tap of a (2,k,k)
         * MPConv3D on a stereo pair folded into the batch (modules/daes/dae_edm2_d3.py:62-84: the reflected depth row of a depth
         * of two IS the other slice), without materialising the swapped copy */
-       DDX_PAD_SWAP_SRC1 = 2 };
+       DDX_PAD_SWAP_SRC1 = 2,
+       /* flag: the input is the 4-part concatenation [src0 | src1 | src0' | src1'] (' = image b ^ 1), 2 * (C0 + C1) channels: both
+        * depth taps of a (2,k,k) MPConv3D over an mp_cat operand that is never materialised */
+       DDX_PAD_SWAP_PAIRED = 4 };
 
 typedef struct {
   const void* src0;         /* NHWC [B][sH][sW][C0] */

@@ -543,6 +543,30 @@ def test_conv_swap_src1(path, dtype, ks, up):
         ops.conv2d(xn[:3].contiguous(), pw, src1=xn[:3].contiguous(), swap_src1=True, path=path)
 
 
+@pytest.mark.parametrize("path,dtype", [("direct", torch.float32), ("mfma", torch.float32), ("mfma", torch.bfloat16), ("dma", torch.bfloat16)])
+def test_conv_swap_paired(path, dtype):
+    """DDX_PAD_SWAP_PAIRED: input [src0 | src1 | src0' | src1'] (' = image b ^ 1) against a conv over the explicit concatenation:
+    both depth taps of the decoder's (2,1,1) skip conv over an mp_cat operand that is never materialised."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(101)
+    B, H, W, C0, C1, Cout = 4, 12, 40, 64, 32, 64
+    a = _round(torch.randn(B, C0, H, W, generator=g), dtype)
+    b = _round(torch.randn(B, C1, H, W, generator=g), dtype)
+    w = torch.randn(Cout, 2 * (C0 + C1), 1, 1, generator=g)
+    wp_ref = O.prepared_weight(w)
+    if dtype == torch.bfloat16:
+        wp_ref = _round(wp_ref, dtype)
+    sw = lambda t: t.reshape(B // 2, 2, *t.shape[1:]).flip(1).reshape(t.shape)
+    ref = torch.nn.functional.conv2d(torch.cat([a, b, sw(a), sw(b)], dim=1), wp_ref)
+    pw = ops.wprep(w.cuda(), 1, dtype)
+    out = ops.conv2d(to_nhwc(a, dtype), pw, src1=to_nhwc(b, dtype), swap_paired=True, path=path)
+    torch.cuda.synchronize()
+    e = rel_l2(to_nchw(out), ref)
+    assert e < TOL[dtype], (path, e)
+    ref_noswap = torch.nn.functional.conv2d(torch.cat([a, b, a, b], dim=1), wp_ref)
+    assert rel_l2(to_nchw(out), ref_noswap) > 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cat2_act(dtype):
     """ddx_cat2_act: mp_cat materialised with its mp_silu'd twin in one pass."""

@@ -33,6 +33,11 @@ CASES = {
     "L1 128->64 x8 res": (4, 16, 344, 1024, 0, 512, 8, 0, True, False, False),
     "L1 96->128 x8": (4, 16, 344, 768, 0, 1024, 8, 0, False, True, False),
     "ragged 30x70 64->64": (2, 30, 70, 128, 0, 128, 2, 0, True, False, True),
+    "ddec L0 32->32 act": (2, 256, 5504, 32, 0, 32, 1, 0, False, True, False),
+    "ddec L0 32->32 res": (2, 256, 5504, 32, 0, 32, 1, 0, True, False, False),
+    "ddec L0 64->32 act": (2, 256, 5504, 64, 0, 32, 1, 0, False, True, False),
+    "ddec L1 64->64 res": (2, 128, 2752, 64, 0, 64, 1, 0, True, False, False),
+    "ddec L2 96->96 act": (2, 64, 1376, 96, 0, 96, 1, 0, False, True, False),
     "B8 L0 64->64 x8": (8, 32, 688, 512, 0, 512, 8, 0, True, False, False),
 }
 
