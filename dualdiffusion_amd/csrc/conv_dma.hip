@@ -65,7 +65,7 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
   static constexpr int EPI_WAVE = 32 * 36 * 4;  // one 32 pixel x 32 channel fp32 patch, rows padded to 36 floats
   // 8-fragment waves in 4-wave workgroups: two workgroups per CU only fit when the epilogue patches reuse stage 1 (idle between
   // the last matrix phase of a unit and the second stage of the next one) -- at the price of one barrier before the epilogue
-  static constexpr bool EPI_OVERLAY = MF > 2 && NW == 4;
+  static constexpr bool EPI_OVERLAY = NF * MF > 4 && NW == 4;
   static constexpr int SMEM = NST * STAGE + (EPI_OVERLAY ? 0 : NW * EPI_WAVE);
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
   static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
   constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
   constexpr int KSTEPS = SK / 16;
-  constexpr bool LATE_RES = NF > 2 || MF > 2;  // too many fragments to hold every residual row during the last matrix phase
+  constexpr bool LATE_RES = NF * MF > 4;  // too many fragments to hold every residual row during the last matrix phase
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         }
     };
     if constexpr (!LATE_RES) epilogue_offsets();  // needed by the residual prefetch inside the last matrix phase
-    u32x4 rres[NF > 2 ? 2 : (MF > 2 ? 1 : NF)][MF][2];
-    auto rslot = [](int i) { return NF > 2 ? (i & 1) : (MF > 2 ? 0 : i); };
+    u32x4 rres[LATE_RES ? (NF > 2 ? 2 : 1) : NF][MF][2];
+    auto rslot = [](int i) { return LATE_RES ? (NF > 2 ? (i & 1) : 0) : i; };
 
     {
       // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
@@ -580,7 +580,7 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   static_assert(GEO::SMEM <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
   static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, (MF > 2 ? 0 : 1), EB, WM, MF>;
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, (NF * MF > 4 ? 0 : 1), EB, WM, MF>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::SMEM) != hipSuccess)
@@ -702,21 +702,23 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     if (ksize == 3) return narrow ? launch_dma_t<3, 16, 1, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 1>(p, s);
     return narrow ? launch_dma_t<1, 32, 1, 1, 1>(p, s) : launch_dma_t<1, 32, 2, 1, 1>(p, s);
   }
-  if (ksize == 3 && p.Ng > 32) {
-    // 512 pixel x 64 channel units, 4 waves with 4 x 2 fragments each: 6 fragment reads per 8 MFMAs instead of 4 per 4 (the
-    // matrix phase of the 4-fragment variant is bound by LDS read bandwidth), and the weight slices are staged once per 512
-    // pixels instead of once per 256.  Still two workgroups per CU (epilogue patches overlaid on stage 1).
-    static const int big_knob = std::getenv("DDX_DMA_BIG") ? atoi(std::getenv("DDX_DMA_BIG")) : 0;  // 0 never, 1 rule, 2 wherever it fits
+  if (ksize == 3) {
+    // 512-pixel units (4 waves x 4 pixel fragments): twice the matrix work per DMA round trip of a K-stage and the weight
+    // slices staged once per 512 pixels.  With 32-channel tiles (4 fragments per wave, no register pressure) this is the
+    // candidate for layers with few K-stages per unit -- measured 10-40 % slower than the 256-pixel units for both channel
+    // widths, kept behind the knob.
+    static const int big_knob = std::getenv("DDX_DMA_BIG") ? atoi(std::getenv("DDX_DMA_BIG")) : 0;  // experiment knob: 2 = wherever it fits
     using BIG = DmaGeom<3, 16, 2, 1, 4, 4>;
     int bth = 0, btw = 0; double butil = 0;
     if (big_knob && dma_tile(p, 3, &bth, &btw, &butil, BIG::BM, BIG::AROWS)) {
-      const long units = (long)p.B * ceil_div(p.H, bth) * ceil_div(p.W, btw) * p.G * ceil_div(p.Ng, BIG::BN);
-      if (big_knob == 2 || (butil >= 0.9 && units >= 640)) {
+      const int bn = p.Ng <= 32 ? 32 : 64;
+      const long units = (long)p.B * ceil_div(p.H, bth) * ceil_div(p.W, btw) * p.G * ceil_div(p.Ng, bn);
+      if (big_knob == 2 && units > 0) {   // (no automatic rule: both channel widths measured slower than the 256-pixel units)
         p.TH = bth; p.TW = btw;
         p.tiles_h = ceil_div(p.H, bth); p.tiles_w = ceil_div(p.W, btw);
         p.arows_alloc = (bth + 2) * (btw + 2);
         p.inv_TWP = 1.0f / (float)(btw + 2);
-        return launch_dma_t<3, 16, 2, 1, 0, 4, 4>(p, s);
+        return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 4>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 4>(p, s);
       }
     }
   }
