@@ -19,7 +19,7 @@ RESAMPLE_KEEP, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
 RESAMPLE_UP_BWD, RESAMPLE_DOWN_BWD = 3, 4
 PRO_NONE, PRO_SILU, PRO_SCALE, PRO_SCALE_SILU = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT_W, PAD_SWAP_SRC1, PAD_SWAP_PAIRED = 0, 1, 2, 4
-EPI_STORE, EPI_MPSUM = 0, 1
+EPI_STORE, EPI_MPSUM, EPI_PIXELNORM = 0, 1, 3
 
 
 class DDXError(RuntimeError):

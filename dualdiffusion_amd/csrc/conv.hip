@@ -178,10 +178,17 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
 extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   if (!dp) return set_error(DDX_ERR_ARG, "conv: null descriptor");
   const ddx_conv_desc d = *dp;
-  if (d.epilogue != DDX_EPI_STORE && d.epilogue != DDX_EPI_MPSUM) return set_error(DDX_ERR_ARG, "conv: epilogue");
+  if (d.epilogue != DDX_EPI_STORE && d.epilogue != DDX_EPI_MPSUM && d.epilogue != DDX_EPI_PIXELNORM) return set_error(DDX_ERR_ARG, "conv: epilogue");
+  if (d.epilogue == DDX_EPI_PIXELNORM && (d.residual || d.out_act || d.out_scale || !(d.res_t > 0.f)))
+    return set_error(DDX_ERR_ARG, "conv: the pixel-norm epilogue takes eps in res_t and no residual / output activation");
   ConvParams p{};
   if (int rc = conv_fill(d, &p)) return rc;
   const int ks = d.ksize, dt = d.dtype;
+  if (d.epilogue == DDX_EPI_PIXELNORM) {
+    p.norm_eps = d.res_t;
+    if (d.force_direct == 1 || d.force_direct == 2 || d.force_direct >= 16 || !conv_dma_supported(p, ks, dt, /*any_size=*/true))
+      return set_error(DDX_ERR_UNSUPPORTED, "conv: the pixel-norm epilogue is built for the LDS-DMA kernel (one group, Cout <= 64)");
+  }
   // d.force_direct selects the kernel: 0 = automatic, 1 = scalar reference kernel, 2 = register-staged MFMA kernel,
   // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)
   // >= 16: the register-staged kernel with tile / split-K configuration (force_direct - 16), see ConvParams::force_cfg
@@ -190,7 +197,8 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   static const bool dma_enabled = []() { const char* e = std::getenv("DDX_CONV_DMA"); return !e || e[0] != '0'; }();
   if (d.force_direct == 3 && !conv_dma_supported(p, ks, dt, /*any_size=*/true))
     return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the LDS-DMA kernel");
-  const bool dma = d.force_direct == 3 || (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
+  const bool dma = d.force_direct == 3 || d.epilogue == DDX_EPI_PIXELNORM ||
+                   (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
   if (d.force_direct >= 16 && !mfma) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the register-staged MFMA kernel");
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double es = (double)dtype_size(dt);

@@ -405,6 +405,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
     if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
     if constexpr (GEO::EPI_OVERLAY) __builtin_amdgcn_s_barrier();  // every wave is done reading stage 1: the patches live there
+    if constexpr (!EB && WN == 1 && NF <= 2 && MF <= 2) {
+      if (p.epilogue == DDX_EPI_PIXELNORM) {
+        // normalize(y, dim = channels) on the accumulators: a lane holds 16 of the 32 channels of pixel (lane & 31) per fragment,
+        // lane ^ 32 the other 16; channel columns past Cout carry zero weights
+        const float inv_sqrt_c = __builtin_amdgcn_rsqf((float)p.Cout);
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ss = fmaf(acc[i][j][r], acc[i][j][r], ss);
+          ss += __shfl_xor(ss, 32, 64);
+          const float inv = 1.0f / (p.norm_eps + sqrtf(ss) * inv_sqrt_c);
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       if (LATE_RES && p.epilogue == DDX_EPI_MPSUM) {  // wide tiles: no registers to prefetch all residual rows, load per column
@@ -664,6 +685,7 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   if (p.Ng % 8 || p.Cout % 8) return false;
   if (p.epilogue == DDX_EPI_MPSUM && p.out_act && p.out_cs && (p.Cout % 4)) return false;
   if (p.epilogue == DDX_EPI_SILU_BWD && dma_bwd_bn(p) == 0) return false;  // every channel tile must lie in ONE part
+  if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 64)) return false;  // all output channels of a pixel in one wave's fragments
   if ((size_t)p.B * p.sH * p.sW >= (size_t)1 << 31) return false;
   int TH, TW; double util;
   if (!dma_tile(p, ksize, &TH, &TW, &util)) return false;

@@ -26,6 +26,7 @@ struct ConvParams {
   int out_act;
   float out2_scale;
   int reflect_w;        // columns outside the image are mirrored (ReflectionPad on W) instead of zero
+  float norm_eps;       // DDX_EPI_PIXELNORM: eps of normalize()
   int swap1;            // src1 is read from image b ^ 1 (DDX_PAD_SWAP_SRC1)
   int paired;           // input = [src0 | src1 | src0' | src1'], ' = image b ^ 1 (DDX_PAD_SWAP_PAIRED); Cin = 2 * (C0 + C1)
   // DDX_EPI_SILU_BWD (data-gradient conv fused with the backward of the producer-side activation; `res` = y of the first part)

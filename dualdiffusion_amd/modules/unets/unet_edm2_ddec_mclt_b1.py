@@ -244,9 +244,15 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
             N, H, W, Cn = x.shape
             x = ops.resample2d(x, torch.empty((N, H // 2, W // 2, Cn), dtype=x.dtype, device=x.device), RESAMPLE_DOWN)
         if blk.flavor == "enc":
-            xs = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True)
-            x_act = torch.empty_like(xs)
-            x = ops.pixelnorm(xs, out_act=x_act)
+            Cn, Co = x.shape[-1], blk.out_channels
+            if x.dtype == torch.bfloat16 and Co <= 64 and Co % 8 == 0 and Cn % 32 == 0:
+                # pixel norm in the skip conv's epilogue (fp32 accumulators, all channels of a pixel in one wave), twin alongside
+                x_act = torch.empty(*x.shape[:-1], Co, dtype=x.dtype, device=x.device)
+                x = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True, pixelnorm_eps=1e-4, out2=x_act)
+            else:
+                xs = ops.conv2d(x, P[pre + ".skip"], src1=x, swap_src1=True)
+                x_act = torch.empty_like(xs)
+                x = ops.pixelnorm(xs, out_act=x_act)
             y = ops.conv2d(x_act, P[pre + ".res0"], reflect_w=True, out_act=True, out_scale=c)
         else:
             if x_act is None or (skip is not None and skip_act is None):

@@ -152,14 +152,15 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
-           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False) -> torch.Tensor:
+           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False, pixelnorm_eps: float = 0.0) -> torch.Tensor:
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | an integer force_direct code (16 + 3 * tile + k: one tile / split-K configuration of the register-staged kernel).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
     (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y)).
     swap_src1: src1 is read from the pair-swapped image (b ^ 1): second depth tap of a (2,k,k) conv on a folded stereo pair.
-    swap_paired: the input is [src0 | src1 | src0' | src1'] (' = image b ^ 1): both depth taps over a two-source (mp_cat) operand."""
+    swap_paired: the input is [src0 | src1 | src0' | src1'] (' = image b ^ 1): both depth taps over a two-source (mp_cat) operand.
+    pixelnorm_eps > 0: the stored output is normalize(y, dim=channels) (DDX_EPI_PIXELNORM; LDS-DMA kernel, one group, Cout <= 64)."""
     B, sH, sW, C0 = src0.shape
     if out_hw is None:
         out_hw = {L.RESAMPLE_KEEP: (sH, sW), L.RESAMPLE_UP: (sH * 2, sW * 2), L.RESAMPLE_DOWN: (sH // 2, sW // 2)}[resample]
@@ -169,8 +170,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
         out = torch.empty(B, H, W, pw.Cout, dtype=src0.dtype, device=src0.device)
     d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
                    B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
-                   prologue=prologue, epilogue=L.EPI_MPSUM if residual is not None else L.EPI_STORE, scale0=scale0, scale1=scale1,
-                   res_t=res_t, clip=clip, dtype=dtype_code(src0.dtype),
+                   prologue=prologue, epilogue=L.EPI_PIXELNORM if pixelnorm_eps > 0 else (L.EPI_MPSUM if residual is not None else L.EPI_STORE),
+                   scale0=scale0, scale1=scale1, res_t=pixelnorm_eps if pixelnorm_eps > 0 else res_t, clip=clip, dtype=dtype_code(src0.dtype),
                    force_direct=1 if force_direct else (path if isinstance(path, int) else _PATH_CODE[path]),
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=(L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO) | (L.PAD_SWAP_SRC1 if swap_src1 else 0) | (L.PAD_SWAP_PAIRED if swap_paired else 0),

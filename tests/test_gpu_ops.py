@@ -567,6 +567,36 @@ def test_conv_swap_paired(path, dtype):
     assert rel_l2(to_nchw(out), ref_noswap) > 1e-2
 
 
+@pytest.mark.parametrize("Cin,Cout,ks", [(64, 32, 1), (64, 64, 1), (128, 48, 1), (64, 64, 3)])
+def test_conv_pixelnorm_epilogue(Cin, Cout, ks):
+    """DDX_EPI_PIXELNORM: normalize(conv(x), dim=channels) in the LDS-DMA kernel's epilogue (+ activated twin) against the conv
+    followed by torch pixel norm; unsupported layouts fail loudly."""
+    ops = _ops()
+    from dualdiffusion_amd._lib import DDXError
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(7 + Cout)
+    B, H, W = 2, 19, 70
+    x = _round(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g)
+    wp_ref = _round(O.prepared_weight(w), dtype)
+    y = torch.nn.functional.conv2d(x, wp_ref, padding=ks // 2)
+    nrm = 1e-4 + y.norm(dim=1, keepdim=True) / Cout ** 0.5
+    ref = y / nrm
+    pw = ops.wprep(w.cuda(), 1, dtype)
+    xn = to_nhwc(x, dtype)
+    twin = torch.empty(B, H, W, Cout, dtype=dtype, device="cuda")
+    out = ops.conv2d(xn, pw, pixelnorm_eps=1e-4, out2=twin)
+    torch.cuda.synchronize()
+    assert rel_l2(to_nchw(out), ref) < TOL[dtype]
+    assert rel_l2(to_nchw(twin), torch.nn.functional.silu(ref) / 0.596) < 2 * TOL[dtype]
+    rms = to_nchw(out).float().square().mean(dim=1).sqrt()
+    assert float((rms - 1).abs().max()) < 2e-2
+    with pytest.raises(DDXError):       # more output channels than one channel tile
+        ops.conv2d(xn, ops.wprep(torch.randn(128, Cin, ks, ks).cuda(), 1, dtype), pixelnorm_eps=1e-4)
+    with pytest.raises(DDXError):       # fp32: register-staged kernel only
+        ops.conv2d(to_nhwc(x, torch.float32), ops.wprep(w.cuda(), 1, torch.float32), pixelnorm_eps=1e-4)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cat2_act(dtype):
     """ddx_cat2_act: mp_cat materialised with its mp_silu'd twin in one pass."""
