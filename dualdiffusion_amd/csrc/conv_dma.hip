@@ -14,6 +14,7 @@
 //     workgroup barrier) and stores 16 bytes per lane on NHWC rows.
 // One workgroup = 4 waves = 256 output pixels x 64 output channels; two workgroups per CU overlap each other.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -44,6 +45,19 @@ __device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x +
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int kBM = 256;
+
+// Phase timing (build with -DDDX_DMA_TRACE, tools/dma_trace.sh): every wave accumulates shader-clock cycles per pipeline phase
+// (DMA wait, barrier, DMA issue incl. next-unit setup, matrix phase, epilogue, per-unit setup) and adds them to g_trace at exit;
+// DDX_DMA_TRACE=1 in the environment prints the per-wave means after each launch.  The s_memtime round trips inflate the
+// kernel by ~20 %; the split between the phases is what the numbers are for.
+#ifdef DDX_DMA_TRACE
+__device__ unsigned long long g_trace[8];
+#define DDX_TR_INIT long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64()
+#define DDX_TR(k) do { const long long now_ = clock64(); tr[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define DDX_TR_INIT do {} while (0)
+#define DDX_TR(k) do {} while (0)
+#endif
 
 // WM waves along the pixels (MF fragments of 32 pixels each) x WN waves along the output channels (NF fragments of 32 channels)
 template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom {
@@ -322,8 +336,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  DDX_TR_INIT;
   if (live(iu)) issue_setup(iu);
   issue_next(S0{});
+  DDX_TR(2);
   for (int u = blockIdx.x; live(u); u += gridDim.x) {
     const Unit t = it;  // the issue cursor is still on this unit (it moves on during the last stage)
 #pragma unroll
@@ -380,13 +396,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     {
       // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
       for (int q = 0; q < nk; q += 2) {
+        DDX_TR(5);
         wait_vmcnt<0>();
+        DDX_TR(0);
         __builtin_amdgcn_s_barrier();  // this stage landed for every wave; everyone is done reading the other one
+        DDX_TR(1);
         issue_next(S1{});
+        DDX_TR(2);
         compute(S0{});
+        DDX_TR(3);
         wait_vmcnt<0>();
+        DDX_TR(0);
         __builtin_amdgcn_s_barrier();
+        DDX_TR(1);
         issue_next(S0{});
+        DDX_TR(2);
         if (!LATE_RES && q + 2 == nk && (EB || p.epilogue == DDX_EPI_MPSUM)) {  // residual (EB: y) rows ride along with the last matrix phase
 #pragma unroll
           for (int i = 0; i < NF; ++i)
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
               }
         }
         compute(S1{});
+        DDX_TR(3);
       }
     }
 
@@ -541,6 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
       }
     }
+    DDX_TR(4);
     if constexpr (EB) {
       if (p.bwd_ws) {
         // channel sums of this wave's 64 pixels: the 16 lanes that share (lane & 3) hold the same 8*NF channels.  Transposing
@@ -574,6 +600,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
       }
     }
   }
+#ifdef DDX_DMA_TRACE
+  if (lane == 0) {
+    for (int k = 0; k < 6; ++k) atomicAdd(&g_trace[k], (unsigned long long)tr[k]);
+    atomicAdd(&g_trace[6], 1ull);
+  }
+#endif
 }
 
 // dc[b][c] += scale * sum over the (pixel tile, wave) partial rows of image b written by the EB epilogue.
@@ -637,6 +669,17 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
     hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
                        p.B * tpi * GEO::NW, GEO::BN, ntile_n, p.Ng, p.Cout, p.bwd_s0);
   }
+#ifdef DDX_DMA_TRACE
+  if (getenv("DDX_DMA_TRACE")) {
+    unsigned long long h[8] = {0}, z[8] = {0};
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) == hipSuccess && h[6]) {
+      const double w = (double)h[6];
+      fprintf(stderr, "[dma trace] %d units, cycles per wave: dma-wait %.0f barrier %.0f dma-issue %.0f matrix %.0f epilogue %.0f unit-setup %.0f\n",
+              (int)total, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z));
+  }
+#endif
   return check_launch("conv_dma");
 }
 
