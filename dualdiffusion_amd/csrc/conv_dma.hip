@@ -80,7 +80,10 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
   // 8-fragment waves in 4-wave workgroups: two workgroups per CU only fit when the epilogue patches reuse stage 1 (idle between
   // the last matrix phase of a unit and the second stage of the next one) -- at the price of one barrier before the epilogue
   static constexpr bool EPI_OVERLAY = NF * MF > 4 && NW == 4;
-  static constexpr int SMEM = NST * STAGE + (EPI_OVERLAY ? 0 : NW * EPI_WAVE);
+  // output channel scales of the unit's BN channels, staged by DMA with the unit's first stage (two 1-KiB DMA targets, units
+  // alternate): a global load inside the epilogue would wait behind the next unit's first stage, which is in flight there
+  static constexpr int CS_OFF = NST * STAGE + (EPI_OVERLAY ? 0 : NW * EPI_WAVE);
+  static constexpr int SMEM = CS_OFF + 2048;
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
   static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
 };
@@ -195,10 +198,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   const rsrc_t rs0 = make_rsrc(p.src0, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
   const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
   const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.G * p.nchunk * TAPS * p.NgP * p.CK * 2);
+  const rsrc_t rscs = make_rsrc(p.out_cs ? (const void*)p.out_cs : p.wp, p.out_cs ? (size_t)p.B * p.Cout * 4 : 0);
+  constexpr bool CS_LDS = !EB && NF <= 2 && MF <= 2;   // (the 8-fragment variants have no registers to spare for it)
+  const bool cs_lds = CS_LDS && p.out_cs != nullptr;
 
   // issue cursor: (unit, stage) of the next DMA batch.  Per lane only byte offsets inside the tensors are kept; the
   // stage (input-channel) advance is a scalar offset, so one batch costs one m0 write + one buffer_load per piece.
-  int iu = blockIdx.x, iq = 0, isrc = -1;
+  int iu = blockIdx.x, iq = 0, isrc = -1, iunit = 0;
   Unit it{};
   int apix[AI], avoff[AI], bvoff[BI];
   [[maybe_unused]] int aslot_u[DMA_TABLE ? 1 : AI];
@@ -250,6 +256,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
       const int piece = wave + NW * i;
       if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
     }
+    if (cs_lds && iq == 0 && wave == 0)   // (rides with the unit's first stage: landed at that stage's barrier)
+      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((it.b * p.Cout + it.g * p.Ng + it.n0) * 4), smem + GEO::CS_OFF + (iunit & 1) * 1024);
     const int k0 = iq * SK;
     const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
 #pragma unroll
@@ -259,6 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     }
     if (++iq == nk) {
       iq = 0;
+      ++iunit;
       iu += gridDim.x;
       if (live(iu)) issue_setup(iu);
     }
@@ -340,7 +349,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   if (live(iu)) issue_setup(iu);
   issue_next(S0{});
   DDX_TR(2);
+  int cunit = -1;
   for (int u = blockIdx.x; live(u); u += gridDim.x) {
+    ++cunit;
+    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + GEO::CS_OFF + (cunit & 1) * 1024);
     const Unit t = it;  // the issue cursor is still on this unit (it moves on during the last stage)
 #pragma unroll
     for (int i = 0; i < NF; ++i)
@@ -533,7 +545,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
           if (p.out2) {
             Vec16<bf16> tv;
             if (p.out_cs && !p.out_act) {  // raw main output: the channel scale belongs to the twin (training forward)
-              const float* csp = p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
+              const float* csp = CS_LDS ? cs_l + (wn * NF + i) * 32 + c8   // (LDS copy of this unit's scales)
+                                        : p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
               const f32x4 ca = *reinterpret_cast<const f32x4*>(csp);
               const f32x4 cb = *reinterpret_cast<const f32x4*>(csp + 4);
 #pragma unroll
@@ -549,7 +562,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
           }
           if (p.out_act) {
             if (p.out_cs) {
-              const float* csp = p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
+              const float* csp = CS_LDS ? cs_l + (wn * NF + i) * 32 + c8   // (LDS copy of this unit's scales)
+                                        : p.out_cs + (size_t)t.b * p.Cout + t.g * p.Ng + nch;
               const f32x4 ca = *reinterpret_cast<const f32x4*>(csp);
               const f32x4 cb = *reinterpret_cast<const f32x4*>(csp + 4);
 #pragma unroll
