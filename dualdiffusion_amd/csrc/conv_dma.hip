@@ -51,8 +51,8 @@ constexpr int kBM = 256;
 // DDX_DMA_TRACE=1 in the environment prints the per-wave means after each launch.  The s_memtime round trips inflate the
 // kernel by ~20 %; the split between the phases is what the numbers are for.
 #ifdef DDX_DMA_TRACE
-__device__ unsigned long long g_trace[8];
-#define DDX_TR_INIT long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64()
+__device__ unsigned long long g_trace[12];
+#define DDX_TR_INIT long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64()
 #define DDX_TR(k) do { const long long now_ = clock64(); tr[k] += now_ - tlast; tlast = now_; } while (0)
 #else
 #define DDX_TR_INIT do {} while (0)
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
           *reinterpret_cast<f32x4*>(sE + l31 * 36 + 8 * qd + 4 * khalf) = y4;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave: only the compiler must not reorder
+        DDX_TR(6);   // (epilogue sub-phases: 6 = accumulators -> LDS patch, 7 = patch rows -> registers + math, 8 = stores)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int idx = lane + 64 * tt;
@@ -575,7 +576,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
           Vec16<bf16> ov;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov.set(e, y[e]);
+          DDX_TR(7);
           *reinterpret_cast<bf16x8*>(out + off) = ov.v;
+          DDX_TR(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
       }
@@ -616,8 +619,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   }
 #ifdef DDX_DMA_TRACE
   if (lane == 0) {
-    for (int k = 0; k < 6; ++k) atomicAdd(&g_trace[k], (unsigned long long)tr[k]);
-    atomicAdd(&g_trace[6], 1ull);
+    for (int k = 0; k < 9; ++k) atomicAdd(&g_trace[k], (unsigned long long)tr[k]);
+    atomicAdd(&g_trace[9], 1ull);
   }
 #endif
 }
@@ -685,11 +688,12 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   }
 #ifdef DDX_DMA_TRACE
   if (getenv("DDX_DMA_TRACE")) {
-    unsigned long long h[8] = {0}, z[8] = {0};
-    if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) == hipSuccess && h[6]) {
-      const double w = (double)h[6];
-      fprintf(stderr, "[dma trace] %d units, cycles per wave: dma-wait %.0f barrier %.0f dma-issue %.0f matrix %.0f epilogue %.0f unit-setup %.0f\n",
-              (int)total, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w);
+    unsigned long long h[12] = {0}, z[12] = {0};
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) == hipSuccess && h[9]) {
+      const double w = (double)h[9];
+      fprintf(stderr, "[dma trace] %d units, cycles per wave: dma-wait %.0f barrier %.0f dma-issue %.0f matrix %.0f epilogue %.0f (patch write %.0f, "
+              "read + math %.0f, stores %.0f, rest %.0f) unit-setup %.0f\n",
+              (int)total, h[0] / w, h[1] / w, h[2] / w, h[3] / w, (h[4] + h[6] + h[7] + h[8]) / w, h[6] / w, h[7] / w, h[8] / w, h[4] / w, h[5] / w);
     }
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z));
   }
