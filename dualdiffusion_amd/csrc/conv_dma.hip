@@ -33,7 +33,13 @@ constexpr int kOobOffset = 0x7fffff00;  // voffset of a lane that must read zero
 
 // 16 bytes per lane, global -> LDS (lane-linear destination at l).  Raw buffer addressing: the address is
 // base + voff + soff and lanes with voff + soff >= num_records write zeros -- that is the conv zero padding.
+// Ablation builds for timing experiments (tools/dma_ablate.sh; the results are WRONG): -DDDX_ABL_NODMA issues no DMA,
+// -DDDX_ABL_NOMATRIX skips the fragment reads and MFMAs, -DDDX_ABL_NOSTORE skips the epilogue's global stores.
 __device__ __forceinline__ void dma16(rsrc_t rs, int voff, int soff, void* l) {
+#ifdef DDX_ABL_NODMA
+  (void)rs; (void)voff; (void)soff; (void)l;
+  return;
+#endif
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
 }
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, size_t bytes) {
@@ -94,7 +100,8 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
 // starts half a unit late so that one workgroup's memory phases (epilogue stores, first-stage latency) fall into the
 // other's matrix phase instead of both doing the same thing at the same time.
 // EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
-template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2>
+// DEEP = 1: activation ring of three stages and weight ring of two (see the DEEP main loop)
+template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd, const int tile_order) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
@@ -273,6 +280,87 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     }
   };
 
+  // ---- DEEP pipeline: the activation stages (HBM latency) run TWO ahead in a ring of three slots, the weight stages (L2) one
+  // ahead in a ring of two.  Timing ablations (tools/dma_ablate.sh) show why: with one stage in flight per workgroup the DMA
+  // side alone takes stages x latency (44 us for 64->64 x8) -- as long as the matrix side alone (50 us) -- and the two overlap
+  // only to 72 us.  LDS: 3 x A + 2 x B (+ separate epilogue patches for 32-channel tiles; 64-channel tiles overlay the idle
+  // weight slot) + channel scales = 71 KB, still two workgroups per CU.  The A cursor is (iu, iq, it, ...) above; the weights
+  // have their own cursor.  One barrier per stage as before; the wait leaves exactly the younger activation batch in flight.
+  constexpr int D_BOFF = 3 * GEO::A_BYTES;                                             // weight slots
+  constexpr int D_EOFF = D_BOFF + 2 * GEO::B_BYTES;                                    // epilogue patches (32-channel tiles)
+  constexpr bool D_OVERLAY = NW * GEO::EPI_WAVE <= GEO::B_BYTES;                       // patches fit a weight slot
+  constexpr int D_CSOFF = D_EOFF + (D_OVERLAY ? 0 : NW * GEO::EPI_WAVE);
+  constexpr int CS_BASE = DEEP ? D_CSOFF : GEO::CS_OFF;
+  int iuB = blockIdx.x, iqB = 0, iunitB = 0;
+  Unit itB{};
+  [[maybe_unused]] int bvoffB[BI];
+  auto setup_B = [&](int u) {
+    itB = decode(u);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int tp, nn, sl;
+      if constexpr (DMA_TABLE) { tp = btap[i]; nn = bn[i]; sl = bslot[i]; }
+      else b_row(i, lrow, tp, nn, sl);
+      const int n = min(itB.n0 + nn, p.NgP - 1);
+      bvoffB[i] = (((tp * p.NgP + n) << ck_shift) + sl) * 2;
+    }
+  };
+  auto issue_B = [&](int slot) {
+    if (!live(iuB)) return;
+    char* sb = smem + D_BOFF + slot * GEO::B_BYTES;
+    if (cs_lds && iqB == 0 && wave == 0)
+      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((itB.b * p.Cout + itB.g * p.Ng + itB.n0) * 4), smem + CS_BASE + (iunitB & 1) * 1024);
+    const int k0 = iqB * SK;
+    const int soff_b = ((((itB.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int piece = wave + NW * i;
+      if (piece < GEO::BPIECES) dma16(rsw, bvoffB[i], soff_b, sb + piece * 1024);
+    }
+    if (++iqB == nk) {
+      iqB = 0;
+      ++iunitB;
+      iuB += gridDim.x;
+      if (live(iuB)) setup_B(iuB);
+    }
+  };
+  auto issue_A = [&](int slot) -> bool {
+    if (!live(iu)) return false;
+    char* sbase = smem + slot * GEO::A_BYTES;
+    int cabs = it.g * p.Cg + iq * SK;
+    const int half = p.C0 + p.C1;
+    const int swapped = (p.paired && cabs >= half) ? 1 : 0;
+    if (swapped) cabs -= half;
+    const int src_id = cabs >= p.C0 ? 1 : 0;
+    if (src_id + 2 * swapped != isrc) {
+      isrc = src_id + 2 * swapped;
+      const int cs2 = (src_id ? p.C1 : p.C0) * 2;
+      const int dpix = (swapped || (src_id && p.swap1)) ? ((it.b ^ 1) - it.b) * p.sH * p.sW : 0;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+    }
+    const int soff_a = (src_id ? cabs - p.C0 : cabs) * 2;
+    const rsrc_t rsa = src_id ? rs1 : rs0;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int piece = wave + NW * i;
+      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
+    }
+    if (++iq == nk) {
+      iq = 0;
+      iu += gridDim.x;
+      if (live(iu)) issue_setup(iu);
+    }
+    return true;
+  };
+  // (waves 0 .. APIECES % NW - 1 move one activation piece more than the others: the younger batch this wave may leave in flight)
+  auto wait_stage = [&](bool younger_a) {
+    if (!younger_a) { wait_vmcnt<0>(); return; }
+    constexpr int REM = GEO::APIECES % NW;
+    if (REM == 0 || wave < REM) wait_vmcnt<AI>();
+    else wait_vmcnt<(AI > 1 ? AI - 1 : 0)>();
+  };
+
   // ---- fragment read addresses (bytes inside a stage); the tile geometry is the same for every unit
   // (MF > 2: only the halo row of tap 0 is kept per fragment and the tap offsets are added at the read -- 5 VALU per read
   // against 4 * 9 address registers the 8-fragment variant does not have)
@@ -307,14 +395,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   const int boff_r = l31 * RB;
 
   f32x16 acc[NF][MF];
-  auto compute = [&](auto stage) {  // compile-time stage: every LDS address is register + immediate
-    const char* sA = smem + (int)stage * GEO::STAGE;
-    const char* sB = sA + GEO::A_BYTES;
+  // matrix phase of one stage: activations at sA, weight slices at sB (compile-time offsets in the two-stage pipeline: every
+  // LDS address is then register + immediate)
+  auto compute_at = [&](const char* sA, const char* sB) {
+#ifdef DDX_ABL_NOMATRIX
+    (void)sA; (void)sB;
+    return;
+#endif
     constexpr int SLOTS = TAPS * KSTEPS;
     // fragments are read PD slots ahead of the MFMAs that consume them (register ring of PD+1 slots), so that one wave
     // alone keeps the matrix pipe fed while the other wave of its SIMD is in a memory phase
-    constexpr int RING = PD + 1;
-    bf16x8 wf[RING][NF], xf[RING][MF];
+    constexpr int FRING = PD + 1;
+    bf16x8 wf[FRING][NF], xf[FRING][MF];
     auto load_frags = [&](int slot, int buf) {
       const int tap = slot / KSTEPS, ks = slot % KSTEPS;
 #pragma unroll
@@ -325,11 +417,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         xf[buf][j] = *reinterpret_cast<const bf16x8*>(sA + (a_addr(j, tap) ^ (ks << 5)));
     };
 #pragma unroll
-    for (int s0 = 0; s0 < PD && s0 < SLOTS; ++s0) load_frags(s0, s0 % RING);
+    for (int s0 = 0; s0 < PD && s0 < SLOTS; ++s0) load_frags(s0, s0 % FRING);
 #pragma unroll
     for (int slot = 0; slot < SLOTS; ++slot) {
-      const int cur = slot % RING;
-      if (slot + PD < SLOTS) load_frags(slot + PD, (slot + PD) % RING);
+      const int cur = slot % FRING;
+      if (slot + PD < SLOTS) load_frags(slot + PD, (slot + PD) % FRING);
       __builtin_amdgcn_sched_barrier(0);  // keep the reads in front of the MFMAs of this slot
 #pragma unroll
       for (int i = 0; i < NF; ++i)
@@ -338,8 +430,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     }
   };
 
+  auto compute = [&](auto stage) {
+    compute_at(smem + (int)stage * GEO::STAGE, smem + (int)stage * GEO::STAGE + GEO::A_BYTES);
+  };
+
   static_assert(!GEO::EPI_OVERLAY || NW * GEO::EPI_WAVE <= GEO::STAGE, "epilogue patches overlay stage 1");
-  float* sE = reinterpret_cast<float*>(smem + (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE) + wave * GEO::EPI_WAVE);
+  float* sE = reinterpret_cast<float*>(smem + (DEEP ? D_EOFF : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE)) + wave * GEO::EPI_WAVE);
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
@@ -347,13 +443,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   using S1 = std::integral_constant<int, 1>;
   DDX_TR_INIT;
   if (live(iu)) issue_setup(iu);
-  issue_next(S0{});
+  [[maybe_unused]] bool a_ahead = false;   // DEEP: the activation batch after the next one is in flight
+  [[maybe_unused]] int gs = 0, sa = 0;     // DEEP: global stage counter of the compute side (weight slot gs & 1), gs % 3
+  if constexpr (DEEP) {
+    static_assert(!EB && NF * MF <= 4 && WN == 1, "deep ring: forward epilogues of the 4-fragment variants");
+    if (live(iuB)) setup_B(iuB);
+    issue_A(0);
+    issue_B(0);
+    a_ahead = issue_A(1);
+  } else {
+    issue_next(S0{});
+  }
   DDX_TR(2);
   int cunit = -1;
   for (int u = blockIdx.x; live(u); u += gridDim.x) {
     ++cunit;
-    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + GEO::CS_OFF + (cunit & 1) * 1024);
-    const Unit t = it;  // the issue cursor is still on this unit (it moves on during the last stage)
+    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + CS_BASE + (cunit & 1) * 1024);
+    const Unit t = DEEP ? decode(u) : it;  // (two-stage pipeline: the issue cursor is still on this unit, it moves on during the last stage)
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -405,7 +511,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     u32x4 rres[LATE_RES ? (NF > 2 ? 2 : 1) : NF][MF][2];
     auto rslot = [](int i) { return LATE_RES ? (NF > 2 ? (i & 1) : 0) : i; };
 
-    {
+    if constexpr (DEEP) {
+      for (int q = 0; q < nk; ++q) {
+        DDX_TR(5);
+        wait_stage(a_ahead);             // stage gs landed (its weights were issued before the younger activation batch)
+        DDX_TR(0);
+        __builtin_amdgcn_s_barrier();    // ... for every wave, and everyone is done reading the slots of stage gs - 1
+        DDX_TR(1);
+        issue_B((gs + 1) & 1);                                   // weights one stage ahead (slot of stage gs - 1)
+        a_ahead = issue_A(sa == 0 ? 2 : sa - 1);                 // activations two ahead: slot (gs + 2) % 3 = (gs - 1) % 3
+        DDX_TR(2);
+        if (q + 1 == nk && p.epilogue == DDX_EPI_MPSUM) {        // residual rows ride along with the last matrix phase
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < MF; ++j)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt) {
+                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
+              }
+        }
+        compute_at(smem + sa * GEO::A_BYTES, smem + D_BOFF + (gs & 1) * GEO::B_BYTES);
+        DDX_TR(3);
+        ++gs;
+        sa = sa == 2 ? 0 : sa + 1;
+      }
+    } else {
       // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
       for (int q = 0; q < nk; q += 2) {
         DDX_TR(5);
@@ -442,6 +574,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
     if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
     if constexpr (GEO::EPI_OVERLAY) __builtin_amdgcn_s_barrier();  // every wave is done reading stage 1: the patches live there
+    if constexpr (DEEP) {
+      // 64-channel tiles: the patches overlay the weight slot of the stage just multiplied (idle until the next stage's barrier)
+      if constexpr (D_OVERLAY) {
+        __builtin_amdgcn_s_barrier();
+        sE = reinterpret_cast<float*>(smem + D_BOFF + ((gs - 1) & 1) * GEO::B_BYTES + wave * GEO::EPI_WAVE);
+      }
+    }
     if constexpr (!EB && WN == 1 && NF <= 2 && MF <= 2) {
       if (p.epilogue == DDX_EPI_PIXELNORM) {
         // normalize(y, dim = channels) on the accumulators: a lane holds 16 of the 32 channels of pixel (lane & 31) per fragment,
@@ -559,7 +698,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 #pragma unroll
               for (int e = 0; e < 8; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
             }
+#ifndef DDX_ABL_NOSTORE
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + off) = tv.v;
+#else
+            if (tv.v[0] == (bf16)12345.f) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + off) = tv.v;   // (keeps the math alive)
+#endif
           }
           if (p.out_act) {
             if (p.out_cs) {
@@ -577,7 +720,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov.set(e, y[e]);
           DDX_TR(7);
+#ifndef DDX_ABL_NOSTORE
           *reinterpret_cast<bf16x8*>(out + off) = ov.v;
+#else
+          if (ov.v[0] == (bf16)12345.f) *reinterpret_cast<bf16x8*>(out + off) = ov.v;   // (keeps the math alive)
+#endif
           DDX_TR(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
@@ -645,15 +792,17 @@ __global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __rest
   }
 }
 
-template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2>
+template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
-  static_assert(GEO::SMEM <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
+  constexpr int DEEP_SMEM = 3 * GEO::A_BYTES + 2 * GEO::B_BYTES + (GEO::NW * GEO::EPI_WAVE <= GEO::B_BYTES ? 0 : GEO::NW * GEO::EPI_WAVE) + 2048;
+  constexpr int SMEM_BYTES = DEEP ? DEEP_SMEM : GEO::SMEM;
+  static_assert(SMEM_BYTES <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
   static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF>;  // (no fragment prefetch only where 128 accumulators leave no registers)
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF, DEEP>;  // (no fragment prefetch only where 128 accumulators leave no registers)
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::SMEM) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess)
       return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_dma)");
     attr_done = true;
   }
@@ -680,7 +829,7 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
     if (per_xcd) tile_order = 1;
     else if (ntile_px % 8 == 0 && (p.B * p.tiles_w) % 8 == 0 && grid % 8 == 0) tile_order = 2;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), GEO::SMEM, s, p, (int)total, ntile_n, per_xcd, tile_order);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), SMEM_BYTES, s, p, (int)total, ntile_n, per_xcd, tile_order);
   if (EB && p.bwd_ws && p.bwd_dc) {
     const int tpi = p.tiles_h * p.tiles_w;
     hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
@@ -805,6 +954,8 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
       }
     }
   }
+  static const int deep_knob = std::getenv("DDX_DMA_DEEP") ? atoi(std::getenv("DDX_DMA_DEEP")) : 0;
+  if (ksize == 3 && deep_knob) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
   const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);
