@@ -726,3 +726,44 @@ def test_conv_autotune_choice_is_consistent():
         ran += 1
         assert rel_l2(y, ref) < 2e-3, code
     assert ran >= 4
+
+
+_KNOB_SCRIPT = r"""
+import torch
+from dualdiffusion_amd import ops
+g = torch.Generator(device="cuda").manual_seed(3)
+worst = 0.0
+for (B, H, W, C0, C1, Cout, G, res) in [(2, 40, 200, 128, 0, 128, 2, True), (2, 40, 200, 64, 64, 64, 2, False), (4, 32, 344, 256, 0, 512, 8, False)]:
+    a0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
+    a1 = torch.randn(B, H, W, C1, device="cuda", generator=g).bfloat16() if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // G, 3, 3, device="cuda", generator=g)
+    r = torch.randn(B, H, W, Cout, device="cuda", generator=g).bfloat16() if res else None
+    cs = torch.rand(B, Cout, device="cuda", generator=g) + 0.5
+    pw = ops.wprep(w, G, torch.bfloat16, npix=B * H * W)
+    kw = dict(src1=a1, residual=r, res_t=0.3, clip=256.0) if res else dict(src1=a1, out_act=True, out_scale=cs)
+    tw_d, tw_m = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16), torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    y_d = ops.conv2d(a0, pw, path="dma", out2=tw_d if res else None, **kw)
+    y_m = ops.conv2d(a0, pw, path="mfma", out2=tw_m if res else None, **kw)
+    torch.cuda.synchronize()
+    e = float((y_d.float() - y_m.float()).norm() / y_m.float().norm())
+    if res:
+        e = max(e, float((tw_d.float() - tw_m.float()).norm() / tw_m.float().norm()))
+    worst = max(worst, e)
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("knob", ["DDX_DMA_DEEP=1", "DDX_DMA_BIG=2", "DDX_DMA_COL=1", "DDX_DMA_XCD=2"])
+def test_conv_dma_experiment_knobs_stay_correct(knob):
+    """The experimental LDS-DMA variants kept behind environment knobs (deep DMA ring, 512-pixel units, tile orders; read once per
+    process, so each runs in its own interpreter) against the register-staged kernel on grouped / two-source / residual layers."""
+    import os
+    import subprocess
+    import sys
+    k, v = knob.split("=")
+    env = dict(os.environ, **{k: v})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().splitlines()[-1].split()[1])
+    assert worst < 1e-2, (knob, worst)
