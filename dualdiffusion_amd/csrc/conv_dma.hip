@@ -101,7 +101,9 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
 // other's matrix phase instead of both doing the same thing at the same time.
 // EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
 // DEEP = 1: activation ring of three stages and weight ring of two (see the DEEP main loop)
-template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0>
+// WS = 1: weights stationary -- a workgroup keeps ONE (group, channel tile), its nk weight stages stay in LDS for the whole launch
+// and only activations stream (layers with few input channels per group, where the weight slices are most of the staged bytes)
+template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0, int WS = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd, const int tile_order) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
@@ -132,11 +134,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   const int gn = p.G * ntile_n;
   const float inv_gn = 1.0f / (float)gn, inv_G = 1.0f / (float)p.G;
   auto order = [&](int u) { return per_xcd ? (u & 7) * per_xcd + (u >> 3) : u; };
-  auto live = [&](int u) { return per_xcd ? ((u >> 3) < per_xcd && order(u) < total_units) : u < total_units; };
+  // WS order: workgroup w owns combo (w >> 3) % gn = (channel tile, group) and the tiles j, j + stride, ... with
+  // j = (w & 7) + 8 * (w / (8 * gn)), stride = gridDim.x / gn: every XCD (w & 7) sees all groups of its own tiles
+  const int ws_c = WS ? (int)((blockIdx.x >> 3) % gn) : 0;
+  const int ws_j = WS ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x / (8 * gn))) : 0;
+  const int ws_stride = WS ? (int)(gridDim.x / gn) : 1;
+  const float inv_grid = 1.0f / (float)gridDim.x;
+  auto ws_tile = [&](int u) { return ws_j + fdiv(u, inv_grid) * ws_stride; };
+  auto live = [&](int u) {
+    if constexpr (WS) return ws_tile(u) < ntile_px;
+    else return per_xcd ? ((u >> 3) < per_xcd && order(u) < total_units) : u < total_units;
+  };
   auto decode = [&](int u) {
     Unit t;
     int tile;
-    if (per_xcd) {
+    if constexpr (WS) {
+      tile = ws_tile(u);
+      const int nt = fdiv(ws_c, inv_G);
+      t.g = ws_c - nt * p.G;
+      t.n0 = nt * BN;
+    } else if (per_xcd) {
       const int o = order(u);
       tile = fdiv(o, inv_gn);
       const int rem = o - tile * gn;
@@ -208,6 +225,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   const rsrc_t rscs = make_rsrc(p.out_cs ? (const void*)p.out_cs : p.wp, p.out_cs ? (size_t)p.B * p.Cout * 4 : 0);
   constexpr bool CS_LDS = !EB && NF <= 2 && MF <= 2;   // (the 8-fragment variants have no registers to spare for it)
   const bool cs_lds = CS_LDS && p.out_cs != nullptr;
+  // LDS map of the WS variant: [A stage 0 | A stage 1 | nk weight stages | epilogue patches | channel scales]
+  const int ws_boff = 2 * GEO::A_BYTES, ws_eoff = ws_boff + (p.Cg / SK) * GEO::B_BYTES;
+  const int cs_base = WS ? ws_eoff + NW * GEO::EPI_WAVE : (DEEP ? 3 * GEO::A_BYTES + 2 * GEO::B_BYTES + (NW * GEO::EPI_WAVE <= GEO::B_BYTES ? 0 : NW * GEO::EPI_WAVE) : GEO::CS_OFF);
 
   // issue cursor: (unit, stage) of the next DMA batch.  Per lane only byte offsets inside the tensors are kept; the
   // stage (input-channel) advance is a scalar offset, so one batch costs one m0 write + one buffer_load per piece.
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   };
   auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
     if (!live(iu)) return;
-    char* sbase = smem + (int)stage * GEO::STAGE;
+    char* sbase = smem + (int)stage * (WS ? GEO::A_BYTES : GEO::STAGE);
     int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
     const int half = p.C0 + p.C1;
     const int swapped = (p.paired && cabs >= half) ? 1 : 0;   // [src0 | src1 | src0' | src1']: second half from image b ^ 1
@@ -264,13 +284,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
       if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
     }
     if (cs_lds && iq == 0 && wave == 0)   // (rides with the unit's first stage: landed at that stage's barrier)
-      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((it.b * p.Cout + it.g * p.Ng + it.n0) * 4), smem + GEO::CS_OFF + (iunit & 1) * 1024);
-    const int k0 = iq * SK;
-    const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
+      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((it.b * p.Cout + it.g * p.Ng + it.n0) * 4), smem + cs_base + (iunit & 1) * 1024);
+    if constexpr (!WS) {
+      const int k0 = iq * SK;
+      const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int piece = wave + NW * i;
-      if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, sbase + GEO::A_BYTES + piece * 1024);
+      for (int i = 0; i < BI; ++i) {
+        const int piece = wave + NW * i;
+        if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, sbase + GEO::A_BYTES + piece * 1024);
+      }
     }
     if (++iq == nk) {
       iq = 0;
@@ -290,7 +312,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   constexpr int D_EOFF = D_BOFF + 2 * GEO::B_BYTES;                                    // epilogue patches (32-channel tiles)
   constexpr bool D_OVERLAY = NW * GEO::EPI_WAVE <= GEO::B_BYTES;                       // patches fit a weight slot
   constexpr int D_CSOFF = D_EOFF + (D_OVERLAY ? 0 : NW * GEO::EPI_WAVE);
-  constexpr int CS_BASE = DEEP ? D_CSOFF : GEO::CS_OFF;
   int iuB = blockIdx.x, iqB = 0, iunitB = 0;
   Unit itB{};
   [[maybe_unused]] int bvoffB[BI];
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     if (!live(iuB)) return;
     char* sb = smem + D_BOFF + slot * GEO::B_BYTES;
     if (cs_lds && iqB == 0 && wave == 0)
-      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((itB.b * p.Cout + itB.g * p.Ng + itB.n0) * 4), smem + CS_BASE + (iunitB & 1) * 1024);
+      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((itB.b * p.Cout + itB.g * p.Ng + itB.n0) * 4), smem + cs_base + (iunitB & 1) * 1024);
     const int k0 = iqB * SK;
     const int soff_b = ((((itB.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
 #pragma unroll
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   };
 
   static_assert(!GEO::EPI_OVERLAY || NW * GEO::EPI_WAVE <= GEO::STAGE, "epilogue patches overlay stage 1");
-  float* sE = reinterpret_cast<float*>(smem + (DEEP ? D_EOFF : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE)) + wave * GEO::EPI_WAVE);
+  float* sE = reinterpret_cast<float*>(smem + (WS ? ws_eoff : (DEEP ? D_EOFF : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE))) + wave * GEO::EPI_WAVE);
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
@@ -452,13 +473,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     issue_B(0);
     a_ahead = issue_A(1);
   } else {
+    if constexpr (WS) {
+      static_assert(!EB && !DEEP && NF * MF <= 4 && WN == 1, "stationary weights: forward epilogues of the 4-fragment variants");
+      if (live(iu)) {   // all nk weight stages of this workgroup's (group, channel tile), once
+        for (int q = 0; q < nk; ++q) {
+          const int k0 = q * SK;
+          const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
+#pragma unroll
+          for (int i = 0; i < BI; ++i) {
+            const int piece = wave + NW * i;
+            if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, smem + ws_boff + q * GEO::B_BYTES + piece * 1024);
+          }
+        }
+      }
+    }
     issue_next(S0{});
   }
   DDX_TR(2);
   int cunit = -1;
   for (int u = blockIdx.x; live(u); u += gridDim.x) {
     ++cunit;
-    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + CS_BASE + (cunit & 1) * 1024);
+    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + cs_base + (cunit & 1) * 1024);
     const Unit t = DEEP ? decode(u) : it;  // (two-stage pipeline: the issue cursor is still on this unit, it moves on during the last stage)
 #pragma unroll
     for (int i = 0; i < NF; ++i)
@@ -547,7 +582,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         DDX_TR(1);
         issue_next(S1{});
         DDX_TR(2);
-        compute(S0{});
+        if constexpr (WS) compute_at(smem, smem + ws_boff + q * GEO::B_BYTES);
+        else compute(S0{});
         DDX_TR(3);
         wait_vmcnt<0>();
         DDX_TR(0);
@@ -566,7 +602,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
                 rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
               }
         }
-        compute(S1{});
+        if constexpr (WS) compute_at(smem + GEO::A_BYTES, smem + ws_boff + (q + 1) * GEO::B_BYTES);
+        else compute(S1{});
         DDX_TR(3);
       }
     }
@@ -792,23 +829,26 @@ __global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __rest
   }
 }
 
-template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0>
+template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0, int WS = 0>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int DEEP_SMEM = 3 * GEO::A_BYTES + 2 * GEO::B_BYTES + (GEO::NW * GEO::EPI_WAVE <= GEO::B_BYTES ? 0 : GEO::NW * GEO::EPI_WAVE) + 2048;
-  constexpr int SMEM_BYTES = DEEP ? DEEP_SMEM : GEO::SMEM;
-  static_assert(SMEM_BYTES <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
+  constexpr int WS_NK_MAX = (80 * 1024 - 2 * GEO::A_BYTES - GEO::NW * GEO::EPI_WAVE - 2048) / GEO::B_BYTES;   // weight stages that fit
+  const int SMEM_BYTES = WS ? 2 * GEO::A_BYTES + (p.Cg / SK) * GEO::B_BYTES + GEO::NW * GEO::EPI_WAVE + 2048 : (DEEP ? DEEP_SMEM : GEO::SMEM);
+  static_assert((DEEP ? DEEP_SMEM : GEO::SMEM) <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
+  if (WS && (p.Cg / SK > WS_NK_MAX)) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma: weights do not fit LDS");
   static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF, DEEP>;  // (no fragment prefetch only where 128 accumulators leave no registers)
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF, DEEP, WS>;  // (no fragment prefetch only where 128 accumulators leave no registers)
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WS ? 80 * 1024 : SMEM_BYTES) != hipSuccess)
       return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_dma)");
     attr_done = true;
   }
   const int ntile_n = ceil_div(p.Ng, GEO::BN);
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
   int grid = (int)std::min<long>(total, GEO::NW == 4 ? 512 : 256);  // persistent: every CU holds 8 waves
+  if (WS) grid = 512;   // (the launcher checked: 512 % (8 * combos) == 0)
   static const int grid_knob = getenv("DDX_DMA_GRID") ? atoi(getenv("DDX_DMA_GRID")) : 0;   // experiment knob: persistent grid size
   if (grid_knob > 0) grid = (int)std::min<long>(total, grid_knob);
   // XCD-aware unit order where it was measured to cut HBM fetches: 3x3 layers whose group slice of a pixel is half a cache
@@ -953,6 +993,17 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
         return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 4>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 4>(p, s);
       }
     }
+  }
+  // stationary weights where all K-stages of a channel tile fit beside two activation stages (Cg <= 32 with 64-channel tiles,
+  // Cg <= 64 with 32-channel tiles): -7 ... -15 % on those layers.  DDX_DMA_WS=0 off, 2 = also 32-channel tiles for
+  // Ng = 64 layers with Cg = 64 (experiment)
+  static const int ws_knob = std::getenv("DDX_DMA_WS") ? atoi(std::getenv("DDX_DMA_WS")) : 1;
+  if (ksize == 3 && ws_knob) {
+    const int nk = p.Cg / 16;
+    const int bn = (p.Ng <= 32 || (ws_knob == 2 && p.Ng == 64 && nk == 4)) ? 32 : 64, combos = p.G * ceil_div(p.Ng, bn);
+    const long tiles = (long)p.B * p.tiles_h * p.tiles_w;
+    if (combos <= 64 && 512 % (8 * combos) == 0 && tiles * combos >= 1024 && nk <= (bn == 32 ? 4 : 2))
+      return bn == 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 0, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 0, 1>(p, s);
   }
   static const int deep_knob = std::getenv("DDX_DMA_DEEP") ? atoi(std::getenv("DDX_DMA_DEEP")) : 0;
   if (ksize == 3 && deep_knob) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
