@@ -767,3 +767,37 @@ def test_conv_dma_experiment_knobs_stay_correct(knob):
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.strip().splitlines()[-1].split()[1])
     assert worst < 1e-2, (knob, worst)
+
+
+@pytest.mark.parametrize("case", ["ungrouped_32", "two_source_64_to_32", "grouped_32_to_64_act", "residual_twin_64_to_32"])
+def test_conv_dma_stationary_weights(case):
+    """Layers large enough (>= 1024 units) and narrow enough (Cg <= 32 with 64-channel tiles, Cg <= 64 with 32-channel tiles) for the
+    stationary-weights variant of the LDS-DMA kernel (a workgroup keeps one channel tile, its own unit order): against the
+    register-staged kernel on the same operands, ragged tile edges included."""
+    ops = _ops()
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, H, W, C0, C1, Cout, G, res, act = {
+        "ungrouped_32": (2, 130, 1000, 32, 0, 32, 1, False, False),
+        "two_source_64_to_32": (2, 128, 1030, 32, 32, 32, 1, False, True),
+        "grouped_32_to_64_act": (4, 32, 688, 256, 0, 512, 8, False, True),
+        "residual_twin_64_to_32": (4, 32, 700, 512, 0, 256, 8, True, False),
+    }[case]
+    a0 = torch.randn(B, H, W, C0, device="cuda", generator=g).to(dt)
+    a1 = torch.randn(B, H, W, C1, device="cuda", generator=g).to(dt) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // G, 3, 3, device="cuda", generator=g)
+    r = torch.randn(B, H, W, Cout, device="cuda", generator=g).to(dt) if res else None
+    cs = torch.rand(B, Cout, device="cuda", generator=g) + 0.5
+    pw = ops.wprep(w, G, dt, npix=B * H * W)
+    kw = dict(src1=a1, residual=r, res_t=0.3, clip=256.0) if res else dict(src1=a1, out_act=act, out_scale=cs if act else None)
+    tw_d = torch.empty(B, H, W, Cout, device="cuda", dtype=dt) if res else None
+    tw_m = torch.empty_like(tw_d) if res else None
+    y_d = ops.conv2d(a0, pw, path="dma", out2=tw_d, **kw)
+    y_m = ops.conv2d(a0, pw, path="mfma", out2=tw_m, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(y_d, y_m) < 5e-3
+    if res:
+        assert rel_l2(tw_d, tw_m) < 5e-3
+    # every output pixel written (no unit lost by the per-workgroup order): compare a checksum of the border rows / columns too
+    assert torch.isfinite(y_d.float()).all()
+    assert rel_l2(y_d[:, -1], y_m[:, -1]) < 5e-3 and rel_l2(y_d[:, :, -1], y_m[:, :, -1]) < 5e-3
