@@ -43,7 +43,8 @@ class ConvDesc(C.Structure):
                 ("scale0", C.c_float), ("scale1", C.c_float), ("res_t", C.c_float), ("clip", C.c_float),
                 ("dtype", C.c_int32), ("force_direct", C.c_int32),
                 ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float),
-                ("pad_mode", C.c_int32), ("prologue_rows", C.c_int32)]
+                ("pad_mode", C.c_int32), ("prologue_rows", C.c_int32),
+                ("out2_linear", C.c_int32), ("out2_chan_scale", C.c_void_p), ("src0_alt", C.c_void_p)]
 
 
 class DgradActDesc(C.Structure):

@@ -61,7 +61,7 @@ extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype
 extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
   if (!dp || !dp->w || !dp->wp) return set_error(DDX_ERR_ARG, "wprep: null");
   const ddx_wprep_desc d = *dp;
-  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 32 && d.CK != 64 && d.CK != 128))
+  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 16 && d.CK != 32 && d.CK != 64 && d.CK != 128))
     return set_error(DDX_ERR_ARG, "wprep: bad shape");
   if (d.qk_head_dim > 0 && (d.groups != 1 || d.Cout % (2 * d.qk_head_dim))) return set_error(DDX_ERR_ARG, "wprep: bad qk_head_dim");
   if (d.rows_total != 0 && (d.groups != 1 || d.transpose || d.row_offset < 0 || d.row_offset + d.Cout > d.rows_total))
@@ -163,6 +163,9 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;
   p.clip = d.clip;
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
+  p.src0_alt = d.src0_alt; p.out2_cs = d.out2_chan_scale; p.out2_linear = d.out2_linear;
+  if (d.out2_linear && (!d.out2 || !d.out2_chan_scale)) return set_error(DDX_ERR_ARG, "conv: out2_linear needs out2 and out2_chan_scale");
+  if ((d.src0_alt || d.out2_linear) && d.CK != 16) return set_error(DDX_ERR_UNSUPPORTED, "conv: src0_alt / out2_linear are served by the small-M kernel only (CK = 16)");
   p.reflect_w = (d.pad_mode & DDX_PAD_REFLECT_W) ? 1 : 0;
   p.swap1 = (d.pad_mode & DDX_PAD_SWAP_SRC1) ? 1 : 0;
   p.paired = (d.pad_mode & DDX_PAD_SWAP_PAIRED) ? 1 : 0;
@@ -193,6 +196,15 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)
   // >= 16: the register-staged kernel with tile / split-K configuration (force_direct - 16), see ConvParams::force_cfg
   if (d.force_direct >= 16) p.force_cfg = d.force_direct - 16 + 1;
+  // CK = 16 is the weight layout of the small-M weight-streaming kernel (conv_sm.hip): the choice was made when the weights were prepared
+  if (d.CK == 16 && d.force_direct != 1) {
+    if ((d.force_direct != 0 && d.force_direct != 4) || !conv_sm_supported(p, ks, dt))
+      return set_error(DDX_ERR_UNSUPPORTED, "conv: weights prepared with CK = 16 run on the small-M kernel only, and this layer does not qualify");
+    const double flops_sm = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
+    const double bytes_sm = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) + (double)p.Cout * p.Cg * ks * ks);
+    return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_sm(p, ks, s); }, stream, ks == 3 ? "conv3x3_sm" : "conv1x1_sm", flops_sm, bytes_sm);
+  }
+  if (d.force_direct == 4) return set_error(DDX_ERR_UNSUPPORTED, "conv: the small-M kernel needs weights prepared with CK = 16");
   const bool mfma = d.force_direct != 1 && conv_mfma_supported(p, ks, dt);
   static const bool dma_enabled = []() { const char* e = std::getenv("DDX_CONV_DMA"); return !e || e[0] != '0'; }();
   if (d.force_direct == 3 && !conv_dma_supported(p, ks, dt, /*any_size=*/true))

@@ -27,6 +27,9 @@ struct ConvParams {
   float out2_scale;
   int reflect_w;        // columns outside the image are mirrored (ReflectionPad on W) instead of zero
   float norm_eps;       // DDX_EPI_PIXELNORM: eps of normalize()
+  const void* src0_alt; // small-M kernel: source of the output-channel tiles below pro_rows (x * c twin), or null
+  const float* out2_cs; // small-M kernel: per-(b, channel) scale of a LINEAR twin (out2 = y * out2_cs), with out2_linear
+  int out2_linear;
   int swap1;            // src1 is read from image b ^ 1 (DDX_PAD_SWAP_SRC1)
   int paired;           // input = [src0 | src1 | src0' | src1'], ' = image b ^ 1 (DDX_PAD_SWAP_PAIRED); Cin = 2 * (C0 + C1)
   // DDX_EPI_SILU_BWD (data-gradient conv fused with the backward of the producer-side activation; `res` = y of the first part)
@@ -55,6 +58,8 @@ void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype);
 int launch_conv_direct(const ConvParams& p, int ksize, int dtype, hipStream_t s);  // conv_direct.hip
 bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size);  // conv_dma.hip
 int launch_conv_dma(const ConvParams& p, int ksize, hipStream_t s);
+bool conv_sm_supported(const ConvParams& p, int ksize, int dtype);  // conv_sm.hip (small-M weight-streaming kernel, CK = 16 layout)
+int launch_conv_sm(const ConvParams& p, int ksize, hipStream_t s);
 size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize);  // per (unit, wave) channel sums of the DDX_EPI_SILU_BWD epilogue
 
 }  // namespace ddx

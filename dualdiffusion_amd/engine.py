@@ -37,6 +37,13 @@ EMB_LANE = os.environ.get("DDX_EMB_LANE", "0") != "0"
 # Measured (default UNet, hipGraph): B=1 2.77 -> 2.66 ms, B=4 4.99 -> 4.98 ms, B=8 8.44 -> 8.40 ms -- the built-in heuristics were
 # tuned at B=4/8 and leave little there, so it is opt-in (adds ~1-2 s to the first call, run-to-run choices may differ).
 AUTOTUNE = os.environ.get("DDX_AUTOTUNE", "0") != "0"
+# 1x1 layers of an inference plan with at most this many output pixels (B*H*W) run on the small-M weight-streaming kernel
+# (conv_sm.hip): their weights are prepared with 16-channel chunks, the layout that kernel streams straight into the MFMA operand
+# registers.  Measured on MI355X (tools/conv_bench.py --cases small, graph-chained launches, B=4): level-4 1x1 layers (344 pixels)
+# 7.0-12.9 us against 9.1-17.2 us on the register-staged split-K kernel; level-3 1x1 layers (1376 pixels) 13-31 us against 12-26 us,
+# and the 3x3 variant (DDX_SM_3X3=1) 10-33 us against 9-28 us -> the default covers what is faster.  0 switches it off.
+SM_MAX_PIXELS = int(os.environ.get("DDX_SM_MAX_PIXELS", "512"))
+SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
 
 
 class PlanBuilder:
@@ -65,12 +72,19 @@ class PlanBuilder:
         self.keep.append(t)
         return t
 
+    def pick_ck(self, Cg: int, ks: int, npix: int) -> int:
+        # (1x1 layers: a wave of the small-M kernel owns a quarter of the channels in whole 64-channel lines, four steps in flight)
+        if (not self.training and self.dt == torch.bfloat16 and 0 < npix <= SM_MAX_PIXELS and Cg >= 32 and
+                ((SM_3X3 and Cg % 16 == 0) if ks == 3 else Cg % 256 == 0)):
+            return 16
+        return ops.pick_ck(Cg, ks, self.dt, npix)
+
     def gain_slot(self, p) -> int:
         self.gains.append(p)
         return len(self.gains) - 1
 
     def prep(self, conv, gain_param=None, qk_head_dim: int = 0, cg_pad: Optional[int] = None, npix: int = 0,
-             in_split: int = 0, in_scale0: float = 1.0, in_scale1: float = 1.0, cout_pad: int = 0):
+             in_split: int = 0, in_scale0: float = 1.0, in_scale1: float = 1.0, cout_pad: int = 0, allow_sm: bool = True):
         """Declare a conv's prepared weights; the buffer is filled whenever `wplan` runs.
         in_split / in_scale*: mp_cat scales of a linear consumer folded into the weights.
         cout_pad: prepare from a zero-row-padded copy of the weight (refreshed with the weights), so that a conv with
@@ -82,7 +96,7 @@ class PlanBuilder:
             self.padded.append((conv, wsrc))
             w = wsrc
         Cg, ks = w.shape[1], (w.shape[2] if w.ndim == 4 else 1)
-        CK = ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
+        CK = self.pick_ck(Cg, ks, npix) if (cg_pad is None and allow_sm) else ops.pick_ck(cg_pad or Cg, ks, self.dt, npix)
         nbytes = ops.lib().ddx_wprep_bytes(w.shape[0], Cg, ks, conv.groups, CK, ops.dtype_code(self.dt))
         buf = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         self.keep.append(buf)
@@ -90,7 +104,7 @@ class PlanBuilder:
                                in_scale1=in_scale1, gain_slot=self.gain_slot(gain_param) if gain_param is not None else None))
         return ops.PreparedWeight(buf, w.shape[0], Cg, ks, conv.groups, CK, self.dt, None)
 
-    def prep_merged(self, parts: list, npix: int = 0):
+    def prep_merged(self, parts: list, npix: int = 0, allow_sm: bool = True):
         """Several 1x1 convs on the same input as ONE prepared matrix (rows concatenated): parts = [(conv, qk_head_dim), ...].
         Each part is prepared into its row range whenever `wplan` runs."""
         w0 = parts[0][0].weight
@@ -98,7 +112,7 @@ class PlanBuilder:
         total = sum(c.weight.shape[0] for c, _ in parts)
         assert all(c.weight.shape[1] == Cg and c.groups == 1 and c.weight.ndim in (2, 4) and (c.weight.ndim == 2 or c.weight.shape[2] == 1)
                    for c, _ in parts)
-        CK = ops.pick_ck(Cg, 1, self.dt, npix)
+        CK = self.pick_ck(Cg, 1, npix) if allow_sm else ops.pick_ck(Cg, 1, self.dt, npix)
         nbytes = ops.lib().ddx_wprep_bytes(total, Cg, 1, 1, CK, ops.dtype_code(self.dt))
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=self.dev)       # padding rows stay zero
         self.keep.append(buf)
@@ -140,6 +154,12 @@ class PlanBuilder:
         last_clip = 0.0 if attn else clip
         twin = self.act(h, w, cout) if twin_scale is not None else None
         tw_res1 = dict(out2=twin, out2_scale=twin_scale) if (twin is not None and not attn) else {}
+        if attn:
+            c_qk, c_v = self.cvec(blk.emb_linear_qk, blk.emb_gain_qk), self.cvec(blk.emb_linear_v, blk.emb_gain_v)
+            if pw_res1.CK == 16:
+                # small-M kernels take raw operands: conv_res1 also writes the scaled twin x * c_qk that attn_qk reads
+                xs = self.act(h, w, cout)
+                tw_res1 = dict(out2=xs, out2_chan_scale=c_qk)
         S = self.step
         if blk.flavor == "enc":
             pw_skip = self.prep(blk.conv_skip, npix=npix) if blk.conv_skip is not None else None
@@ -168,6 +188,11 @@ class PlanBuilder:
                 self.first_cvec_step = len(self.steps)
             if act0 is not None and (src1 is None or act1 is not None):
                 S(lambda: ops.conv2d(act0, pw_res0, out_hw=(h, w), src1=act1, resample=rs, out_act=True, out_scale=c_emb, out=y0))
+            elif pw_res0.CK == 16 and src1 is None:
+                # small-M kernel (raw operands only): one element-wise pass makes the activated operand the producer did not write
+                a0 = self.act(src0.shape[1], src0.shape[2], src0.shape[3])
+                S(lambda: ops.silu_scale_fwd(src0, None, s0, out=a0))
+                S(lambda: ops.conv2d(a0, pw_res0, out_hw=(h, w), resample=rs, out_act=True, out_scale=c_emb, out=y0))
             else:   # no twins available: fused prologue on the raw inputs
                 S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU,
                                      out_act=True, out_scale=c_emb, out=y0))
@@ -192,20 +217,23 @@ class PlanBuilder:
             S(lambda: ops.conv2d(y0, pw_res1, residual=sk, res_t=res_balance, clip=last_clip, out=xo, **tw_res1))
         if not attn:
             return xo, twin
-        c_qk, c_v = self.cvec(blk.emb_linear_qk, blk.emb_gain_qk), self.cvec(blk.emb_linear_v, blk.emb_gain_v)
         heads = blk.num_heads
+        sm_qk = pw_res1.CK == 16
         # attn_qk and attn_v read the same tensor: ONE conv over the row-concatenated weights writes [q|k (2C) | v (C)]; the
         # channel-scale prologue (x * c_qk) only applies to the q|k output tiles (one 15 us small-M launch less per block)
         pw_proj = self.prep(blk.attn_proj, npix=npix)
         ao, xa = self.act(h, w, cout), self.act(h, w, cout)
         tw_proj = dict(out2=twin, out2_scale=twin_scale) if twin is not None else {}
         if MERGE_QKV:
-            pw_qkv = self.prep_merged([(blk.attn_qk, cout // heads), (blk.attn_v, 0)], npix=npix)
+            pw_qkv = self.prep_merged([(blk.attn_qk, cout // heads), (blk.attn_v, 0)], npix=npix, allow_sm=sm_qk)
             qkv = self.act(h, w, 3 * cout)
             qk, vv = qkv[..., :2 * cout], qkv[..., 2 * cout:]
-            S(lambda: ops.conv2d(xo, pw_qkv, prologue=PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * cout, out=qkv))
+            if pw_qkv.CK == 16:
+                S(lambda: ops.conv2d(xo, pw_qkv, src0_alt=xs, prologue_rows=2 * cout, out=qkv))
+            else:
+                S(lambda: ops.conv2d(xo, pw_qkv, prologue=PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * cout, out=qkv))
         else:
-            pw_qk, pw_v = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix), self.prep(blk.attn_v, npix=npix)
+            pw_qk, pw_v = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix, allow_sm=False), self.prep(blk.attn_v, npix=npix)
             qk, vv = self.act(h, w, 2 * cout), self.act(h, w, cout)
             S(lambda: ops.conv2d(xo, pw_v, out=vv))
             S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))

@@ -293,6 +293,7 @@ class _UNetEngine:
         in_kw = dict(out2=x_tw, out2_scale=skip_twin[0]) if x_tw is not None else {}   # bound now: x_tw is re-assigned below
         pb.step(lambda x=x, in_kw=in_kw: ops.conv2d(x0, pw_in, out=x, **in_kw))
         skips = [(x, x_tw)]
+        self.stages = {"enc.conv_in": x}     # name -> NHWC output buffer of every block (static buffers: valid after any run)
         h, w = H, W
         bk = dict(mlp_multiplier=cfg.mlp_multiplier, res_balance=cfg.res_balance, attn_balance=cfg.attn_balance)
         for i, name in enumerate(enc_names):
@@ -303,6 +304,7 @@ class _UNetEngine:
                 h, w = h // 2, w // 2
             x, x_tw = pb.block(blk, x, None, 1.0, 1.0, h, w, twin_scale=skip_twin.get(i), **bk)
             skips.append((x, x_tw))
+            self.stages[f"enc.{name}"] = x
         x_act = None   # the last encoder output's twin carries the skip scale, not 1: the first mid block uses the fused prologue
         for j, (name, blk) in enumerate(dec_items):
             if blk.resample_mode == "up":
@@ -314,6 +316,7 @@ class _UNetEngine:
                 x, x_act = pb.block(blk, x, sk, s0, s1, h, w, act0=x_act, act1=sk_act, twin_scale=next_scale, **bk)
             else:
                 x, x_act = pb.block(blk, x, None, 1.0, 1.0, h, w, act0=x_act, twin_scale=next_scale, **bk)
+            self.stages[f"dec.{name}"] = x
         # ---- output (reference unet_edm2_b4.py:290-296)
         pw_out = pb.prep(unet.conv_out, gain_param=unet.out_gain, npix=B * H * W)
         y = pb.act(H, W, cfg.out_channels)

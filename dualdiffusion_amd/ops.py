@@ -93,7 +93,7 @@ def normalize_weights_(weight: torch.Tensor) -> None:
 # its real operands (heuristic choice, LDS-DMA kernel, every built tile / split-K configuration of the register-staged kernel)
 # and remembers the fastest per layer signature; later calls (the plan recording) ask for that kernel.  The heuristic stays
 # unless a candidate is at least 4 % faster.
-_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3}
+_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3, "sm": 4}
 _conv_choice: dict = {}
 _tuning = False
 
@@ -152,15 +152,19 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
-           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False, pixelnorm_eps: float = 0.0) -> torch.Tensor:
+           path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False, pixelnorm_eps: float = 0.0,
+           out2_chan_scale: Optional[torch.Tensor] = None, src0_alt: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
+    | "sm" (small-M weight-streaming kernel; weights prepared with CK = 16, which also selects it automatically)
     | an integer force_direct code (16 + 3 * tile + k: one tile / split-K configuration of the register-staged kernel).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
     (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y)).
     swap_src1: src1 is read from the pair-swapped image (b ^ 1): second depth tap of a (2,k,k) conv on a folded stereo pair.
     swap_paired: the input is [src0 | src1 | src0' | src1'] (' = image b ^ 1): both depth taps over a two-source (mp_cat) operand.
-    pixelnorm_eps > 0: the stored output is normalize(y, dim=channels) (DDX_EPI_PIXELNORM; LDS-DMA kernel, one group, Cout <= 64)."""
+    pixelnorm_eps > 0: the stored output is normalize(y, dim=channels) (DDX_EPI_PIXELNORM; LDS-DMA kernel, one group, Cout <= 64).
+    Small-M kernel only: out2_chan_scale [B, Cout] makes out2 the LINEAR twin y_final * out2_chan_scale (operand of attn_qk);
+    src0_alt (with prologue_rows > 0): output channels below prologue_rows read src0_alt instead of src0."""
     B, sH, sW, C0 = src0.shape
     if out_hw is None:
         out_hw = {L.RESAMPLE_KEEP: (sH, sW), L.RESAMPLE_UP: (sH * 2, sW * 2), L.RESAMPLE_DOWN: (sH // 2, sW // 2)}[resample]
@@ -175,8 +179,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    force_direct=1 if force_direct else (path if isinstance(path, int) else _PATH_CODE[path]),
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=(L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO) | (L.PAD_SWAP_SRC1 if swap_src1 else 0) | (L.PAD_SWAP_PAIRED if swap_paired else 0),
-                   prologue_rows=prologue_rows)
-    if d.force_direct == 0 and (_tuning or _conv_choice):
+                   prologue_rows=prologue_rows, out2_linear=int(out2_chan_scale is not None), out2_chan_scale=ptr(out2_chan_scale), src0_alt=ptr(src0_alt))
+    if d.force_direct == 0 and d.CK != 16 and (_tuning or _conv_choice):
         sig = _conv_signature(d)
         if _tuning and sig not in _conv_choice:
             _conv_choice[sig] = _tune_conv(d)
@@ -272,10 +276,12 @@ def add3(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None) -> 
     return out
 
 
-def silu_scale_fwd(x: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0, act: bool = True) -> torch.Tensor:
+def silu_scale_fwd(x: torch.Tensor, chan_scale: Optional[torch.Tensor] = None, scale: float = 1.0, act: bool = True,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """mp_silu(x * chan_scale[b, c] * scale) on an NHWC tensor (recomputed conv operand of the backward pass)."""
     B, Cn = x.shape[0], x.shape[-1]
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
     check(lib().ddx_silu_scale_fwd(ptr(x), ptr(chan_scale), float(scale), ptr(out), B, x.numel() // (B * Cn), Cn, int(act), dtype_code(x.dtype),
                                    current_stream()), "silu_scale_fwd")
     return out

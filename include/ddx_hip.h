@@ -120,6 +120,8 @@ typedef struct {
   float clip;               /* <= 0: none */
   int32_t dtype;            /* activations and wp */
   int32_t force_direct;     /* kernel choice: 0 automatic, 1 scalar reference kernel, 2 register-staged MFMA, 3 LDS-DMA MFMA,
+                             * 4 small-M weight-streaming MFMA (conv_sm.hip; needs wp prepared with CK = 16 -- with CK = 16 it is
+                             * also the automatic choice, the layout is its own),
                              * 16 + 3 * tile + k: register-staged MFMA with tile 0..3 = 256x64, 256x32, 128x64, 128x32 (pixels x
                              * channels) and split-K 1 << k (k = 0..2); DDX_ERR_UNSUPPORTED when the combination is not built.
                              * Used by plan-time autotuning (the host times the candidates once per layer shape). */
@@ -140,6 +142,14 @@ typedef struct {
   /* > 0: the prologue (chan_scale / mp_silu) only applies to output channels below prologue_rows; the rest read the raw
    * input (merged attn_qk | attn_v conv: qk = conv(x * c_qk), v = conv(x)).  Must be a multiple of 64. */
   int32_t prologue_rows;
+  /* small-M kernel (conv_sm.hip) only:
+   *   out2_linear = 1: out2 = y_final * out2_chan_scale[b][cout] (no activation) -- the scaled twin x * c_qk that attn_qk reads
+   *                (unet_edm2_b4.py:131-133), written by the conv that produces x;
+   *   src0_alt != NULL (with prologue == NONE and prologue_rows > 0): output channels below prologue_rows read src0_alt instead
+   *                of src0 -- merged attn_qk | attn_v conv over [x * c_qk | x] without a per-element prologue. */
+  int32_t out2_linear;
+  const float* out2_chan_scale;   /* [B][Cout] fp32 or NULL */
+  const void* src0_alt;           /* NHWC like src0, or NULL */
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);

@@ -801,3 +801,77 @@ def test_conv_dma_stationary_weights(case):
     # every output pixel written (no unit lost by the per-workgroup order): compare a checksum of the border rows / columns too
     assert torch.isfinite(y_d.float()).all()
     assert rel_l2(y_d[:, -1], y_m[:, -1]) < 5e-3 and rel_l2(y_d[:, :, -1], y_m[:, :, -1]) < 5e-3
+
+
+SM_CASES = {
+    # name: (B, H, W, C0, C1, Cout, groups, ksize, resample, residual, clip, out_act, twin, special)
+    "k3_l4": (4, 2, 43, 320, 0, 128, 2, 3, "keep", True, 256.0, False, True, None),          # whole image = one 96-pixel tile, Cg = 160
+    "k3_l3_act": (2, 4, 86, 256, 0, 192, 2, 3, "keep", False, 0.0, True, False, None),       # conv_res0: mp_silu(y * c), Ng = 96 (ragged 64-tiles)
+    "k3_cat_up": (2, 4, 86, 160, 128, 64, 1, 3, "up", True, 2.0, False, True, None),         # two sources in ONE group (masked DMA passes) + nearest-up
+    "k3_cat_groups": (1, 4, 86, 256, 256, 128, 4, 3, "keep", False, 0.0, False, False, None),  # two sources, groups on either side of the boundary
+    "k3_groups8": (1, 4, 22, 256, 0, 256, 8, 3, "keep", True, 1.5, False, False, None),      # Cg = 32, eight groups
+    "k3_big_cg": (2, 2, 43, 640, 0, 64, 2, 3, "keep", False, 0.0, False, False, None),       # Cg = 320: one workgroup per CU (118 KB slab)
+    "k1_l4": (4, 2, 43, 1280, 0, 192, 1, 1, "keep", True, 256.0, False, True, None),
+    "k1_cat": (2, 4, 86, 512, 256, 128, 1, 1, "keep", False, 0.0, False, False, None),
+    "k1_up": (1, 4, 86, 768, 0, 96, 1, 1, "up", False, 0.0, False, False, None),
+    "k1_qkv": (2, 2, 43, 256, 0, 768, 1, 1, "keep", False, 0.0, False, False, "alt_rows"),    # first 512 output rows read the x * c twin
+    "k3_lin_twin": (2, 2, 43, 256, 0, 128, 2, 3, "keep", True, 0.0, False, True, "lin_twin"),  # out2 = y * c2 (operand of attn_qk)
+    "k3_tiny": (1, 2, 5, 64, 0, 32, 1, 3, "keep", True, 0.0, False, True, None),
+}
+
+
+@pytest.mark.parametrize("name", list(SM_CASES))
+def test_conv_sm(name):
+    """Small-M weight-streaming kernels (conv_sm.hip; weights prepared with CK = 16) against the oracle conv on the same bf16 operands
+    and against the register-staged kernel."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dtype = torch.bfloat16
+    B, H, W, C0, C1, Cout, groups, ks, resample, has_res, clip, out_act, twin, special = SM_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    sh, sw = (H // 2, W // 2) if resample == "up" else (H, W)
+    a = _round(torch.randn(B, C0, sh, sw, generator=g) * 1.3, dtype)
+    b = _round(torch.randn(B, C1, sh, sw, generator=g), dtype) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // groups, ks, ks, generator=g)
+    cs = torch.rand(B, Cout, generator=g) + 0.5
+    cs2 = torch.rand(B, Cout, generator=g) + 0.5
+    res = _round(torch.randn(B, Cout, H, W, generator=g), dtype) if has_res else None
+    x = O.resample2x(torch.cat([a, b], 1) if C1 else a, resample)
+    wq = _round(O.prepared_weight(w), dtype)
+    kw, kw_old = {}, {}
+    if special == "alt_rows":
+        rows = 512
+        cin_scale = torch.rand(B, C0, generator=g) + 0.5
+        xs = _round(x * cin_scale[:, :, None, None], dtype)
+        y = torch.cat([torch.nn.functional.conv2d(xs, wq[:rows]), torch.nn.functional.conv2d(x, wq[rows:])], 1)
+        kw = dict(src0_alt=to_nhwc(xs, dtype), prologue_rows=rows)
+        kw_old = dict(prologue=L.PRO_SCALE, chan_scale=cin_scale.cuda(), prologue_rows=rows)
+    else:
+        y = torch.nn.functional.conv2d(x, wq, padding=ks // 2, groups=groups)
+    if has_res:
+        y = O.sum_mp(res, y, 0.3)
+    if clip > 0:
+        y = y.clamp(-clip, clip)
+    ref = O.silu_mp(y * cs[:, :, None, None]) if out_act else y
+    ref2 = y * cs2[:, :, None, None] if special == "lin_twin" else O.silu_mp(0.8 * y)
+    pw = ops.wprep(w.cuda(), groups, dtype, CK=16)
+    pw_old = ops.wprep(w.cuda(), groups, dtype)
+    common = dict(src1=to_nhwc(b, dtype) if C1 else None, resample={"keep": L.RESAMPLE_KEEP, "up": L.RESAMPLE_UP}[resample],
+                  residual=to_nhwc(res, dtype) if has_res else None, res_t=0.3, clip=clip, out_act=out_act, out_scale=cs.cuda() if out_act else None)
+    tw = torch.empty(B, H, W, Cout, device="cuda", dtype=dtype) if twin else None
+    tkw = dict(out2=tw, out2_chan_scale=cs2.cuda()) if special == "lin_twin" else dict(out2=tw, out2_scale=0.8)
+    out = ops.conv2d(to_nhwc(a, dtype), pw, path="sm", **common, **tkw, **kw)
+    old = ops.conv2d(to_nhwc(a, dtype), pw_old, path="mfma", **common, **kw_old)
+    torch.cuda.synchronize()
+    e, e_old = rel_l2(to_nchw(out), ref), rel_l2(to_nchw(old), ref)
+    print(f"conv_sm {name}: {e:.3e} (register-staged kernel {e_old:.3e})")
+    assert e < TOL[dtype], (name, e)
+    assert rel_l2(to_nchw(out), to_nchw(old)) < 6e-3
+    if twin:
+        assert rel_l2(to_nchw(tw), ref2) < TOL[dtype]
+    # automatic choice with CK = 16 weights is the same kernel, and it is deterministic
+    out2 = ops.conv2d(to_nhwc(a, dtype), pw, **common, **kw)
+    assert torch.equal(to_nchw(out2), to_nchw(out))
+    # what the small-M kernels do not serve is refused, not mis-computed
+    with pytest.raises(Exception):
+        ops.conv2d(to_nhwc(a, dtype), pw, prologue=L.PRO_SILU, **common)

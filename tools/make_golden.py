@@ -280,6 +280,45 @@ def gen_unet() -> None:
                   stages=("enc.block0_layer0", "enc.block1_layer0", "dec.block1_layer0", "dec.block0_up"))
 
 
+def gen_unet_default() -> None:
+    """BASELINE.json configs[1] at B=1: the DEFAULT unet.json model (5 levels, 293 M parameters, attention at L3/L4) on a full
+    45 s latent (1, 4, 32, 688), run by the reference itself.  Weights are re-derived from the seed on the GPU box
+    (oracle.random_unet_state), the fixture only holds inputs, the output and a strided sub-sample of every stage output
+    (so that a failure names the block)."""
+    print("unet default (full size, B=1)")
+    cfg = O.unet_cfg(channel_mult_noise=1, channel_mult_emb=3)      # config/models/default/unet.json
+    unet = make_ref_unet(cfg)
+    sd = O.random_unet_state(cfg, 5)
+    unet.load_state_dict(sd)
+    fmt = FakeFormat()
+    g = torch.Generator().manual_seed(6)
+    B, H, W = 1, 32, 688
+    sigma = torch.tensor([1.7])
+    x_in = torch.randn(B, 4, H, W, generator=g) * torch.sqrt(sigma ** 2 + 1).view(-1, 1, 1, 1)
+    clap = torch.randn(B, 512, generator=g)
+    mask = torch.tensor([True])
+    got, hooks = {}, []
+    for side in ("enc", "dec"):
+        for nm, mod in getattr(unet, side).items():
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=f"{side}.{nm}": got.__setitem__(key, o.detach().clone())))
+    with torch.no_grad():
+        emb = unet.get_embeddings(clap, mask)
+        out = unet(x_in, sigma, fmt, emb)
+    for h in hooks:
+        h.remove()
+    coll = {}
+    ours = O.unet_forward(sd, cfg, x_in, sigma, emb, collect=coll)
+    check("default forward", ours, out, 1e-5)
+    t = {"x_in": x_in, "sigma": sigma, "clap": clap, "mask": mask.to(torch.uint8), "embeddings": emb, "out": out}
+    STRIDE = 389
+    for k, v in got.items():
+        check(f"stage {k}", coll[k], v, 1e-5)
+        t[f"stage_sub.{k}"] = v.flatten()[::STRIDE].clone()
+    save("unet_default_b1", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, seed=5, B=B, H=H, W=W,
+                                    weights="oracle.random_unet_state(cfg, seed)", freq_range=[20.0, 16000.0], stage_stride=STRIDE,
+                                    params=sum(v.numel() for v in sd.values())))
+
+
 def gen_schedule() -> None:
     print("schedule")
     from sampling.schedule import SamplingSchedule
@@ -582,7 +621,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ddec": gen_ddec}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ddec": gen_ddec}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
