@@ -82,6 +82,76 @@ def cpu_baseline(unet, fmt_range, max_seconds: float = 25.0) -> dict:
                       f"{t:.3f} s/sample = {FLOP_PER_SAMPLE / t / 1e9:.0f} GFLOP/s; value = 1/(4*t) (B=4 step equivalent)"}
 
 
+def train_main(a) -> None:
+    """BASELINE.json configs[3]: data-parallel UNet training, one process per GPU, global batch = 8 x N (x accumulation steps):
+    sigma for the global batch from rank 0, per-rank strided slices, local gradient accumulation, ONE flat-bucket gradient exchange over
+    RCCL per optimizer step (two collectives, the decoder's overlapped with the encoder's backward), fused AdamW + EMAs + forced weight
+    norm.  One `step` = one optimizer step; value = optimizer steps/s of the whole job (time = max over ranks); weak scaling."""
+    from dualdiffusion_amd import distributed as D
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    from dualdiffusion_amd.training.optimizer import EMASpec, LRScheduleConfig, OptimizerConfig
+    from dualdiffusion_amd.training.sigma_sampler import SigmaSampler, SigmaSamplerConfig
+    from dualdiffusion_amd.training.train_step import UNetTrainStep
+    rank, world, local_rank = D.world()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init(backend="nccl", device=dev)
+
+    class Fmt:
+        ms_freq_scale = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+    Bd = a.batch if a.batch != 4 else 8       # configs[3]: 8 per rank (global 64 on 8 GPUs)
+    unet = build_model(dev, torch.float32, seed=0).train(True)          # same seed on every rank: identical replicas
+    emas = [EMASpec(name="0.9999", tensors={k: p.data.clone() for k, p in unet.named_parameters()}, beta=0.9999),
+            EMASpec(name="fb", tensors={k: p.data.clone() for k, p in unet.named_parameters()}, beta=0.99999, feedback_beta=0.9999)]
+    step = UNetTrainStep(unet, Fmt(), OptimizerConfig(max_grad_norm=10.0), LRScheduleConfig(learning_rate=1e-2, lr_warmup_steps=4000, lr_reference_steps=20000),
+                         use_graph=not a.no_graph, gradient_accumulation_steps=a.accum,
+                         sigma_sampler=SigmaSampler(SigmaSamplerConfig(distribution="ln_sech", dist_offset=0.45)), conditioning_dropout=0.1, emas=emas)
+    step.global_step = 100
+    g = torch.Generator(device=dev).manual_seed(1 + rank)               # synthetic latents / CLAP embeddings, different per rank
+    samples = torch.randn(Bd * a.accum, 4, 32, 688, device=dev, generator=g)
+    clap = torch.randn(Bd * a.accum, 512, device=dev, generator=g)
+    for _ in range(max(a.warmup, 1)):
+        out = step.run_batch(samples, clap, generator=g)
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step.run_batch(samples, clap, generator=g)
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out["loss"]).all() and out["grad_norm"] == out["grad_norm"], "non-finite training step"
+    _units, elapsed = D.replica_throughput(a.steps, elapsed)
+    # all ranks must hold identical weights after identical-seed init + summed gradients
+    w = torch.stack([p.data.float().sum() for p in unet.parameters()]).sum().reshape(1)
+    ws = [torch.empty_like(w) for _ in range(world)] if world > 1 else [w]
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_gather(ws, w)
+    if rank == 0:
+        gb = Bd * a.accum * world
+        sps = gb * a.steps / elapsed
+        fl = 3 * FLOP_PER_SAMPLE * gb * a.steps / elapsed
+        line = {"metric": "UNet training optimizer steps/sec (data parallel, RCCL gradient all-reduce)", "value": round(a.steps / elapsed, 4), "unit": "steps/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "configs[3]: DDP training of the default EDM2 UNet (293M params), latents (8,4,32,688) per GPU per micro-step, "
+                                       "stratified ln_sech sigma over the global batch, conditioning dropout 0.1, AdamW + 2 EMAs (one feedback) + forced weight norm",
+                           "global_batch": gb, "per_gpu_batch": Bd, "accumulation_steps": a.accum, "parallelism": f"dp{world}", "graph": not a.no_graph,
+                           "gradient_bucket_bytes": int(step.trainer.grad_flat.numel() * 4)},
+                "samples_per_s": round(sps, 2), "model_tflops": round(fl / 1e12, 1), "loss_mean": round(float(out["loss"].mean()), 4),
+                "grad_norm": round(float(out["grad_norm"]), 3), "replicas_identical": bool(all(torch.equal(x, ws[0]) for x in ws)),
+                "roofline": {"bound": "mfma", "achieved": round(fl / 1e12 / world, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(fl / 1e12 / world / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                             "note": "whole-step model FLOPs (3 x forward) per GPU; per-kernel rooflines: profiles/"}}
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        D.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +161,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--layer-table", action="store_true", help="print the per-op hipEvent profile (rank 0)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer: the BASELINE metric (UNet denoise steps/s, replicas); train: BASELINE configs[3], data-parallel optimizer steps/s")
+    ap.add_argument("--accum", type=int, default=1, help="--mode train: gradient-accumulation micro-steps per optimizer step")
     a = ap.parse_args()
+    if a.mode == "train":
+        return train_main(a)
 
     from dualdiffusion_amd import distributed as D
     rank, world, local_rank = D.world()

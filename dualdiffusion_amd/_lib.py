@@ -26,6 +26,21 @@ class DDXError(RuntimeError):
     pass
 
 
+# Parameters are also written through `.data` and raw device pointers (fused AdamW, forced weight normalisation of the weight
+# bank), which torch's per-tensor `_version` counters do not see.  Every such writer bumps this epoch; the prepared-weight caches
+# of the inference engines key on it (together with the `_version`s).
+_weights_epoch = 0
+
+
+def bump_weights_epoch() -> None:
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def weights_epoch() -> int:
+    return _weights_epoch
+
+
 class WPrepDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("gain_ptr", C.c_void_p), ("gain", C.c_float),
                 ("w_dtype", C.c_int32), ("wp_dtype", C.c_int32), ("Cout", C.c_int32), ("Cg", C.c_int32),
@@ -75,6 +90,14 @@ class BgemmDesc(C.Structure):
 
 class OptimJob(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_int64)]
+
+
+MAX_EMAS = 4
+
+
+class OptimJobEx(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p * MAX_EMAS),
+                ("n", C.c_int64), ("rows", C.c_int64), ("normalize", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LinearBwdJob(C.Structure):
@@ -159,6 +182,8 @@ PROTOTYPES = {
     "ddx_multi_grad_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "ddx_multi_adamw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int32, C.c_float, C.c_void_p]),
+    "ddx_multi_adamw_ema_wn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_void_p]),
     "ddx_ddec_input_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_cat2_act": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -1,0 +1,98 @@
+"""torch.autograd bridge of the HIP UNet: `unet(...)`, `unet.get_embeddings(...)` and `unet.get_sigma_loss_logvar(...)` called with
+autograd enabled on a module in training mode return tensors that `loss.backward()` differentiates, so the reference's train
+loop (src/training/trainer.py:1016 `accelerator.backward(loss)`, module_trainers/unet_trainer.py:236-282) runs unchanged and any
+torch optimizer can step the module's parameters.
+
+Each call is ONE autograd node: forward = `training.unet_grad.UNetTrainer.forward` (HIP launch sequence, activations taped on the
+device), backward = `UNetTrainer.backward` -- the same kernels `UNetTrainStep` drives directly.  The parameters are inputs of the
+node so that autograd delivers their gradients into `.grad` (accumulating across calls, i.e. gradient accumulation works as in
+the reference).  One forward may be outstanding per module (the tape is the trainer's); calling backward twice, or after a
+second forward, raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import DDXError
+
+
+def _named(unet):
+    return [(k, p) for k, p in unet.named_parameters()]
+
+
+class _UNetForward(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, unet, x_in, sigma, format, embeddings, perturbed_input, *params):
+        tr = unet._get_trainer()
+        with torch.no_grad():
+            out = tr.forward(x_in, sigma, format, embeddings, perturbed_input)
+        tr._tape_owner = ctx
+        ctx.unet, ctx.emb_dtype = unet, embeddings.dtype
+        ctx.names = [k for k, _ in _named(unet)]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        tr = ctx.unet._get_trainer()
+        if getattr(tr, "_tape_owner", None) is not ctx or tr.tape is None:
+            raise DDXError("UNet backward: the activation tape of this forward is gone (one forward per backward, no double backward)")
+        grads = tr.backward(d_out.contiguous().float())
+        tr._tape_owner, tr.tape = None, None
+        d_emb = grads.pop("embeddings").to(ctx.emb_dtype)
+        g = tr.store_grads(grads)
+        # clones: autograd may keep what it is handed as `.grad`, and the trainer's flat bucket is overwritten by the next backward
+        return (None, None, None, None, d_emb, None) + tuple(g[k].clone() if k in g else None for k in ctx.names)
+
+
+class _Embeddings(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, unet, emb_in, mask, w_c, w_u):
+        tr = unet._get_trainer()
+        with torch.no_grad():
+            emb, ectx = tr.embeddings_forward(emb_in, mask)
+        ctx.unet, ctx.ectx = unet, ectx
+        return emb.to(unet.dtype)
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        g = ctx.unet._get_trainer().embeddings_backward(d_emb.float(), ctx.ectx)
+        return None, None, None, g["emb_label.weight"].reshape(ctx.unet.emb_label.weight.shape), \
+            g["emb_label_unconditional.weight"].reshape(ctx.unet.emb_label_unconditional.weight.shape)
+
+
+class _Logvar(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, unet, sigma, w_lv):
+        tr = unet._get_trainer()
+        with torch.no_grad():
+            logvar, lctx = tr.logvar_forward(sigma)
+        ctx.unet, ctx.lctx = unet, lctx
+        return logvar.clone().view(-1, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, d_lv):
+        g = ctx.unet._get_trainer().logvar_backward(d_lv.reshape(-1), ctx.lctx)
+        return None, None, g["logvar_linear.weight"].reshape(ctx.unet.logvar_linear.weight.shape)
+
+
+def wants_grad(unet) -> bool:
+    return torch.is_grad_enabled() and unet.training and any(p.requires_grad for p in unet.parameters())
+
+
+def unet_forward(unet, x_in, sigma, format, embeddings, x_ref: Optional[torch.Tensor], perturbed_input: Optional[torch.Tensor]):
+    if x_ref is not None:
+        raise DDXError("autograd through the HIP UNet does not take x_ref (the reference's unet_train_batch passes none for this model)")
+    return _UNetForward.apply(unet, x_in, sigma, format, embeddings, perturbed_input, *[p for _, p in _named(unet)])
+
+
+def get_embeddings(unet, emb_in, conditioning_mask):
+    return _Embeddings.apply(unet, emb_in, conditioning_mask, unet.emb_label.weight, unet.emb_label_unconditional.weight)
+
+
+def get_sigma_loss_logvar(unet, sigma):
+    return _Logvar.apply(unet, sigma, unet.logvar_linear.weight)

@@ -34,6 +34,9 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const ddx_optim_job* _
                                                           float beta1, float beta2, float eps, float weight_decay, float bias1, float bias2,
                                                           float ema_beta) {
   const ddx_optim_job j = jobs[blockIdx.y];
+  // non-finite gradient norm (coef[1]): the whole step is skipped on the device, so NaN / Inf never reach p, m, v or the EMA
+  // (the host reads the norm after this launch: one sync per step, reference trainer.py:1044-1060)
+  if (coef && !(fabsf(coef[1]) <= 3.0e38f)) return;
   const float gs = gscale * (coef ? coef[0] : 1.0f);
   const float step = lr / bias1;
   const float inv_sqrt_bias2 = rsqrtf(bias2);
@@ -49,10 +52,76 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const ddx_optim_job* _
   }
 }
 
+// ---- the whole post-backward parameter pass as ONE multi-tensor launch: clip * AdamW, then for every EMA (in configuration order,
+// reference src/training/ema.py:284-321) ema_k <- lerp(ema_k, p, 1 - beta_k) and, for a feedback EMA, p <- lerp(p, ema_k,
+// 1 - feedback_beta_k), then the forced weight normalisation of the row (mp_tools.py:375-378, trainer.py:1105-1108).  A workgroup
+// owns whole rows (fan-in elements of one output channel): first sweep updates p / m / v / EMAs and sums p^2, second sweep re-reads
+// the row (a few KB, L2-resident) and rescales it -- the pass `normalize_weights()` would make over the tensor anyway.
+struct EmaCoef { float beta[DDX_MAX_EMAS]; float fb[DDX_MAX_EMAS]; };   // fb < 0: no feedback
+
+__global__ __launch_bounds__(256) void multi_adamw_ema_wn_kernel(const ddx_optim_job_ex* __restrict__ jobs, const float* __restrict__ coef, float gscale,
+                                                                 float lr, float beta1, float beta2, float eps, float weight_decay, float bias1,
+                                                                 float bias2, int n_ema, EmaCoef ec, float norm_eps) {
+  __shared__ float scratch[4];
+  const ddx_optim_job_ex j = jobs[blockIdx.y];
+  if (coef && !(fabsf(coef[1]) <= 3.0e38f)) return;   // non-finite gradient norm: skip the step on the device
+  const float gs = gscale * (coef ? coef[0] : 1.0f);
+  const float step = lr / bias1;
+  const float inv_sqrt_bias2 = rsqrtf(bias2);
+  const int64_t fan = j.n / j.rows;
+  for (int64_t row = blockIdx.x; row < j.rows; row += gridDim.x) {
+    const int64_t base = row * fan;
+    float ss = 0.f;
+    for (int64_t k = threadIdx.x; k < fan; k += 256) {
+      const int64_t i = base + k;
+      const float g = j.g[i] * gs;
+      float p = j.p[i];
+      const float m = beta1 * j.m[i] + (1.0f - beta1) * g;
+      const float v = beta2 * j.v[i] + (1.0f - beta2) * g * g;
+      p -= lr * weight_decay * p;
+      p -= step * m / (sqrtf(v) * inv_sqrt_bias2 + eps);
+      j.m[i] = m; j.v[i] = v;
+#pragma unroll
+      for (int e = 0; e < DDX_MAX_EMAS; ++e) {
+        if (e < n_ema && j.ema[e]) {
+          float a = j.ema[e][i];
+          a = a + (1.0f - ec.beta[e]) * (p - a);              // torch.lerp(ema, p, 1 - beta)
+          j.ema[e][i] = a;
+          if (ec.fb[e] >= 0.f) p = p + (1.0f - ec.fb[e]) * (a - p);   // feedback: torch.lerp(p, ema, 1 - feedback_beta)
+        }
+      }
+      j.p[i] = p;
+      ss += p * p;
+    }
+    if (j.normalize) {   // (workgroup-uniform)
+      ss = block_sum_256(ss, scratch);
+      const float inv = 1.0f / (norm_eps + sqrtf(ss) * sqrtf(1.0f / (float)fan));
+      __syncthreads();
+      for (int64_t k = threadIdx.x; k < fan; k += 256) j.p[base + k] *= inv;   // each thread re-reads what it wrote
+    }
+  }
+}
+
 }  // namespace
 }  // namespace ddx
 
 using namespace ddx;
+
+extern "C" int ddx_multi_adamw_ema_wn(const ddx_optim_job_ex* jobs_dev, int32_t njobs, int64_t max_rows, const float* clip_coef, float grad_scale,
+                                      float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, int32_t n_ema,
+                                      const float* ema_beta, const float* feedback_beta, float norm_eps, ddx_stream stream) {
+  if (!jobs_dev || njobs <= 0 || max_rows <= 0 || step <= 0 || n_ema < 0 || n_ema > DDX_MAX_EMAS || (n_ema > 0 && (!ema_beta || !feedback_beta)))
+    return set_error(DDX_ERR_ARG, "multi_adamw_ema_wn: bad args");
+  const float bias1 = 1.0f - std::pow(beta1, (float)step), bias2 = 1.0f - std::pow(beta2, (float)step);
+  EmaCoef ec{};
+  for (int e = 0; e < DDX_MAX_EMAS; ++e) { ec.beta[e] = e < n_ema ? ema_beta[e] : 1.f; ec.fb[e] = e < n_ema ? feedback_beta[e] : -1.f; }
+  return dispatch([=](hipStream_t s) -> int {
+    dim3 grid((unsigned)std::min<int64_t>(max_rows, 512), (unsigned)njobs);
+    hipLaunchKernelGGL(multi_adamw_ema_wn_kernel, grid, dim3(256), 0, s, jobs_dev, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, bias1,
+                       bias2, n_ema, ec, norm_eps);
+    return check_launch("multi_adamw_ema_wn");
+  }, stream, "adamw_ema_wn");
+}
 
 extern "C" int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float grad_scale, float max_norm,
                                    float* workspace3, ddx_stream stream) {

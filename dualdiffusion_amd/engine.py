@@ -17,7 +17,7 @@ from typing import Callable, Optional
 import torch
 
 from . import ops
-from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan, check, lib
+from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan, check, lib, weights_epoch
 
 _RESAMPLE = {"keep": RESAMPLE_KEEP, "up": RESAMPLE_UP, "down": RESAMPLE_DOWN}
 
@@ -312,7 +312,7 @@ class PlanBuilder:
 
     def refresh_weights(self, params) -> None:
         """Re-run weight preparation when training (forced weight norm every forward) or when any parameter changed."""
-        key = None if self.training else tuple(p._version for p in params)
+        key = None if self.training else (weights_epoch(),) + tuple(p._version for p in params)
         if self.training or key != self._weights_key:
             if self.gains:
                 self.gain_f32.copy_(torch.stack([g.detach().float().reshape(()) for g in self.gains]))

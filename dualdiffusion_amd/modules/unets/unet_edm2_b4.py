@@ -13,8 +13,9 @@ from typing import Optional, Union
 
 import torch
 
+from ... import autograd as _autograd
 from ... import ops
-from ..._lib import DDXError
+from ..._lib import DDXError, bump_weights_epoch
 from ...engine import PlanBuilder, mp_cat_weights
 from .unet import DualDiffusionUNet, DualDiffusionUNetConfig
 
@@ -54,6 +55,7 @@ class MPConvWeight(torch.nn.Module):
             if not self.weight.is_cuda:
                 raise DDXError("normalize_weights needs the module on a ROCm device (no CPU path)")
             ops.normalize_weights_(self.weight.data)
+            bump_weights_epoch()     # (.data write: invisible to the parameter's _version)
 
 
 class FourierTable(torch.nn.Module):
@@ -97,6 +99,9 @@ class UNet(DualDiffusionUNet):
     def __init__(self, config: UNetConfig) -> None:
         super().__init__()
         self.config = config
+        if getattr(config, "dropout", 0):
+            # reference Block applies magnitude-preserving dropout in training (unet_edm2_b4.py:124-125); no kernel for it here
+            raise NotImplementedError(f"UNetConfig.dropout = {config.dropout}: dropout is not implemented on the HIP path (use 0)")
         cblock = [config.model_channels * m for m in config.channel_mult]
         cnoise = config.model_channels * config.channel_mult_noise if config.channel_mult_noise is not None else max(cblock)
         cemb = config.model_channels * config.channel_mult_emb if config.channel_mult_emb is not None else max(cblock)
@@ -140,31 +145,45 @@ class UNet(DualDiffusionUNet):
         self._engines: dict = {}
         self._use_graph = False
         self._small: Optional["_SmallOps"] = None
+        self._trainer = None
 
     # ------------------------------------------------------------------ reference API
     def _on_placement_change(self) -> None:
         self._engines = {}
         self._small = None
+        self._trainer = None
 
     def _require_device(self) -> None:
         if self.device.type != "cuda":
             raise DDXError("UNet is not on a ROCm device: dualdiffusion_amd runs only on its HIP kernels (no CPU fallback)")
 
-    @torch.no_grad()
+    def _get_trainer(self):
+        """The module's differentiation engine (training.unet_grad.UNetTrainer): taped HIP forward + backward, shared by the
+        autograd bridge (dualdiffusion_amd.autograd) and training.train_step.UNetTrainStep."""
+        if self._trainer is None:
+            from ...training.unet_grad import UNetTrainer
+            self._trainer = UNetTrainer(self)
+        return self._trainer
+
     def get_embeddings(self, emb_in: torch.Tensor, conditioning_mask: torch.Tensor) -> torch.Tensor:
         """reference unet_edm2_b4.py:232-235."""
         self._require_device()
-        if self._small is None:
-            self._small = _SmallOps(self)
-        return self._small.embeddings(emb_in, conditioning_mask)
+        if _autograd.wants_grad(self):
+            return _autograd.get_embeddings(self, emb_in, conditioning_mask)
+        with torch.no_grad():
+            if self._small is None:
+                self._small = _SmallOps(self)
+            return self._small.embeddings(emb_in, conditioning_mask)
 
-    @torch.no_grad()
     def get_sigma_loss_logvar(self, sigma: Optional[torch.Tensor] = None) -> torch.Tensor:
         """reference unet_edm2_b4.py:237-238."""
         self._require_device()
-        if self._small is None:
-            self._small = _SmallOps(self)
-        return self._small.logvar(sigma)
+        if _autograd.wants_grad(self):
+            return _autograd.get_sigma_loss_logvar(self, sigma)
+        with torch.no_grad():
+            if self._small is None:
+                self._small = _SmallOps(self)
+            return self._small.logvar(sigma)
 
     def get_latent_shape(self, latent_shape: Union[torch.Size, tuple]) -> torch.Size:
         q = 2 ** (self.num_levels - 1)
@@ -182,8 +201,16 @@ class UNet(DualDiffusionUNet):
                 x_ref: Optional[torch.Tensor] = None, perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
         """reference unet_edm2_b4.py:250-296.  Returns float32 NCHW like the reference."""
         self._require_device()
+        if _autograd.wants_grad(self):
+            # training forward under autograd (reference trainer: unet(...) then accelerator.backward(loss), trainer.py:1016)
+            return _autograd.unet_forward(self, x_in, sigma, format, embeddings, x_ref, perturbed_input)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise DDXError("autograd through the HIP UNet is not available yet: call under torch.no_grad()")
+            raise DDXError("autograd through the HIP UNet needs the module in training mode (module.train()); "
+                           "for inference call under torch.no_grad() or requires_grad_(False)")
+        return self._forward_plan(x_in, sigma, format, embeddings, x_ref, perturbed_input)
+
+    @torch.no_grad()
+    def _forward_plan(self, x_in, sigma, format, embeddings, x_ref=None, perturbed_input=None) -> torch.Tensor:
         B, _, H, W = x_in.shape
         key = (B, H, W, self.dtype, self.training, x_ref is not None)
         eng = self._engines.get(key)
@@ -326,7 +353,9 @@ class _UNetEngine:
         self.fplan = pb.fplan
 
     def run(self, x_in, sigma, format, embeddings, x_ref, perturbed_input, use_graph: bool) -> torch.Tensor:
-        lkey = (id(format),)
+        fs = format.ms_freq_scale
+        lkey = (type(fs).__name__, getattr(fs, "freq_scale", None), float(getattr(fs, "freq_min", 0.0)), float(getattr(fs, "freq_max", 0.0)),
+                int(getattr(fs, "num_filters", 0)))     # by value: an id() can be recycled by a different format object
         if lkey != self._lnf_key:
             self.lnf.copy_(self.u.get_ln_freqs_rows(format, self.B, self.H, self.W))
             self._lnf_key = lkey

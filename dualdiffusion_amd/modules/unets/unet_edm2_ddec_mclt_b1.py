@@ -20,7 +20,7 @@ from typing import Optional, Union
 import torch
 
 from ... import ops
-from ..._lib import DDXError, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, check, current_stream, dtype_code, lib, ptr
+from ..._lib import weights_epoch, DDXError, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, check, current_stream, dtype_code, lib, ptr
 from ...engine import mp_cat_weights
 from .unet import DualDiffusionUNet, DualDiffusionUNetConfig
 
@@ -157,7 +157,7 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
 
     # ------------------------------------------------------------------ weight preparation (once per weight version)
     def _prep(self) -> dict:
-        key = tuple(p._version for p in self.parameters()) + (self.dtype,)
+        key = (weights_epoch(),) + tuple(p._version for p in self.parameters()) + (self.dtype,)
         if key == self._prepared_key:
             return self._prepared
         dt, G = self.dtype, self.config.mlp_groups

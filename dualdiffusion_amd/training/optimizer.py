@@ -57,14 +57,61 @@ def lr_multiplier(cfg: LRScheduleConfig, step: int, warmup_steps: Optional[int] 
     return lr
 
 
-class FusedAdamW:
-    """AdamW over a fixed set of fp32 device tensors.  `step(grads)` = clip_grad_norm_(max_grad_norm) + optimizer.step() (+ EMA)."""
+def std_to_exp(std: float) -> float:
+    """EDM2 power-function EMA: exponent gamma of a profile with relative standard deviation `std` -- the real root of
+    gamma^3 + 7 gamma^2 + (16 - 1/std^2) gamma + (12 - 1/std^2) = 0 (Karras et al. 2024, Algorithm 2; reference ema.py:95-107)."""
+    import numpy as np
+    tmp = np.float64(std) ** -2
+    roots = np.roots([1.0, 7.0, 16.0 - tmp, 12.0 - tmp])
+    return float(roots.real.max())
 
-    def __init__(self, params: dict, cfg: OptimizerConfig = OptimizerConfig(), ema: Optional[dict] = None, ema_beta: float = 0.0) -> None:
+
+def power_function_beta(std: float, t_next: int, t_delta: int) -> float:
+    """reference ema.py:112-114."""
+    return float((1 - t_delta / t_next) ** (std_to_exp(std) + 1))
+
+
+@dataclass
+class EMASpec:
+    """One EMA of the training weights (reference ema.py EMA_Config :197-206): classic (`beta`) or power-function (`std`), optional
+    warm-up of beta and optional feedback of the EMA into the training weights."""
+    name: str
+    tensors: dict                               # parameter name -> fp32 device tensor (the EMA weights)
+    beta: Optional[float] = None
+    std: Optional[float] = None
+    num_warmup_steps: Optional[int] = None
+    feedback_beta: Optional[float] = None
+
+    def __post_init__(self) -> None:
+        if (self.beta is None) == (self.std is None):
+            raise ValueError(f"EMA {self.name}: give exactly one of beta / std")
+
+    def effective_beta(self, global_step: int, total_samples_processed: int, total_batch_size: int) -> float:
+        """ema.py:297-301 (the update runs after the step's samples were counted)."""
+        beta = self.beta if self.beta is not None else power_function_beta(self.std, total_samples_processed + total_batch_size, total_batch_size)
+        if self.num_warmup_steps:
+            beta *= min(global_step / self.num_warmup_steps, 1)
+        return beta
+
+
+class FusedAdamW:
+    """AdamW over a fixed set of fp32 device tensors.  `step(grads)` = clip_grad_norm_(max_grad_norm) + optimizer.step() (+ EMA).
+    With `emas` (list of EMASpec, at most 4) and / or `wn_rows` ({parameter name: output rows} of the weight-normalised tensors) the
+    update runs as ONE launch that also steps every EMA in order (with feedback) and re-normalises the rows afterwards
+    (ddx_multi_adamw_ema_wn; reference trainer.py:1063-1108 + ema.py:284-321)."""
+
+    def __init__(self, params: dict, cfg: OptimizerConfig = OptimizerConfig(), ema: Optional[dict] = None, ema_beta: float = 0.0,
+                 emas: Optional[list] = None, wn_rows: Optional[dict] = None) -> None:
         for k, p in params.items():
             if p.dtype != torch.float32 or p.device.type != "cuda" or not p.is_contiguous():
                 raise L.DDXError(f"FusedAdamW: parameter {k} must be a contiguous float32 tensor on the ROCm device")
         self.params, self.cfg, self.ema, self.ema_beta = params, cfg, ema, ema_beta
+        self.emas, self.wn_rows = list(emas or []), wn_rows
+        if len(self.emas) > L.MAX_EMAS:
+            raise L.DDXError(f"FusedAdamW: at most {L.MAX_EMAS} EMAs per launch")
+        if self.emas and ema is not None:
+            raise L.DDXError("FusedAdamW: give either `ema` (one fixed-beta EMA) or `emas`")
+        self.fused = bool(self.emas) or wn_rows is not None
         self.m = {k: torch.zeros_like(p) for k, p in params.items()}
         self.v = {k: torch.zeros_like(p) for k, p in params.items()}
         self.steps = 0
@@ -89,6 +136,25 @@ class FusedAdamW:
         self.grad_norm_logmean = self.grad_norm_logmean * c.grad_norm_mean_ema_beta + (1 - c.grad_norm_mean_ema_beta) * math.log(grad_norm)
         self.grad_norm_logvar = self.grad_norm_logvar * c.grad_norm_std_ema_beta + (1 - c.grad_norm_std_ema_beta) * math.log(grad_var)
 
+    def _table_ex(self, grads: dict) -> torch.Tensor:
+        key = tuple(grads[k].data_ptr() for k in self._names)
+        if getattr(self, "_table_ex_key", None) == key:
+            return self._table_ex_dev
+        arr = (L.OptimJobEx * len(self._names))()
+        self._max_rows = 1
+        for i, k in enumerate(self._names):
+            g, p = grads[k], self.params[k]
+            rows = int((self.wn_rows or {}).get(k, 0))
+            norm = int(rows > 0)
+            rows = rows if rows > 0 else (p.shape[0] if p.ndim >= 2 else 1)
+            self._max_rows = max(self._max_rows, rows)
+            emap = (C.c_void_p * L.MAX_EMAS)(*[ptr(e.tensors[k]) if (j < len(self.emas) and k in (e := self.emas[j]).tensors) else None
+                                               for j in range(L.MAX_EMAS)])
+            arr[i] = L.OptimJobEx(p=ptr(p), g=ptr(g), m=ptr(self.m[k]), v=ptr(self.v[k]), ema=emap, n=g.numel(), rows=rows, normalize=norm, reserved=0)
+        self._table_ex_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self._ws.device)
+        self._table_ex_key = key
+        return self._table_ex_dev
+
     def _table(self, grads: dict) -> torch.Tensor:
         key = tuple(grads[k].data_ptr() for k in self._names)      # the trainer's gradients live in one persistent bucket:
         if getattr(self, "_table_key", None) == key:               # the table is built once, no host->device copy per step
@@ -104,8 +170,9 @@ class FusedAdamW:
         self._table_key = key
         return self._table_dev
 
-    def step(self, grads: dict, lr: float, grad_scale: Optional[float] = None) -> float:
+    def step(self, grads: dict, lr: float, grad_scale: Optional[float] = None, ema_betas: Optional[list] = None) -> float:
         """grads: d mean(loss) / d parameter (summed over ranks when distributed; pass grad_scale = loss_scale / world_size).
+        ema_betas: this step's beta of every EMASpec (EMASpec.effective_beta), in order.
         Returns the (scaled) global gradient norm before clipping, like accelerator.clip_grad_norm_."""
         c = self.cfg
         gs = c.loss_scale if grad_scale is None else grad_scale
@@ -114,8 +181,27 @@ class FusedAdamW:
         n = len(self._names)
         check(lib().ddx_multi_grad_norm(ptr(table), n, self._max_n, gs, max_norm, ptr(self._ws), current_stream()), "multi_grad_norm")
         self.steps += 1
-        check(lib().ddx_multi_adamw(ptr(table), n, self._max_n, self._ws.data_ptr() + 4, gs, lr, c.adam_beta1, c.adam_beta2, c.adam_epsilon,
-                                    c.adam_weight_decay, self.steps, self.ema_beta, current_stream()), "multi_adamw")
+        if self.fused:
+            tex = self._table_ex(grads)
+            ne = len(self.emas)
+            if ne and (ema_betas is None or len(ema_betas) != ne):
+                raise L.DDXError("FusedAdamW.step: ema_betas must give one beta per EMA")
+            betas = (C.c_float * max(ne, 1))(*([float(b) for b in ema_betas] if ne else [1.0]))
+            fbs = (C.c_float * max(ne, 1))(*([float(e.feedback_beta) if e.feedback_beta is not None else -1.0 for e in self.emas] if ne else [-1.0]))
+            check(lib().ddx_multi_adamw_ema_wn(ptr(tex), n, self._max_rows, self._ws.data_ptr() + 4, gs, lr, c.adam_beta1, c.adam_beta2,
+                                               c.adam_epsilon, c.adam_weight_decay, self.steps, ne, betas, fbs, 1e-4, current_stream()),
+                  "multi_adamw_ema_wn")
+        else:
+            check(lib().ddx_multi_adamw(ptr(table), n, self._max_n, self._ws.data_ptr() + 4, gs, lr, c.adam_beta1, c.adam_beta2, c.adam_epsilon,
+                                        c.adam_weight_decay, self.steps, self.ema_beta, current_stream()), "multi_adamw")
+        L.bump_weights_epoch()                   # raw-pointer parameter write
         grad_norm = float(self._ws[2])           # one host sync per step, as the reference's .item()
+        if not math.isfinite(grad_norm):
+            # the kernel skipped the update (non-finite clip coefficient): parameters, moments and EMA are untouched.
+            # The reference warns on inf and aborts on NaN before optimizer.step() (trainer.py:1053-1060).
+            self.steps -= 1
+            if math.isnan(grad_norm):
+                raise FloatingPointError("gradient norm is NaN: optimizer step skipped (reference trainer aborts here, trainer.py:1055-1060)")
+            return grad_norm
         self.update_grad_norm_stats(grad_norm)
         return grad_norm

@@ -1,11 +1,19 @@
-"""One data-parallel UNet training step on MI355X: train batch (forward, loss, backward) -> gradient all-reduce over RCCL ->
-dynamic clipping + fused AdamW (+EMA) -> forced weight normalisation.
+"""One data-parallel UNet optimizer step on MI355X: [gradient-accumulation micro-steps of (train batch: forward, loss, backward)] ->
+gradient all-reduce over RCCL -> dynamic clipping + fused AdamW + EMAs (+ feedback) + forced weight normalisation.
 
-Mirrors the per-step body of reference src/training/trainer.py:1001-1067 + :375-381 for `UNetTrainer`
-(module_trainers/unet_trainer.py:169-296): sigma is drawn for the GLOBAL batch on rank 0, broadcast, and strided per rank
-(dualdiffusion_amd.distributed, SigmaSampler); every rank runs its local batch; gradients are summed across ranks in ONE
-flat bucket (1.17 GB for the default UNet: a single large all-reduce suits the point-to-point xGMI links better than many
-small ones) and averaged through the optimizer's gradient scale.
+Mirrors the per-step body of reference src/training/trainer.py:1001-1108 for `UNetTrainer`
+(module_trainers/unet_trainer.py:169-296):
+  * `init_batch` (:169-200): sigma is drawn ONCE for the GLOBAL batch (device_batch x accumulation steps x ranks) on rank 0 and
+    broadcast (dualdiffusion_amd.distributed.broadcast_from_rank0 replaces the all_gather-row-0 idiom of :197-198);
+  * every micro-step takes the strided slice global_sigma[rank::world][accum * B:(accum + 1) * B] (:245-246), draws the
+    conditioning mask / noise / input perturbation, runs the train batch on the HIP kernels; gradients ACCUMULATE over the
+    micro-steps locally (accelerate's `accumulate` / no_sync, trainer.py:1012-1016) and the per-sample scalars travel in ONE small
+    all_gather per micro-step (distributed.gather_scalars replaces the separate gathers of unet_trainer.py:284 / trainer.py:77);
+  * only the LAST micro-step exchanges gradients: ONE flat fp32 bucket (1.17 GB for the default UNet) in two collectives, the
+    decoder's part overlapped with the encoder's backward (GradientExchange);
+  * the optimizer's gradient scale loss_scale / (world x accumulation steps) does the averaging (accelerate divides the loss by
+    the accumulation steps, DDP averages over ranks).
+`step(...)` is the single-micro-step entry with the random draws given by the caller (tests, benchmarks).
 """
 from __future__ import annotations
 
@@ -14,13 +22,18 @@ from typing import Optional
 
 import torch
 
-from .optimizer import FusedAdamW, LRScheduleConfig, OptimizerConfig, lr_multiplier
-from .unet_grad import UNetTrainer
+from .. import distributed as D
+from .optimizer import EMASpec, FusedAdamW, LRScheduleConfig, OptimizerConfig, lr_multiplier
 
 
 def _world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def _dist_ready() -> bool:
@@ -44,6 +57,15 @@ def allreduce_gradients(grads: dict, names: Optional[list] = None) -> dict:
     return out
 
 
+def check_trainer_config(cfg: dict) -> None:
+    """Reject reference `module_trainer_config` options (unet_trainer.py:38-72) that the HIP train batch does not implement, instead
+    of silently training a different objective."""
+    bad = [k for k in ("conditioning_perturbation", "use_dynamic_sigma_data", "normalize_latents", "inpainting_probability")
+           if cfg.get(k) not in (None, 0, 0.0, False)]
+    if bad:
+        raise NotImplementedError(f"UNetTrainStep: trainer options not implemented on the HIP path: {bad}")
+
+
 class GradientExchange:
     """Data-parallel gradient SUM over one flat fp32 bucket in two pieces (reference: accelerate's DDP wrapper buckets the
     gradients and all-reduces each bucket as soon as it is complete: src/training/trainer.py:375 accelerator.prepare, :1016
@@ -51,27 +73,40 @@ class GradientExchange:
     `flat[:early_numel]` holds the gradients that are final first (the decoder's, back-propagated before the encoder):
     start_early() sends them asynchronously on RCCL's stream while the rest of the backward pass runs; finish() sends the tail
     and waits for both.  xGMI rings are per-link bound (~150 GB/s): 0.6 GB per bucket keeps each collective bandwidth-bound,
-    not latency-bound."""
+    not latency-bound.
+    With `accum` (gradient accumulation) the bucket that travels is `accum`, and the last micro-step's gradients `flat` are added
+    into it piecewise right before each piece is sent."""
 
-    def __init__(self, flat: torch.Tensor, early_numel: int) -> None:
+    def __init__(self, flat: torch.Tensor, early_numel: int, accum: Optional[torch.Tensor] = None) -> None:
         if not 0 <= early_numel <= flat.numel():
             raise ValueError("GradientExchange: early_numel outside the bucket")
-        self.flat, self.early_numel, self._pending = flat, early_numel, None
+        if accum is not None and accum.shape != flat.shape:
+            raise ValueError("GradientExchange: accumulation bucket must have the gradient bucket's shape")
+        self.flat, self.early_numel, self.accum, self._pending = flat, early_numel, accum, None
+        self.bucket = accum if accum is not None else flat
 
     def start_early(self) -> None:
         import torch.distributed as dist
         if self._pending is not None:
             raise RuntimeError("GradientExchange: start_early twice in one step")
-        if self.early_numel > 0:
-            self._pending = dist.all_reduce(self.flat[:self.early_numel], op=dist.ReduceOp.SUM, async_op=True)
+        e = self.early_numel
+        if e > 0:
+            if self.accum is not None:
+                self.accum[:e].add_(self.flat[:e])
+            self._pending = dist.all_reduce(self.bucket[:e], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self) -> None:
         import torch.distributed as dist
+        e = self.early_numel
         if self._pending is None:            # start_early never ran (graph replay, or nothing early): one collective over everything
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.accum is not None:
+                self.accum.add_(self.flat)
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
             return
-        if self.early_numel < self.flat.numel():
-            dist.all_reduce(self.flat[self.early_numel:], op=dist.ReduceOp.SUM)
+        if e < self.flat.numel():
+            if self.accum is not None:
+                self.accum[e:].add_(self.flat[e:])
+            dist.all_reduce(self.bucket[e:], op=dist.ReduceOp.SUM)
         self._pending.wait()
         self._pending = None
 
@@ -79,20 +114,37 @@ class GradientExchange:
 class UNetTrainStep:
 
     def __init__(self, unet, format, optimizer: OptimizerConfig = OptimizerConfig(), lr_schedule: LRScheduleConfig = LRScheduleConfig(),
-                 ema: Optional[dict] = None, ema_beta: float = 0.0, input_perturbation: float = 0.0, use_graph: bool = False) -> None:
+                 ema: Optional[dict] = None, ema_beta: float = 0.0, input_perturbation: float = 0.0, use_graph: bool = False,
+                 gradient_accumulation_steps: int = 1, sigma_sampler=None, conditioning_dropout: float = 0.1,
+                 emas: Optional[list] = None, fused_weight_norm: bool = False, trainer=None, optimizer_impl=None) -> None:
         """use_graph: capture the whole train batch (forward, loss, backward: ~1900 launches) into one hipGraph on first use and
         replay it afterwards (static input buffers).  The eager loop needs ~20 ms of host time per step and every host hiccup of
         a shared machine lands in the step time; the replay needs the host for the input copies, one graph launch, the
-        all-reduce and the four optimizer launches."""
+        all-reduce and the optimizer launches.
+        emas: list of training.optimizer.EMASpec (power-function / classic / feedback EMAs, reference ema.py); with emas or
+        fused_weight_norm the parameter pass after the backward is ONE launch (AdamW + EMAs + feedback + forced weight norm).
+        trainer / optimizer_impl: differentiation engine and parameter pass (defaults: the module's own UNetTrainer and
+        FusedAdamW on the HIP kernels; the world_size-2 CPU test passes stubs to drive this class's control flow over gloo)."""
         self.unet, self.format, self.lr_cfg = unet, format, lr_schedule
         self.use_graph = use_graph
         self._graph = None
         self._graph_key = None
-        self.trainer = UNetTrainer(unet)
+        self.trainer = trainer if trainer is not None else unet._get_trainer()
         self.params = {k: p.data for k, p in unet.named_parameters()}
-        self.opt = FusedAdamW(self.params, optimizer, ema, ema_beta)
+        wn_rows = None
+        if fused_weight_norm or emas:
+            wn_rows = {k + ".weight": m.weight.shape[0] for k, m in unet.named_modules()
+                       if hasattr(m, "disable_weight_norm") and hasattr(m, "weight") and not m.disable_weight_norm}
+        self.fused_weight_norm = wn_rows is not None
+        self.opt = optimizer_impl if optimizer_impl is not None else FusedAdamW(self.params, optimizer, ema, ema_beta, emas=emas, wn_rows=wn_rows)
+        self.emas = list(emas or [])
         self.input_perturbation = input_perturbation
+        self.accum_steps = int(gradient_accumulation_steps)
+        self.sigma_sampler, self.conditioning_dropout = sigma_sampler, conditioning_dropout
         self.global_step = 0
+        self.total_samples_processed = 0
+        self._accum: Optional[torch.Tensor] = None
+        self.last_gathered: list = []        # per micro-step: [loss, sigma] of the GLOBAL micro-batch (one all_gather each)
 
     def _train_batch_graph(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation):
         dev = self.unet.device
@@ -120,32 +172,93 @@ class UNetTrainStep:
         self._graph.replay()
         return self._graph_out
 
-    def step(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
-             conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:
-        """One optimizer step on this rank's batch (the random draws are inputs: the caller owns the generators)."""
-        world = _world_size()
+    # ------------------------------------------------------------------------------------------------ micro-steps
+    def _micro(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook):
         tr = self.trainer
-        # DDX_DDP_BUCKETS=1 runs the two-bucket exchange on any initialised process group (world_size 1 included: single-GPU check)
-        exchange = world > 1 or (os.environ.get("DDX_DDP_BUCKETS", "0") == "1" and _dist_ready())
-        ex = GradientExchange(tr.grad_flat, tr.early_numel) if exchange else None
-        # eager: the decoder's bucket travels while the encoder is back-propagated; graph replay: one collective after the replay
-        tr.bucket_hook = ex.start_early if (ex is not None and not self.use_graph) else None
+        tr.bucket_hook = hook
         if self.use_graph:
-            loss, grads = self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation)
-        else:
-            loss, grads = self.trainer.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation,
-                                                   self.input_perturbation)
+            return self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation)
+        return tr.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation, self.input_perturbation)
+
+    def _finish(self, loss, grads, world: int, n_micro: int, ex: Optional[GradientExchange], device_batch: int) -> dict:
+        tr = self.trainer
         missing = [k for k in self.params if k not in grads]
         if missing:
             raise RuntimeError(f"UNetTrainStep: no gradient for {missing[:4]}")
         if ex is not None:                  # every gradient already lives in the trainer's flat bucket: no gather copies
             ex.finish()
+        elif self._accum is not None and n_micro > 1:
+            self._accum.add_(tr.grad_flat)
+        if n_micro > 1:                     # the optimizer reads the accumulated bucket (same layout as the trainer's)
+            base = tr.grad_flat.data_ptr()
+            grads = {k: self._accum[(v.data_ptr() - base) // 4:(v.data_ptr() - base) // 4 + v.numel()].view(v.shape) for k, v in grads.items()}
         lr = self.lr_cfg.learning_rate * lr_multiplier(self.lr_cfg, self.global_step)
-        grad_norm = self.opt.step(grads, lr, self.opt.cfg.loss_scale / world)
-        # trainer.py:375-381: forced weight normalisation after every optimizer step (one launch over the weight bank)
-        if self.trainer.bank is not None:
-            self.trainer.bank.normalize()
-        else:
-            self.unet.normalize_weights()
+        total_batch = device_batch * n_micro * world
+        betas = [e.effective_beta(self.global_step, self.total_samples_processed, total_batch) for e in self.emas] if self.emas else None
+        grad_norm = self.opt.step(grads, lr, self.opt.cfg.loss_scale / (world * n_micro), ema_betas=betas)
+        # trainer.py:1105-1108: forced weight normalisation after every optimizer step (inside the fused launch, or one launch over
+        # the weight bank)
+        if not self.fused_weight_norm:
+            if getattr(tr, "bank", None) is not None:
+                tr.bank.normalize()
+            else:
+                self.unet.normalize_weights()
         self.global_step += 1
+        self.total_samples_processed += total_batch
         return {"loss": loss, "grad_norm": grad_norm, "lr": lr}
+
+    def _exchange(self, world: int, n_micro: int) -> Optional[GradientExchange]:
+        tr = self.trainer
+        # DDX_DDP_BUCKETS=1 runs the two-bucket exchange on any initialised process group (world_size 1 included: single-GPU check)
+        exchange = world > 1 or (os.environ.get("DDX_DDP_BUCKETS", "0") == "1" and _dist_ready())
+        if n_micro > 1 and (self._accum is None or self._accum.shape != tr.grad_flat.shape):
+            self._accum = torch.zeros_like(tr.grad_flat)
+        return GradientExchange(tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None) if exchange else None
+
+    def step(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
+             conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:
+        """One optimizer step on this rank's batch, ONE micro-step (the random draws are inputs: the caller owns the generators)."""
+        world = _world_size()
+        ex = self._exchange(world, 1)
+        # eager: the decoder's bucket travels while the encoder is back-propagated; graph replay: one collective after the replay
+        hook = ex.start_early if (ex is not None and not self.use_graph) else None
+        loss, grads = self._micro(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook)
+        return self._finish(loss, grads, world, 1, ex, int(samples.shape[0]))
+
+    def run_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, generator: Optional[torch.Generator] = None,
+                  sigma_jitter: Optional[torch.Tensor] = None) -> dict:
+        """One optimizer step as the reference's loop body (trainer.py:1001-1108) on this rank's LOCAL batch
+        `samples` [device_batch * accumulation steps, C, H, W] / `audio_embeddings`: sigma for the global batch from the sigma
+        sampler on rank 0, micro-steps with local gradient accumulation, exchange after the last one, one parameter pass."""
+        if self.sigma_sampler is None:
+            raise RuntimeError("UNetTrainStep.run_batch needs a sigma_sampler")
+        world, rank, A = _world_size(), _rank(), self.accum_steps
+        if samples.shape[0] % A:
+            raise ValueError(f"local batch of {samples.shape[0]} is not divisible by {A} accumulation steps")
+        Bd = samples.shape[0] // A
+        dev = self.unet.device
+        # init_batch (unet_trainer.py:169-200): whole-batch sigma, identical on every rank
+        gsig = self.sigma_sampler.sample(Bd * A * world, jitter=sigma_jitter).float()
+        gsig = gsig.to(dev) if _dist_ready() and D.dist.get_backend() == "nccl" else gsig
+        gsig = D.broadcast_from_rank0(gsig.contiguous())
+        self.global_sigma = gsig
+        ex = self._exchange(world, A)
+        if self._accum is not None and A > 1:
+            self._accum.zero_()
+        self.last_gathered = []
+        losses = []
+        for a in range(A):
+            last = a == A - 1
+            x = samples[a * Bd:(a + 1) * Bd]
+            e = audio_embeddings[a * Bd:(a + 1) * Bd]
+            sig = D.strided_slice(gsig, rank, world, a, Bd).to(dev)
+            mask = torch.rand(Bd, generator=generator, device=generator.device if generator is not None else dev) > self.conditioning_dropout
+            noise = torch.randn(x.shape, generator=generator, device=mask.device)
+            pert = torch.randn(x.shape, generator=generator, device=mask.device) if self.input_perturbation > 0 else None
+            hook = ex.start_early if (ex is not None and last and not self.use_graph) else None
+            loss, grads = self._micro(x, e, sig, noise, mask, pert, hook)
+            if not last:                      # no_sync micro-step: gradients stay local
+                self._accum.add_(self.trainer.grad_flat)
+            self.last_gathered.append(D.gather_scalars([loss, sig]))       # one small collective per micro-step
+            losses.append(loss)
+        return self._finish(torch.cat(losses) if A > 1 else losses[0], grads, world, A, ex, Bd)

@@ -331,19 +331,12 @@ class UNetTrainer:
         self.bank.backward("late")         # weight-path backward of the remaining layers (fills the bucket views handed out above)
         return self.store_grads(grads)
 
-    # ------------------------------------------------------------------------------------------------ one training batch
-    def train_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
-                    conditioning_mask: torch.Tensor, format, input_perturbation: Optional[torch.Tensor] = None,
-                    input_perturbation_scale: float = 0.0):
-        """The device part of reference UNetTrainer.unet_train_batch (unet_trainer.py:222-296) with the random draws given:
-        noise / input_perturbation ~ N(0, 1) like `samples`, conditioning_mask [B] bool, sigma [B].
-        Returns (loss [B], grads) where grads holds d mean(loss) / d parameter for EVERY parameter of the module."""
-        u, cfg, dev = self.u, self.u.config, self.u.device
-        B = samples.shape[0]
-        samples = samples.to(dev, torch.float32).contiguous()
-        sig = sigma.flatten().to(dev, torch.float32).contiguous()
+    # ------------------------------------------------------------------------------------------------ small heads (forward + backward)
+    def embeddings_forward(self, audio_embeddings: torch.Tensor, conditioning_mask: torch.Tensor):
+        """get_embeddings (unet_edm2_b4.py:232-235) in training mode, with what its backward needs: returns (emb [B, cemb] fp32, ctx)."""
+        u, dev = self.u, self.u.device
+        B = audio_embeddings.shape[0]
         mask = conditioning_mask.to(dev, torch.float32).contiguous()
-        # get_embeddings (unet_edm2_b4.py:232-235) -- kept here with its intermediates for the backward
         xn = ops.pixelnorm(audio_embeddings.to(dev, torch.float32).contiguous())
         ones = self._buf("ones", (1, 1))
         ones.fill_(1.0)
@@ -354,26 +347,62 @@ class UNetTrainer:
         ops.linear_small(self._lin_table(("emb_label", B), [(w_c, None, cemb, 1.0, 0.0, 1, True)]), 1, u.cemb, xn, B, w_c.dtype)
         emb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
         ops.mpsum_rows(uemb, cemb, emb, t_rows=mask)
-        # model inputs (unet_trainer.py:249-259)
-        s4 = sig.view(-1, 1, 1, 1)
-        x_in = samples + noise.to(dev, torch.float32) * s4
-        pert = x_in + input_perturbation.to(dev, torch.float32) * s4 * input_perturbation_scale if input_perturbation is not None else None
-        denoised = self.forward(x_in, sig, format, emb, pert)
-        # learned per-sigma log-variance (unet_edm2_b4.py:237-238; no weight norm on logvar_linear)
+        return emb, dict(xn=xn, ones=ones, mask=mask)
+
+    def embeddings_backward(self, dE: torch.Tensor, ctx: dict) -> dict:
+        """embeddings = mp_sum(u, c, mask) row-wise with mask in {0, 1}: rows pick c (conditioned) or u (dropped)  -- [B, cemb] glue."""
+        u = self.u
+        w_u, w_c = u.emb_label_unconditional.weight.data, u.emb_label.weight.data
+        t = ctx["mask"].view(-1, 1)
+        nrm = torch.sqrt((1 - t) ** 2 + t ** 2)
+        dE = dE.to(torch.float32)
+        dc = (dE * t / nrm).contiguous()
+        du = (dE * (1 - t) / nrm).sum(dim=0, keepdim=True).contiguous()
+        g = {}
+        g["emb_label.weight"], _ = ops.linear_small_bwd(dc, ctx["xn"], w_c, 1, None, True, None)
+        g["emb_label_unconditional.weight"], _ = ops.linear_small_bwd(du, ctx["ones"], w_u, 1, None, True, None)
+        return g
+
+    def logvar_forward(self, sigma: torch.Tensor):
+        """get_sigma_loss_logvar (unet_edm2_b4.py:237-238; no weight norm on logvar_linear): returns (logvar [B, 1] fp32, ctx)."""
+        u, cfg, dev = self.u, self.u.config, self.u.device
+        sig = sigma.flatten().to(dev, torch.float32).contiguous()
+        B = sig.numel()
         f_lv = torch.empty(B, cfg.logvar_channels, device=dev, dtype=torch.float32)
         ops.mpfourier(sig, u.logvar_fourier.freqs.float().contiguous(), u.logvar_fourier.phases.float().contiguous(), f_lv, True)
         logvar = self._buf(("logvar", B), (B, 1))
         w_lv = u.logvar_linear.weight.data
         ops.linear_small(self._lin_table(("logvar_linear", B), [(w_lv, None, logvar, 1.0, 0.0, 1, False)]), 1, 1, f_lv, B, w_lv.dtype)
+        return logvar, dict(f_lv=f_lv)
+
+    def logvar_backward(self, dlv: torch.Tensor, ctx: dict) -> dict:
+        w_lv = self.u.logvar_linear.weight.data
+        g, _ = ops.linear_small_bwd(dlv.to(torch.float32).reshape(-1, 1).contiguous(), ctx["f_lv"], w_lv, 1, None, False, None)
+        return {"logvar_linear.weight": g}
+
+    # ------------------------------------------------------------------------------------------------ one training batch
+    def train_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
+                    conditioning_mask: torch.Tensor, format, input_perturbation: Optional[torch.Tensor] = None,
+                    input_perturbation_scale: float = 0.0):
+        """The device part of reference UNetTrainer.unet_train_batch (unet_trainer.py:222-296) with the random draws given:
+        noise / input_perturbation ~ N(0, 1) like `samples`, conditioning_mask [B] bool, sigma [B].
+        Returns (loss [B], grads) where grads holds d mean(loss) / d parameter for EVERY parameter of the module.
+        Not covered (the reference options behind them are off in config/models/default/training/unet_train.json):
+        conditioning_perturbation, use_dynamic_sigma_data, a custom loss_weight -- callers mapping a trainer config onto this path
+        must reject them (training.train_step.check_trainer_config)."""
+        u, cfg, dev = self.u, self.u.config, self.u.device
+        B = samples.shape[0]
+        samples = samples.to(dev, torch.float32).contiguous()
+        sig = sigma.flatten().to(dev, torch.float32).contiguous()
+        emb, ectx = self.embeddings_forward(audio_embeddings, conditioning_mask)
+        # model inputs (unet_trainer.py:249-259)
+        s4 = sig.view(-1, 1, 1, 1)
+        x_in = samples + noise.to(dev, torch.float32) * s4
+        pert = x_in + input_perturbation.to(dev, torch.float32) * s4 * input_perturbation_scale if input_perturbation is not None else None
+        denoised = self.forward(x_in, sig, format, emb, pert)
+        logvar, lctx = self.logvar_forward(sig)
         loss, dD, dlv = ops.edm2_loss(denoised, samples, sig, logvar.view(-1), cfg.sigma_data)
         grads = self.backward(dD)
-        grads["logvar_linear.weight"], _ = ops.linear_small_bwd(dlv.view(B, 1), f_lv, w_lv, 1, None, False, None)
-        # embeddings = mp_sum(u, c, mask) row-wise with mask in {0, 1}: rows pick c (conditioned) or u (dropped)  -- [B, cemb] glue
-        dE = grads.pop("embeddings")
-        t = mask.view(-1, 1)
-        nrm = torch.sqrt((1 - t) ** 2 + t ** 2)
-        dc = (dE * t / nrm).contiguous()
-        du = (dE * (1 - t) / nrm).sum(dim=0, keepdim=True).contiguous()
-        grads["emb_label.weight"], _ = ops.linear_small_bwd(dc, xn, w_c, 1, None, True, None)
-        grads["emb_label_unconditional.weight"], _ = ops.linear_small_bwd(du, ones, w_u, 1, None, True, None)
+        grads.update(self.logvar_backward(dlv, lctx))
+        grads.update(self.embeddings_backward(grads.pop("embeddings"), ectx))
         return loss, self.store_grads(grads)

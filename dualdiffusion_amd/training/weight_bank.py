@@ -151,3 +151,4 @@ class WeightBank:
 
     def normalize(self) -> None:
         self._run(L.WPATH_NORMALIZE)
+        L.bump_weights_epoch()       # raw-pointer write to the master weights: eval-mode prepared-weight caches must refresh

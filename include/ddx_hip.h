@@ -523,6 +523,28 @@ int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t ma
 int ddx_multi_adamw(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, const float* clip_coef, float grad_scale, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float ema_beta, ddx_stream stream);
 
+/* The whole post-backward parameter pass in ONE launch: clip * AdamW, up to DDX_MAX_EMAS EMAs updated in
+ * configuration order with optional feedback into the training weights (reference src/training/ema.py:284-321:
+ * ema <- lerp(ema, p, 1 - beta); p <- lerp(p, ema, 1 - feedback_beta)), then the forced weight normalisation of every row of
+ * a weight-normalised tensor (mp_tools.py:375-378, trainer.py:1105-1108).  rows = output channels (1 for 0-d gains);
+ * ema_beta / feedback_beta are HOST arrays of n_ema floats (feedback_beta < 0: none).  A non-finite gradient norm in
+ * clip_coef[1] skips the step on the device (as ddx_multi_adamw). */
+#define DDX_MAX_EMAS 4
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  float* ema[DDX_MAX_EMAS];   /* or NULL */
+  int64_t n;
+  int64_t rows;
+  int32_t normalize;          /* 1: rows are RMS-normalised after the update */
+  int32_t reserved;
+} ddx_optim_job_ex;
+int ddx_multi_adamw_ema_wn(const ddx_optim_job_ex* jobs_dev, int32_t njobs, int64_t max_rows, const float* clip_coef, float grad_scale,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, int32_t n_ema,
+                           const float* ema_beta, const float* feedback_beta, float norm_eps, ddx_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Launch plans: a recorded sequence of the calls above, replayed with one FFI call and optionally
  * as a hipGraph (the MI355X replacement for the reference's torch.compile, modules/module.py:145-149).

@@ -76,6 +76,125 @@ def test_world_size_2_gloo(tmp_path):
     assert os.path.isfile(tmp_path / "ok0") and os.path.isfile(tmp_path / "ok1")
 
 
+class _StubTrainer:
+    """Stands in for training.unet_grad.UNetTrainer: deterministic gradients written into one flat bucket in two phases (early part,
+    hook, late part) so that UNetTrainStep's control flow (bucket order, hook timing, accumulation, exchange) runs on CPU."""
+
+    def __init__(self, unet):
+        named = list(unet.named_parameters())
+        self.early_numel = named[0][1].numel()
+        self.grad_flat = torch.zeros(sum(p.numel() for _, p in named))
+        self.grad_views, off = {}, 0
+        for k, p in named:
+            self.grad_views[k] = self.grad_flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self.bucket_hook, self.bank, self.calls, self.hook_calls = None, None, [], 0
+
+    def train_batch(self, samples, emb, sigma, noise, mask, fmt, pert, pert_scale):
+        self.calls.append((samples.clone(), sigma.clone()))
+        keys = list(self.grad_views)
+        # "decoder" gradient first: a function of the data and sigma that is linear in per-sample terms (so that the mean over the
+        # global batch is what a single big batch would give)
+        per = samples.flatten(1).mean(1) * sigma                      # [B]
+        self.grad_views[keys[0]].fill_(float(per.mean()))
+        if self.bucket_hook is not None:
+            self.hook_calls += 1
+            self.bucket_hook()
+        self.grad_views[keys[1]].fill_(float((per * 2).mean()))
+        self.grad_views[keys[2]].fill_(float(mask.float().mean()) * 0 + float(per.mean()) * 3)
+        return per.clone(), dict(self.grad_views)
+
+
+class _StubOpt:
+    """Plain SGD with the gradient scale UNetTrainStep passes (loss_scale / (world * accumulation steps))."""
+
+    class cfg:
+        loss_scale = 250.0
+
+    def __init__(self, params):
+        self.params, self.scales = params, []
+
+    def step(self, grads, lr, grad_scale, ema_betas=None):
+        self.scales.append(grad_scale)
+        for k, p in self.params.items():
+            p -= lr * grad_scale * grads[k]
+        return 1.0
+
+
+def _train_worker(rank: int, ws: int, port: int, out_dir: str):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dualdiffusion_amd import distributed as D
+    from dualdiffusion_amd.training.optimizer import LRScheduleConfig
+    from dualdiffusion_amd.training.sigma_sampler import SigmaSampler, SigmaSamplerConfig
+    from dualdiffusion_amd.training.train_step import UNetTrainStep
+    assert D.init(backend="gloo")
+    n_reduce = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (n_reduce.append(t.numel()), real(t, *a, **k))[1]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dec = torch.nn.Parameter(torch.ones(5))
+            self.enc = torch.nn.Parameter(torch.ones(3, 2))
+            self.gain = torch.nn.Parameter(torch.ones(()))
+            self.device, self.n_norm = torch.device("cpu"), 0
+
+        def normalize_weights(self):
+            self.n_norm += 1
+
+    net = Net().requires_grad_(False)
+    tr = _StubTrainer(net)
+    A, Bd = 2, 2
+    step = UNetTrainStep(net, None, lr_schedule=LRScheduleConfig(lr_schedule="constant", learning_rate=1.0, lr_warmup_steps=1), trainer=tr,
+                         optimizer_impl=_StubOpt({k: p.data for k, p in net.named_parameters()}), gradient_accumulation_steps=A,
+                         sigma_sampler=SigmaSampler(SigmaSamplerConfig()), conditioning_dropout=0.1)
+    step.global_step = 1            # (lr multiplier of the constant schedule is 1 from step 1)
+    g = torch.Generator().manual_seed(7)
+    data_all = torch.randn(ws * A * Bd, 1, 2, 2, generator=g)          # the same "dataset" on both ranks; each takes its half
+    local = data_all[rank * A * Bd:(rank + 1) * A * Bd]
+    out = step.run_batch(local, torch.zeros(A * Bd, 4), generator=torch.Generator().manual_seed(100 + rank), sigma_jitter=torch.tensor([0.5]))
+    # sigma: drawn once for the global batch, identical on both ranks (rank 0's), strided per rank and micro-step
+    gs = step.global_sigma
+    ref = SigmaSampler(SigmaSamplerConfig()).sample(ws * A * Bd, jitter=torch.tensor([0.5])).float()
+    assert torch.equal(gs, ref)
+    for a in range(A):
+        assert torch.equal(tr.calls[a][1], ref[rank::ws][a * Bd:(a + 1) * Bd])
+        assert torch.equal(tr.calls[a][0], local[a * Bd:(a + 1) * Bd])
+    # gradients: accumulated locally over the micro-steps, exchanged ONCE (two collectives: early bucket from the hook of the last
+    # micro-step + tail), averaged by the optimizer's scale
+    assert tr.hook_calls == 1 and n_reduce == [5, 7], (tr.hook_calls, n_reduce)
+    assert step.opt.scales == [250.0 / (ws * A)]
+    # expected update: mean over the GLOBAL batch of the per-sample terms
+    per_all = []
+    for r in range(ws):
+        for a in range(A):
+            x = data_all[r * A * Bd:(r + 1) * A * Bd][a * Bd:(a + 1) * Bd]
+            per_all.append((x.flatten(1).mean(1) * ref[r::ws][a * Bd:(a + 1) * Bd]).mean())
+    gmean = torch.stack(per_all).mean()
+    assert torch.allclose(net.dec.data, torch.ones(5) - 250.0 * gmean, atol=1e-5)
+    assert torch.allclose(net.enc.data, torch.ones(3, 2) - 250.0 * 2 * gmean, atol=1e-5)
+    assert torch.allclose(net.gain.data, torch.ones(()) - 250.0 * 3 * gmean, atol=1e-5)
+    # identical weights on both ranks afterwards; one forced weight-norm; one fused scalar gather per micro-step (global micro-batch)
+    w = torch.cat([p.data.flatten() for p in net.parameters()])
+    both = [torch.empty_like(w) for _ in range(ws)]
+    dist.all_gather(both, w)
+    assert torch.equal(both[0], both[1])
+    assert net.n_norm == 1 and len(step.last_gathered) == A and step.last_gathered[0][0].numel() == ws * Bd
+    assert out["loss"].numel() == A * Bd and step.global_step == 2 and step.total_samples_processed == ws * A * Bd
+    D.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"train_ok{rank}"), "w").write("ok")
+
+
+def test_train_step_control_flow_world2_gloo(tmp_path):
+    """UNetTrainStep.run_batch at world_size 2 (gloo, stub differentiation engine): sigma wiring, micro-step accumulation,
+    exchange timing, gradient scale, identical weights on both ranks."""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.isfile(tmp_path / "train_ok0") and os.path.isfile(tmp_path / "train_ok1")
+
+
 def test_single_process_fallbacks():
     from dualdiffusion_amd import distributed as D
     assert D.replica_throughput(7, 0.5) == (7.0, 0.5)

@@ -181,3 +181,24 @@ def test_ddec_golden():
     for k in [k for k in t if k.startswith("stage.")]:
         assert rel_l2(coll[k[6:]].float(), t[k]) < 1e-6, k
     assert rel_l2(DO.ddec_forward(sd, cfg, t["x_in"], t["sigma"], t["x_ref"], compute_dtype=torch.float32), t["out_fp32_oracle"]) < 1e-6
+
+
+def test_ema_step_golden():
+    """Parameter pass after the backward (clip + AdamW + three EMAs incl. power-function and feedback + forced weight norm): the
+    restatement against the reference's torch.optim.AdamW + EMA_Manager.update + normalize run (tests/golden/ema_step)."""
+    from oracle import train_oracle as TO
+    t, m = load_golden("ema_step")
+    names = [k[3:] for k in t if k.startswith("p0.")]
+    p = {k: t[f"p0.{k}"].clone() for k in names}
+    mm, vv = {k: torch.zeros_like(x) for k, x in p.items()}, {k: torch.zeros_like(x) for k, x in p.items()}
+    emas = [({k: x.clone() for k, x in p.items()}, c.get("feedback_beta")) for c in m["emas"].values()]
+    for s in range(m["steps"]):
+        grads = {k: t[f"g{s}.{k}"] for k in names}
+        norm = TO.adamw_ema_wn_step(p, grads, mm, vv, s + 1, m["lr"], m["loss_scale"], m["max_norm"], emas, m["betas"][s], set(m["wn"]))
+        assert abs(norm - m["norms"][s]) / m["norms"][s] < 1e-5
+    for k in names:
+        assert rel_l2(p[k], t[f"p{m['steps']}.{k}"]) < 2e-6, k
+    for (name, _c), (et, _fb) in zip(m["emas"].items(), emas):
+        for k in names:
+            assert rel_l2(et[k], t[f"ema_{name}.{k}"]) < 2e-6, (name, k)
+    assert abs(TO.power_function_beta(0.05, 32, 16) - m["betas"][1][1]) < 1e-12

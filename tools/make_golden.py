@@ -575,6 +575,76 @@ def gen_train() -> None:
                                grads=keep, freq_range=[20.0, 16000.0]))
 
 
+def gen_ema() -> None:
+    """The parameter pass after the backward as the reference runs it (trainer.py:1027-1108): clip_grad_norm_ + torch.optim.AdamW,
+    EMA_Manager.update (ema.py:284-321: classic EMA with warm-up, power-function EMA, feedback EMA, in this order), forced weight
+    normalisation -- three steps on a small module with given gradients."""
+    print("ema")
+    import copy
+    from modules.mp_tools import normalize
+    from training.ema import EMA_Manager, power_function_beta, std_to_exp
+    from oracle import train_oracle as TO
+    g = torch.Generator().manual_seed(91)
+
+    class Net(torch.nn.Module):
+        dtype = torch.float32
+
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Parameter(torch.randn(6, 4, 3, 3, generator=g))
+            self.lin = torch.nn.Parameter(torch.randn(5, 7, generator=g))
+            self.free = torch.nn.Parameter(torch.randn(3, 2, generator=g))     # a tensor without weight norm (logvar_linear-like)
+            self.gain = torch.nn.Parameter(torch.tensor(0.3))
+
+    net = Net()
+    wn = ["conv", "lin"]
+    steps, total_batch, lr, loss_scale, max_norm = 3, 16, 0.05, 250.0, 10.0
+    ema_cfg = {"fast": dict(beta=0.9, num_warmup_steps=2), "pf": dict(std=0.05), "fb": dict(beta=0.99, feedback_beta=0.9)}
+    trainer = types.SimpleNamespace(persistent_state=types.SimpleNamespace(total_samples_processed=0), total_batch_size=total_batch, global_step=0,
+                                    accelerator=types.SimpleNamespace(device=torch.device("cpu"), is_main_process=False),
+                                    config=types.SimpleNamespace(model_path=None))
+    mgr = EMA_Manager("net", net, ema_cfg, trainer)
+    opt = torch.optim.AdamW(net.parameters(), lr=lr, betas=(0.9, 0.99), weight_decay=0.0, eps=1e-8)
+    t = {f"p0.{k}": p.detach().clone() for k, p in net.named_parameters()}
+    # the restatement runs alongside
+    o_p = {k: p.detach().clone() for k, p in net.named_parameters()}
+    o_m, o_v = {k: torch.zeros_like(p) for k, p in o_p.items()}, {k: torch.zeros_like(p) for k, p in o_p.items()}
+    o_emas = [({k: p.clone() for k, p in o_p.items()}, c.get("feedback_beta")) for c in ema_cfg.values()]
+    assert abs(std_to_exp(0.05) - TO.std_to_exp(0.05)) < 1e-9 and abs(std_to_exp(0.25) - TO.std_to_exp(0.25)) < 1e-9
+    norms, betas_all = [], []
+    for s in range(steps):
+        grads = {k: torch.randn(p.shape, generator=g) * (0.02 if s != 1 else 2.0) for k, p in net.named_parameters()}   # step 1 is clipped
+        for k, p in net.named_parameters():
+            p.grad = grads[k] * loss_scale
+            t[f"g{s}.{k}"] = grads[k]
+        norm = float(torch.nn.utils.clip_grad_norm_(list(net.parameters()), max_norm))
+        opt.step()
+        trainer.global_step = s
+        betas = mgr.get_ema_betas()
+        betas["fast"] *= min(s / 2, 1)
+        mgr.update()
+        with torch.no_grad():
+            for k in wn:
+                getattr(net, k).copy_(normalize(getattr(net, k)))
+        trainer.persistent_state.total_samples_processed += total_batch
+        ob = [TO.power_function_beta(0.05, s * total_batch + total_batch, total_batch) if "std" in c else c["beta"] * (min(s / c["num_warmup_steps"], 1) if c.get("num_warmup_steps") else 1)
+              for c in ema_cfg.values()]
+        assert all(abs(a - b) < 1e-12 for a, b in zip(ob, betas.values())), (ob, betas)
+        n2 = TO.adamw_ema_wn_step(o_p, grads, o_m, o_v, s + 1, lr, loss_scale, max_norm, o_emas, ob, set(wn))
+        assert abs(n2 - norm) / norm < 1e-5
+        norms.append(norm)
+        betas_all.append(ob)
+    for k, p in net.named_parameters():
+        check(f"ema step: p.{k}", o_p[k], p.detach(), 2e-6)
+        t[f"p{steps}.{k}"] = p.detach().clone()
+    for (name, mod), (ot, _fb) in zip(mgr.ema_modules.items(), o_emas):
+        for k, p in mod.named_parameters():
+            check(f"ema step: ema_{name}.{k}", ot[k], p.detach(), 2e-6)
+            t[f"ema_{name}.{k}"] = p.detach().clone()
+    save("ema_step", t, dict(steps=steps, total_batch=total_batch, lr=lr, loss_scale=loss_scale, max_norm=max_norm, wn=wn, emas=ema_cfg, norms=norms,
+                             betas=betas_all, adam=[0.9, 0.99, 1e-8]))
+
+
 def gen_ddec() -> None:
     """MCLT diffusion-decoder UNet (modules/unets/unet_edm2_ddec_mclt_b1.py): eval-mode forward, small config."""
     print("ddec")
@@ -621,7 +691,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ddec": gen_ddec}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "ddec": gen_ddec}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
