@@ -44,7 +44,7 @@ def save_config(cfg, path: str) -> None:
 
 
 _DTYPES = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16, "bf16": torch.bfloat16,
-           "float16": torch.bfloat16, "fp16": torch.bfloat16}
+           "float16": torch.float16, "fp16": torch.float16}
 
 
 class DualDiffusionModule(torch.nn.Module, ABC):
@@ -95,8 +95,12 @@ class DualDiffusionModule(torch.nn.Module, ABC):
         if dtype is not None:
             if isinstance(dtype, str):
                 dtype = _DTYPES[dtype]
-            if dtype in (torch.float16, torch.bfloat16):
-                dtype = torch.bfloat16 if type(self).supports_half_precision else torch.float32
+            if dtype in (torch.float16, torch.bfloat16) and not type(self).supports_half_precision:
+                dtype = torch.float32
+            if dtype == torch.float16:
+                # the reference would keep fp16 parameters (module.py:107-111; only .half() means bfloat16, :133-134); the HIP
+                # kernels compute in float32 or bfloat16, so fp16 is refused rather than silently changed
+                raise ValueError("dualdiffusion_amd modules compute in float32 or bfloat16: float16 is not supported (use .half() / bfloat16)")
         if memory_format == torch.channels_last and not type(self).supports_channels_last:
             memory_format = None
         # parameters of this path are at most 4-D weights whose physical layout is re-done by weight preparation,
@@ -106,6 +110,9 @@ class DualDiffusionModule(torch.nn.Module, ABC):
         self.device = device or self.device
         self.memory_format = memory_format or self.memory_format
         self._on_placement_change()
+        if getattr(self, "_normalize_on_placement", False) and self.device.type == "cuda":
+            self._normalize_on_placement = False
+            self.normalize_weights()
         return self
 
     def _on_placement_change(self) -> None:
@@ -136,7 +143,10 @@ class DualDiffusionModule(torch.nn.Module, ABC):
         if not os.path.isfile(ema_path):
             raise FileNotFoundError(f"Error: Could not find ema file '{ema_path}'")
         self.load_state_dict(load_file(ema_path))
-        self.normalize_weights()
+        if self.device.type == "cuda":
+            self.normalize_weights()
+        else:   # the reference normalises on the host (module.py:173); here it is a HIP kernel: done when the module reaches the device
+            self._normalize_on_placement = True
 
     @torch.no_grad()
     def normalize_weights(self) -> None:

@@ -6,8 +6,12 @@ per expression (`ddx_lincomb3`), and there are no per-step `.item()` host syncs 
 """
 from __future__ import annotations
 
+import importlib
+import json
 import math
-from dataclasses import dataclass
+import os
+import re
+from dataclasses import dataclass, field
 from typing import Optional, Union
 
 import numpy as np
@@ -15,6 +19,37 @@ import torch
 
 from .. import ops
 from ..sampling.schedule import SamplingSchedule
+
+
+@dataclass
+class ModuleInventory:
+    """Checkpoints and EMA files found for one module of a model directory (reference dual_diffusion_pipeline.py:113-117)."""
+    name: str
+    checkpoints: list = field(default_factory=list)
+    emas: dict = field(default_factory=dict)
+
+
+def find_emas_in_dir(module_path: str) -> dict:
+    """{ema name: file name} of the `ema_<name>.safetensors` files of a module directory, newest name first (reference ema.py:137-146)."""
+    out = {}
+    if os.path.isdir(module_path):
+        for path in reversed(sorted(os.listdir(module_path))):
+            if os.path.isfile(os.path.join(module_path, path)) and path.startswith("ema_") and path.endswith(".safetensors"):
+                out[path[len("ema_"):-len(".safetensors")]] = path
+    return out
+
+
+def _import_module_class(package: str, cls: str):
+    """model_index.json names the reference's packages (`modules.unets.unet_edm2_b4`); the drop-in classes live under
+    `dualdiffusion_amd.` with the same relative path and class name (INTEGRATION.md section 1 shows the json edit; both spellings load)."""
+    for name in (package, "dualdiffusion_amd." + package):
+        try:
+            mod = importlib.import_module(name)
+        except ImportError:
+            continue
+        if hasattr(mod, cls) and mod.__name__.startswith("dualdiffusion_amd"):
+            return getattr(mod, cls)
+    raise ImportError(f"model_index.json: no dualdiffusion_amd drop-in for {package}.{cls}")
 
 
 @dataclass
@@ -58,6 +93,117 @@ class DualDiffusionPipeline(torch.nn.Module):
             else:
                 setattr(self, name, module)
         self.debug_info: dict = {}
+        self.model_metadata: dict = {}
+
+    # ------------------------------------------------------------------ placement (reference :131-176)
+    def to(self, device=None, dtype=None, memory_format=None, **kwargs) -> "DualDiffusionPipeline":
+        for name, module in self.named_children():
+            pick = lambda v: v.get(name) if isinstance(v, dict) else v      # noqa: E731  (per-module dicts as in the reference)
+            module.to(device=pick(device), dtype=pick(dtype), memory_format=pick(memory_format), **kwargs)
+        return self
+
+    def half(self) -> "DualDiffusionPipeline":
+        for module in self.children():
+            module.to(dtype=torch.bfloat16)
+        return self
+
+    def compile(self, compile_options: Optional[dict] = None) -> None:
+        for module in self.children():
+            if hasattr(module, "compile"):
+                module.compile(**(compile_options or {}))
+
+    # ------------------------------------------------------------------ model directory (reference :178-300)
+    @staticmethod
+    def get_model_module_classes(model_path: str) -> dict:
+        with open(os.path.join(model_path, "model_index.json")) as f:
+            index = json.load(f)
+        return {name: _import_module_class(d["package"], d["class"]) for name, d in index["modules"].items()}
+
+    @staticmethod
+    def get_model_module_inventory(model_path: str) -> dict:
+        with open(os.path.join(model_path, "model_index.json")) as f:
+            index = json.load(f)
+        inv = {}
+        for name in index["modules"]:
+            mi = ModuleInventory(name)
+            for path in os.listdir(model_path):
+                if os.path.isdir(os.path.join(model_path, path)) and name in path.split("_") and "_checkpoint-" in path:
+                    mi.checkpoints.append(path)
+            mi.checkpoints.sort(key=lambda x: int(re.search(r"\d+", x.split("-")[1]).group()))
+            mi.emas[""] = list(find_emas_in_dir(os.path.join(model_path, name)).values())
+            for ck in mi.checkpoints:
+                mi.emas[ck] = list(find_emas_in_dir(os.path.join(model_path, ck, name)).values())
+            inv[name] = mi
+        return inv
+
+    @staticmethod
+    @torch.no_grad()
+    def from_pretrained(model_path: str, torch_dtype=torch.float32, device=None, memory_format="channels_last",
+                        load_checkpoints: Union[dict, bool, None] = False, load_emas: Union[dict, bool, None] = False,
+                        compile_options: Optional[dict] = None) -> "DualDiffusionPipeline":
+        """model_index.json -> module classes -> `{module}/{module}.json` + `.safetensors` (latest checkpoint / EMA on request),
+        as reference dual_diffusion_pipeline.py:230-300."""
+        classes = DualDiffusionPipeline.get_model_module_classes(model_path)
+        inventory = DualDiffusionPipeline.get_model_module_inventory(model_path)
+        if isinstance(load_checkpoints, bool) or load_checkpoints is None:
+            load_checkpoints = {n: mi.checkpoints[-1] for n, mi in inventory.items() if mi.checkpoints} if load_checkpoints else {}
+        if isinstance(load_emas, bool) or load_emas is None:
+            load_emas = ({n: mi.emas[load_checkpoints.get(n, "")][-1] for n, mi in inventory.items() if mi.emas.get(load_checkpoints.get(n, ""))}
+                         if load_emas else {})
+        modules = {}
+        for name, cls in classes.items():
+            module_path = os.path.join(model_path, load_checkpoints.get(name, ""), name)
+            modules[name] = cls.from_pretrained(module_path, load_config_only=name in load_emas)
+            if name in load_emas:
+                modules[name].load_ema(os.path.join(module_path, load_emas[name]), os.path.join(model_path, f"{name}_ema_archive"))
+        if isinstance(memory_format, str):
+            memory_format = getattr(torch, memory_format)
+        pipe = DualDiffusionPipeline(modules).to(device=device, dtype=torch_dtype, memory_format=memory_format)
+        if compile_options is not None:
+            pipe.compile(compile_options)
+        pipe.model_metadata = {"model_path": model_path, "model_module_classes": {n: str(c) for n, c in classes.items()},
+                               "torch_dtype": torch_dtype, "memory_format": memory_format, "load_checkpoints": load_checkpoints,
+                               "load_emas": load_emas, "compile_options": compile_options,
+                               "last_global_step": {n: getattr(getattr(m, "config", None), "last_global_step", 0) for n, m in pipe.named_children()}}
+        return pipe
+
+    @torch.no_grad()
+    def save_pretrained(self, model_path: str, subfolder: Optional[str] = None, save_config_only: bool = False) -> None:
+        if subfolder is not None:
+            model_path = os.path.join(model_path, subfolder)
+        os.makedirs(model_path, exist_ok=True)
+        index = {}
+        for name, module in self.named_children():
+            if hasattr(module, "save_pretrained"):
+                index[name] = {"package": type(module).__module__, "class": type(module).__name__}
+                module.save_pretrained(model_path, subfolder=name, save_config_only=save_config_only)
+        with open(os.path.join(model_path, "model_index.json"), "w") as f:
+            json.dump({"modules": index}, f, indent=2)
+
+    # ------------------------------------------------------------------ shapes (reference :326-348)
+    def _encoder(self):
+        return getattr(self, "dae", None) or getattr(self, "vae", None)
+
+    def get_mel_spec_shape(self, bsz: int = 1, raw_length: Optional[int] = None) -> tuple:
+        fmt = self.format
+        if hasattr(fmt, "get_mel_spec_shape"):
+            shape = fmt.get_mel_spec_shape(bsz=bsz, raw_length=raw_length)
+        elif hasattr(fmt, "get_mdct_shape"):
+            shape = fmt.get_mdct_shape(bsz=bsz, raw_length=raw_length)
+        else:
+            shape = fmt.get_sample_shape(bsz=bsz, length=raw_length)           # SpectrogramFormat of the default model
+        enc = self._encoder()
+        if enc is None:
+            return tuple(shape)
+        latent = self.get_latent_shape(shape)
+        return tuple(enc.get_mel_spec_shape(latent) if hasattr(enc, "get_mel_spec_shape") else enc.get_sample_shape(latent))
+
+    def get_latent_shape(self, mel_spec_shape) -> Optional[torch.Size]:
+        enc = self._encoder()
+        if enc is None:
+            return None
+        latent = enc.get_latent_shape(mel_spec_shape)
+        return self.unet.get_latent_shape(latent) if hasattr(self, "unet") else latent
 
     @torch.no_grad()
     def diffusion_decode(self, params: SampleParams, quiet: bool = False, audio_embedding: Optional[torch.Tensor] = None,
@@ -72,10 +218,11 @@ class DualDiffusionPipeline(torch.nn.Module):
         p.sigma_max = p.sigma_max or unet.config.sigma_max
         p.sigma_min = p.sigma_min or unet.config.sigma_min
         p.sigma_data = p.sigma_data or unet.config.sigma_data
-        if p.seamless_loop:
-            raise NotImplementedError("seamless_loop sampling is not available on the HIP path yet")
         dev, B = unet.device, p.batch_size
         gen = torch.Generator(device=dev).manual_seed(p.seed)
+        np_gen = np.random.default_rng(p.seed)
+        if p.length is None and fmt is not None and hasattr(getattr(fmt, "config", None), "default_raw_length"):
+            p.length = fmt.config.default_raw_length
 
         emb = None
         if audio_embedding is not None:
@@ -86,8 +233,11 @@ class DualDiffusionPipeline(torch.nn.Module):
             sample_shape = tuple(sample_shape or x_ref.shape)
             ref_in = (x_ref.repeat(2, 1, 1, 1) if emb is not None else x_ref).to(dev, torch.float32).contiguous()
         else:
-            if sample_shape is None:
-                raise ValueError("sample_shape is required (no format-derived default on this path)")
+            if sample_shape is None:      # reference :617-622: the format's shape for the requested length, through the encoder
+                if fmt is None:
+                    raise ValueError("sample_shape is required when the pipeline has no format")
+                mel = self.get_mel_spec_shape(bsz=B, raw_length=p.length)
+                sample_shape = self.get_latent_shape(mel) if self._encoder() is not None else mel
             ref_in = None
         sample_shape = tuple(sample_shape)
 
@@ -132,6 +282,8 @@ class DualDiffusionPipeline(torch.nn.Module):
                 return ops.lincomb3(out, y[:B].contiguous(), p.cfg_scale, y[B:].contiguous(), 1.0 - p.cfg_scale)
             return out.copy_(y)
 
+        if p.seamless_loop:
+            return self._decode_seamless(p, steps, sig_table, sample, ref_in, unet, fmt, emb, B, np_gen, draw)
         for i, (s_curr, t_hat, t, noise_gain) in enumerate(steps):
             guided(sample, sig_table[i, 0], cfg)
             if p.use_heun:
@@ -142,4 +294,40 @@ class DualDiffusionPipeline(torch.nn.Module):
                 ops.lincomb3(sample, cfg, 1.0 - t, sample, t, draw(1 + i), noise_gain)
             else:
                 ops.lincomb3(sample, cfg, 1.0 - t, sample, t)
+        return sample
+
+    def _decode_seamless(self, p, steps, sig_table, sample, ref_in, unet, fmt, emb, B, np_gen, draw) -> torch.Tensor:
+        """seamless_loop (reference :651-658, :729-732): every step rolls the sample (and the reference input) by a random shift
+        along the time axis, pads 32 wrapped columns on either side, denoises the padded tensor and undoes both -- the UNet
+        never sees a seam at a fixed place.  Tensor surgery (roll / cat / crop) as in the reference; the step algebra stays on
+        ddx_lincomb3."""
+        PADW = 32
+
+        def wrap(x, shift):
+            x = torch.roll(x, shifts=shift, dims=-1)
+            return torch.cat((x[..., -PADW:], x, x[..., :PADW]), dim=-1).contiguous()
+
+        def unwrap(x, shift):
+            return torch.roll(x[..., PADW:-PADW], shifts=-shift, dims=-1).contiguous()
+
+        def guided(x, sig_row, ref):
+            x2 = x.repeat(2, 1, 1, 1) if emb is not None else x
+            y = unet(x2, sig_row, fmt, emb, ref)
+            if emb is not None:
+                return ops.lincomb3(torch.empty_like(x), y[:B].contiguous(), p.cfg_scale, y[B:].contiguous(), 1.0 - p.cfg_scale)
+            return y
+
+        for i, (s_curr, t_hat, t, noise_gain) in enumerate(steps):
+            shift = int(np_gen.integers(0, sample.shape[-1]))
+            xs = wrap(sample, shift)
+            ref = wrap(ref_in, shift) if ref_in is not None else None
+            cfg = guided(xs, sig_table[i, 0], ref)
+            if p.use_heun:
+                x_hat = ops.lincomb3(torch.empty_like(xs), cfg, 1.0 - t_hat, xs, t_hat)
+                cfg_hat = guided(x_hat, sig_table[i, 1], ref)
+                ops.lincomb3(cfg, cfg, 0.5, cfg_hat, 0.5)
+            ops.lincomb3(xs, cfg, 1.0 - t, xs, t)
+            sample = unwrap(xs, shift)
+            if noise_gain > 0:
+                ops.lincomb3(sample, sample, 1.0, draw(1 + i), noise_gain)
         return sample

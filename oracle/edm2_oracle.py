@@ -391,23 +391,39 @@ def schedule_edm2(steps: int, sigma_max: float, sigma_min: float, rho: float = 7
 
 def sampler_edm2(denoise, sample_shape, noises: list, *, num_steps: int, sigma_max: float, sigma_min: float, sigma_data: float = 1.0,
                  rho: float = 7.0, cfg_scale: float = 1.5, use_heun: bool = True, input_perturbation: float = 1.0,
-                 input_perturbation_offset: float = 0.0, batch_size: int = 1, conditioned: bool = True):
+                 input_perturbation_offset: float = 0.0, batch_size: int = 1, conditioned: bool = True,
+                 x_ref: Optional[torch.Tensor] = None, seamless_seed: Optional[int] = None):
     """pipelines/dual_diffusion_pipeline.py:589-752 (diffusion_decode), with the random draws injected:
     `noises[0]` is the initial noise, `noises[1:]` the ancestral noise of steps 0..num_steps-2.
-    `denoise(x, sigma_vector)` is the UNet call at batch 2B (cond rows first) when `conditioned`, else at batch B.
+    `denoise(x, sigma_vector)` is the UNet call at batch 2B (cond rows first) when `conditioned`, else at batch B;
+    with `x_ref` it is called as denoise(x, sigma_vector, ref) (ref repeated to 2B like the sample).
+    `seamless_seed`: seamless_loop (:651-658, :729-732) -- per-step random roll (numpy default_rng(seed), as the reference) and
+    32 wrapped columns of padding around the sample and the reference input.
     Returns (final sample, sigma schedule list)."""
+    import numpy as np
     sched = schedule_edm2(num_steps, sigma_max, sigma_min, rho)
     sig = sched.tolist()
     sample = noises[0] * (sched[0] ** 2 + sigma_data ** 2) ** 0.5
     B = batch_size
+    ref = None if x_ref is None else (x_ref.repeat(2, 1, 1, 1) if conditioned else x_ref)
+    rng = np.random.default_rng(seamless_seed) if seamless_seed is not None else None
 
     def guided(x, s):
+        extra = () if ref is None else (ref,)
         if conditioned:
-            out = denoise(x.repeat(2, 1, 1, 1), torch.tensor([s] * B * 2)).float()
+            out = denoise(x.repeat(2, 1, 1, 1), torch.tensor([s] * B * 2), *extra).float()
             return torch.lerp(out[B:], out[:B], cfg_scale)
-        return denoise(x, torch.tensor([s] * B)).float()
+        return denoise(x, torch.tensor([s] * B), *extra).float()
 
     for i, (s_curr, s_next) in enumerate(zip(sig[:-1], sig[1:])):
+        shift = None
+        if rng is not None:
+            shift = int(rng.integers(0, sample.shape[-1]))
+            sample = torch.roll(sample, shifts=shift, dims=-1)
+            sample = torch.cat((sample[..., -32:], sample, sample[..., :32]), dim=-1)
+            if ref is not None:
+                ref = torch.roll(ref, shifts=shift, dims=-1)
+                ref = torch.cat((ref[..., -32:], ref, ref[..., :32]), dim=-1)
         old_next = s_next
         ipo = math.log(s_curr) + input_perturbation_offset
         eff = (math.tanh(ipo) / 2 + 0.5) * float(input_perturbation)        # :683-693
@@ -419,6 +435,10 @@ def sampler_edm2(denoise, sample_shape, noises: list, *, num_steps: int, sigma_m
             out = torch.lerp(out, out_hat, 0.5)
         t = s_next / s_curr if (i + 1) < num_steps else 0
         sample = torch.lerp(out, sample, t)                                  # :723-724
+        if shift is not None:                                                # :729-732
+            sample = torch.roll(sample[..., 32:-32], shifts=-shift, dims=-1)
+            if ref is not None:
+                ref = torch.roll(ref[..., 32:-32], shifts=-shift, dims=-1)
         if i + 1 < num_steps:                                                # :734-737
             p = max(old_next ** 2 - s_next ** 2, 0) ** 0.5
             sample = sample + p * noises[1 + i]

@@ -47,3 +47,75 @@ def test_lincomb3():
     xc = x.cuda()
     ops.lincomb3(xc, xc, 0.5)
     assert rel_l2(xc, 0.5 * x) < 1e-7
+
+
+def test_seamless_loop_matches_reference():
+    """seamless_loop (per-step random roll + 32 wrapped columns, reference dual_diffusion_pipeline.py:651-658,729-732) with a reference
+    input (x_ref), against the reference's own output."""
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams
+    t, m = load_golden("sampler")
+    cfg = O.unet_cfg(**m["cfg"])
+    unet = UNet(UNetConfig(**m["cfg"])).requires_grad_(False).train(False)
+    unet.load_state_dict(O.random_unet_state(cfg, m["seed"]))
+    unet = unet.to(device="cuda", dtype=torch.float32)
+
+    class Fmt:
+        ms_freq_scale = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+    pipe = DualDiffusionPipeline({"unet": unet, "format": Fmt()})
+    params = SampleParams(seed=4321, num_steps=3, batch_size=m["B"], sigma_max=m["sigma_max"], sigma_min=m["sigma_min"], sigma_data=1.0, rho=7.0,
+                          schedule="edm2", seamless_loop=True, use_heun=True, cfg_scale=1.5, input_perturbation=1.0)
+    out = pipe.diffusion_decode(params, quiet=True, audio_embedding=t["clap"], sample_shape=tuple(m["shape"]), x_ref=t["seamless.x_ref"],
+                                noises=[t[f"seamless.noise{i}"] for i in range(3)])
+    e = rel_l2(out, t["seamless.out"])
+    print(f"sampler seamless_loop: rel-L2 {e:.3e}")
+    assert e < 1e-4
+
+
+def test_pipeline_from_pretrained_roundtrip(tmp_path):
+    """save_pretrained -> model_index.json (reference package names) -> from_pretrained with checkpoint / EMA selection; the
+    format-derived default sample shape of diffusion_decode (reference :230-300, :326-348, :617-622)."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.modules.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config
+    from dualdiffusion_amd.pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams
+    ts, ms = load_golden("sampler")
+    _tv, vm = load_golden("vae_small")
+    ucfg, vcfg = O.unet_cfg(**ms["cfg"]), O.vae_cfg(**vm["cfg"])
+    unet = UNet(UNetConfig(**ms["cfg"]))
+    unet.load_state_dict(O.random_unet_state(ucfg, ms["seed"]))
+    vae = AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**vm["cfg"]))
+    vae.load_state_dict(O.random_vae_state(vcfg, vm["seed"]))
+    fmt = SpectrogramFormat(SpectrogramFormatConfig())
+    root = str(tmp_path / "model")
+    DualDiffusionPipeline({"unet": unet, "vae": vae, "format": fmt}).save_pretrained(root)
+    idx = json.load(open(os.path.join(root, "model_index.json")))
+    assert idx["modules"]["unet"] == {"package": "dualdiffusion_amd.modules.unets.unet_edm2_b4", "class": "UNet"}
+    # the reference spells the packages without our prefix: both load
+    for d in idx["modules"].values():
+        d["package"] = d["package"][len("dualdiffusion_amd."):]
+    json.dump(idx, open(os.path.join(root, "model_index.json"), "w"))
+    # a later checkpoint of the unet with an EMA file
+    ck = os.path.join(root, "unet_checkpoint-200", "unet")
+    os.makedirs(ck)
+    unet.save_pretrained(ck)
+    ema_sd = {k: v * 1.5 if v.ndim >= 2 else v for k, v in unet.state_dict().items()}      # un-normalised on purpose: load_ema re-normalises
+    save_file({k: v.contiguous() for k, v in ema_sd.items()}, os.path.join(ck, "ema_0.9999.safetensors"))
+    inv = DualDiffusionPipeline.get_model_module_inventory(root)
+    assert inv["unet"].checkpoints == ["unet_checkpoint-200"] and inv["unet"].emas["unet_checkpoint-200"] == ["ema_0.9999.safetensors"]
+    pipe = DualDiffusionPipeline.from_pretrained(root, torch_dtype=torch.float32, device="cuda", load_checkpoints=True, load_emas=True)
+    assert type(pipe.unet).__name__ == "UNet" and pipe.unet.device.type == "cuda"
+    assert pipe.model_metadata["load_emas"] == {"unet": "ema_0.9999.safetensors"}
+    w = pipe.unet.state_dict()["enc.block0_layer0.conv_res0.weight"]
+    assert rel_l2(w, O.rms_normalize(ema_sd["enc.block0_layer0.conv_res0.weight"])) < 1e-6
+    # default sample shape: format -> vae latent shape -> unet latent shape
+    mel = pipe.get_mel_spec_shape(bsz=2, raw_length=256 * 200)     # 201 frames -> cropped to 128
+    lat = pipe.get_latent_shape(mel)
+    assert tuple(mel) == (2, 2, 256, 128) and tuple(lat) == (2, 4, 64, 32), (mel, lat)
+    params = SampleParams(seed=3, num_steps=2, batch_size=2, length=256 * 200, sigma_max=20.0, sigma_min=0.1, sigma_data=1.0)
+    out = pipe.diffusion_decode(params, audio_embedding=ts["clap"])
+    assert tuple(out.shape) == (2, 4, 64, 32) and torch.isfinite(out).all()

@@ -364,6 +364,21 @@ def gen_sampler() -> None:
         t[f"{case}.out"] = ref
         for i, n in enumerate(noises):
             t[f"{case}.noise{i}"] = n
+    # seamless_loop (:651-658, :729-732): needs a reference input in the reference (it rolls it unconditionally)
+    x_ref = torch.cat([torch.randn(B, 4, 32, 32, generator=g), torch.rand(B, 1, 32, 32, generator=g)], dim=1)
+    params = SampleParams(seed=4321, num_steps=3, batch_size=B, length=1, sigma_max=80.0, sigma_min=0.05, sigma_data=1.0, rho=7.0, schedule="edm2",
+                          seamless_loop=True, use_heun=True, cfg_scale=1.5, input_perturbation=1.0)
+    with torch.no_grad():
+        ref = DualDiffusionPipeline.diffusion_decode(fake, params, quiet=True, audio_embedding=clap, sample_shape=shape, x_ref=x_ref, module=unet)
+    gen = torch.Generator().manual_seed(4321)
+    noises = [torch.randn(shape, generator=gen) for _ in range(3)]
+    den = lambda x, s, r: O.unet_forward(sd, tiny, x, s, emb, x_ref=r)
+    ours, _ = O.sampler_edm2(den, shape, noises, num_steps=3, sigma_max=80.0, sigma_min=0.05, batch_size=B, cfg_scale=1.5, use_heun=True,
+                             input_perturbation=1.0, x_ref=x_ref, seamless_seed=4321)
+    check("sampler seamless", ours, ref, 2e-5)
+    t["seamless.out"], t["seamless.x_ref"] = ref, x_ref
+    for i, n in enumerate(noises):
+        t[f"seamless.noise{i}"] = n
     t["embeddings"] = emb
     save("sampler", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in tiny.items()}, seed=0, B=B, shape=list(shape),
                             cases={"heun": dict(use_heun=True, cfg_scale=1.5, input_perturbation=1.0, input_perturbation_offset=0.0),
