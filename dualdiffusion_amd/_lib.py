@@ -75,6 +75,14 @@ class MelStftDesc(C.Structure):
                 ("n_mel", C.c_int32), ("band_stride", C.c_int32), ("exponent", C.c_float), ("mean", C.c_float), ("scale", C.c_float)]
 
 
+class MsMelDesc(C.Structure):
+    _fields_ = [("audio", C.c_void_p), ("window_low", C.c_void_p), ("window_high", C.c_void_p), ("twiddle", C.c_void_p),
+                ("bin_scale_low", C.c_void_p), ("bin_scale_high", C.c_void_p), ("band_start", C.c_void_p), ("band_len", C.c_void_p),
+                ("band_w", C.c_void_p), ("out", C.c_void_p),
+                ("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("T", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
+                ("n_mel", C.c_int32), ("band_stride", C.c_int32), ("exponent", C.c_float), ("scale", C.c_float), ("offset", C.c_float)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x0", C.c_void_p), ("x1", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
                 ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32), ("Cout", C.c_int32),
@@ -154,6 +162,7 @@ PROTOTYPES = {
     "ddx_unet_output_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_mel_stft": (C.c_int, [C.POINTER(MelStftDesc), C.c_void_p]),
+    "ddx_ms_mel_spec": (C.c_int, [C.POINTER(MsMelDesc), C.c_void_p]),
     "ddx_mel_to_amplitude": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "ddx_fgla_synth": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),

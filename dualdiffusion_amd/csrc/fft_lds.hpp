@@ -142,6 +142,18 @@ __device__ __forceinline__ void fft6400_inplace(cf* a, const float2* __restrict_
   fft_stage_inplace<N, 5, INV, NT>(a, 25, 256, tw, tid);
   fft_stage_inplace<N, 5, INV, NT>(a, 5, 1280, tw, tid);
 }
+// N = 4096 = 4^6 (the 128 ms frames of MS_MDCT_DualFormat's mel spectrogram, reference formats/ms_mdct_dual.py:110-139)
+template <bool INV, int NT>
+__device__ __forceinline__ void fft4096_inplace(cf* a, const float2* __restrict__ tw, int tid) {
+  constexpr int N = 4096;
+  __syncthreads();
+  fft_stage_inplace<N, 4, INV, NT>(a, 4096, 1, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 1024, 4, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 256, 16, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 64, 64, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 16, 256, tw, tid);
+  fft_stage_inplace<N, 4, INV, NT>(a, 4, 1024, tw, tid);
+}
 __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 
 }  // namespace ddx

@@ -223,39 +223,48 @@ class UNet(DualDiffusionUNet):
 # ====================================================================================================== engines
 
 class _SmallOps:
-    """Eager helpers for the small host-called methods (get_embeddings, get_sigma_loss_logvar)."""
+    """Eager helpers for the small host-called methods (get_embeddings, get_sigma_loss_logvar).  Buffers and job tables are kept
+    per batch size, so a call enqueues its launches and returns without synchronising the stream."""
 
     def __init__(self, unet: UNet):
         self.u = unet
+        self._emb: dict = {}
+        self._lv: dict = {}
 
     def embeddings(self, emb_in: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         u, dev = self.u, self.u.device
         B = emb_in.shape[0]
+        st = self._emb.get((B, u.training))
+        if st is None:
+            ones = torch.ones(1, 1, device=dev, dtype=torch.float32)
+            uemb = torch.empty(1, u.cemb, device=dev, dtype=torch.float32)
+            cemb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
+            t1 = ops.make_linear_jobs([(u.emb_label_unconditional.weight, None, uemb, 1.0, 0.0, 1, u.training)], dev)
+            t2 = ops.make_linear_jobs([(u.emb_label.weight, None, cemb, 1.0, 0.0, 1, u.training)], dev)
+            st = self._emb[(B, u.training)] = (ones, uemb, cemb, t1, t2)
+        ones, uemb, cemb, t1, t2 = st
         x = emb_in.to(device=dev, dtype=torch.float32).contiguous()
         xn = ops.pixelnorm(x)
-        ones = torch.ones(1, 1, device=dev, dtype=torch.float32)
-        uemb = torch.empty(1, u.cemb, device=dev, dtype=torch.float32)
-        cemb = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
-        t1 = ops.make_linear_jobs([(u.emb_label_unconditional.weight, None, uemb, 1.0, 0.0, 1, u.training)], dev)
         ops.linear_small(t1, 1, u.cemb, ones, 1, u.emb_label_unconditional.weight.dtype)
-        t2 = ops.make_linear_jobs([(u.emb_label.weight, None, cemb, 1.0, 0.0, 1, u.training)], dev)
         ops.linear_small(t2, 1, u.cemb, xn, B, u.emb_label.weight.dtype)
         out = torch.empty(B, u.cemb, device=dev, dtype=torch.float32)
         ops.mpsum_rows(uemb, cemb, out, t_rows=mask.to(device=dev, dtype=torch.float32).contiguous())
-        torch.cuda.current_stream().synchronize()  # job tables are temporaries
         return out.to(u.dtype)
 
     def logvar(self, sigma: torch.Tensor) -> torch.Tensor:
         u, dev = self.u, self.u.device
         s = sigma.flatten().to(device=dev, dtype=torch.float32).contiguous()
         B = s.numel()
+        st = self._lv.get(B)
+        if st is None:
+            out = torch.empty(B, 1, device=dev, dtype=torch.float32)
+            st = self._lv[B] = (out, ops.make_linear_jobs([(u.logvar_linear.weight, None, out, 1.0, 0.0, 1, False)], dev),
+                                u.logvar_fourier.freqs.float().contiguous(), u.logvar_fourier.phases.float().contiguous())
+        out, table, freqs, phases = st
         f = torch.empty(B, u.config.logvar_channels, device=dev, dtype=torch.float32)
-        ops.mpfourier(s, u.logvar_fourier.freqs.float(), u.logvar_fourier.phases.float(), f, True)
-        out = torch.empty(B, 1, device=dev, dtype=torch.float32)
-        t = ops.make_linear_jobs([(u.logvar_linear.weight, None, out, 1.0, 0.0, 1, False)], dev)
-        ops.linear_small(t, 1, 1, f, B, u.logvar_linear.weight.dtype)
-        torch.cuda.current_stream().synchronize()
-        return out.view(-1, 1, 1, 1)
+        ops.mpfourier(s, freqs, phases, f, True)
+        ops.linear_small(table, 1, 1, f, B, u.logvar_linear.weight.dtype)
+        return out.clone().view(-1, 1, 1, 1)
 
 
 class _UNetEngine:

@@ -425,6 +425,27 @@ typedef struct {
 
 int ddx_mel_stft(const ddx_melstft_desc* d, ddx_stream stream);
 
+/* Dual-window mel-scale spectrogram of MS_MDCT_DualFormat (reference src/modules/formats/ms_mdct_dual.py:229-257): per frame
+ * mel[m] = (sum_k band_w[m][k] * (bin_scale_low[k] * |STFT_low[k]| + bin_scale_high[k] * |STFT_high[k]|)) ** exponent * scale + offset
+ * with window_low / window_high already divided by their L2 norms (torchaudio normalized="window"), bin_scale_low = blend / density,
+ * bin_scale_high = (1 - blend) / density ([n_fft/2 + 1] fp32 host tables), center = True reflect padding, hop-spaced frames.
+ * audio [B][C][L] fp32 -> out [B][C][n_mel][T] fp32.  n_fft = 4096 is built. */
+typedef struct {
+  const float* audio;
+  const float* window_low;
+  const float* window_high;
+  const float* twiddle;         /* [n_fft][2] cos / -sin table of exp(-2 pi i t / n_fft) */
+  const float* bin_scale_low;
+  const float* bin_scale_high;
+  const int32_t* band_start;    /* [n_mel] first STFT bin of every filter */
+  const int32_t* band_len;      /* [n_mel] number of bins */
+  const float* band_w;          /* [n_mel][band_stride] filter values */
+  float* out;
+  int32_t B, C, L, T, n_fft, hop, n_mel, band_stride;
+  float exponent, scale, offset;
+} ddx_msmel_desc;
+int ddx_ms_mel_spec(const ddx_msmel_desc* d, ddx_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * FGLA stereo phase reconstruction  (modules/formats/old/phase_recovery.py:39-129 `griffinlim`; decode half of
  * SpectrogramFormat.sample_to_raw, spectrogram.py:181-185,228-238).  n_fft = 6400 only.

@@ -109,3 +109,57 @@ def mel_to_raw(samples: torch.Tensor, *, window: torch.Tensor, hop: int, filters
     """spectrogram.py:228-238,181-185: undo the affine + exponent, un-mel, FGLA."""
     amp = (samples / scale + mean).clip(min=0) ** (1 / exponent)
     return griffinlim(unmel(amp, filters), window, hop, n_iter, momentum, stereo_coherence, dtype)
+
+
+# ----------------------------------------------------------------------------- MS_MDCT_DualFormat.raw_to_mel_spec (a-10 sibling)
+
+def blackman_harris_window(n: int, exponent: float) -> torch.Tensor:
+    """utils/mclt.py:69-71 (periodic 4-term Blackman-Harris) ** exponent, formats/ms_mdct_dual.py:91-95."""
+    x = torch.arange(n) / n * 2 * torch.pi
+    return (0.35875 - 0.48829 * torch.cos(x) + 0.14128 * torch.cos(2 * x) - 0.01168 * torch.cos(3 * x)) ** exponent
+
+
+def mel_density(hz: torch.Tensor) -> torch.Tensor:
+    """frequency_scale.py:36-37."""
+    return 1127.0 / (700.0 + hz)
+
+
+def slaney_mel_filterbank(n_stft: int, n_mel: int, fmin: float, fmax: float, sample_rate: int) -> torch.Tensor:
+    """frequency_scale.py:151-168 with filter_norm='slaney' (triangular)."""
+    fb = mel_filterbank(n_stft, n_mel, fmin, fmax, sample_rate)
+    mels = torch.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mel + 2)
+    pts = 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    return fb * (2.0 / (pts[2:n_mel + 2] - pts[:n_mel])).unsqueeze(0)
+
+
+def raw_to_ms_mel_spec(audio: torch.Tensor, *, n_fft: int = 4096, hop: int = 256, n_mel: int = 256, sample_rate: int = 32000,
+                       exp_low: float = 17.0, exp_high: float = 58.0, abs_exponent: float = 1.0, scale: float = 50.0, offset: float = 0.0,
+                       freq_min: float = 0.0) -> torch.Tensor:
+    """formats/ms_mdct_dual.py:229-257 (the non-sliced branch; ms_freq_min = 0 makes _high_pass the identity, :187-192):
+    two window-normalised magnitude STFTs (torchaudio Spectrogram(power=1, normalized='window') == |torch.stft| / sqrt(sum w^2)),
+    blended per bin by (mel density / max)^2, divided by the mel density, slaney mel bank, ** exponent * scale + offset."""
+    nb = n_fft // 2 + 1
+    hz = torch.linspace(0, sample_rate / 2, nb)
+    dens = mel_density(hz).view(1, 1, -1, 1)
+    blend = ((mel_density(hz) / mel_density(hz).amax()) ** 2).view(1, 1, -1, 1)
+    specs = []
+    for e in (exp_low, exp_high):
+        w = blackman_harris_window(n_fft, e)
+        specs.append(stft_frames(audio.float(), w, hop).abs() / w.pow(2).sum().sqrt())
+    blended = specs[0] * blend + specs[1] * (1 - blend)
+    fb = slaney_mel_filterbank(nb, n_mel, freq_min, sample_rate / 2, sample_rate)
+    mel = torch.matmul((blended / dens).transpose(-1, -2), fb).transpose(-1, -2)
+    return mel ** abs_exponent * scale + offset
+
+
+def ms_mel_to_mdct_psd(mel_spec: torch.Tensor, *, n_stft: int = 2049, n_mel: int = 256, sample_rate: int = 32000, freq_min: float = 0.0,
+                       abs_exponent: float = 1.0, mel_offset: float = 0.0, scale: float = 0.18, offset: float = 0.0,
+                       dtype: torch.dtype = torch.float64) -> torch.Tensor:
+    """formats/ms_mdct_dual.py:259-271 with mdct_psd_num_bins == n_stft - 1: minimum-norm un-mel (frequency_scale.py:130-142,
+    rectify=False) of the clipped spectrogram, last bin cropped, scaled.  Solved in float64 by default (the reference's float32
+    `gels` solution is a few 1e-4 away from it)."""
+    fb = slaney_mel_filterbank(n_stft, n_mel, freq_min, sample_rate / 2, sample_rate).to(dtype)
+    x = (mel_spec.to(dtype) - mel_offset).clip(min=0) ** (1 / abs_exponent)
+    shp = x.shape
+    sol = torch.linalg.lstsq(fb.t()[None], x.reshape(-1, shp[-2], shp[-1]), driver="gelsd" if dtype == torch.float64 else "gels").solution
+    return (sol.reshape(shp[:-2] + (n_stft, shp[-1]))[:, :, :-1, :] * scale + offset).float()

@@ -124,3 +124,60 @@ def test_fgla_roundtrip_property():
     e = rel_l2(mel2[..., 16:-16], mel.cpu()[..., 16:mel2.shape[-1] - 16])
     print(f"mel(decode(mel)) vs mel: {e:.3e}")
     assert e < 0.15
+
+
+def test_ms_mel_spec_matches_reference():
+    """MS_MDCT_DualFormat.raw_to_mel_spec on the HIP kernel (two in-LDS FFT-4096 per frame, blend, banded slaney bank) against the
+    reference's output, its shapes, and mel_spec_to_mdct_psd (un-mel as a constant 1x1 conv)."""
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd.modules.formats.ms_mdct_dual import MS_MDCT_DualFormat, MS_MDCT_DualFormatConfig
+    t, m = load_golden("ms_mel_spec")
+    fmt = MS_MDCT_DualFormat(MS_MDCT_DualFormatConfig()).to(device="cuda")
+    assert fmt.get_raw_crop_width(1408768) == m["crop_width"] and list(fmt.get_mel_spec_shape(bsz=1)) == m["shape_45s"]
+    mel = fmt.raw_to_mel_spec(t["audio"])
+    e = rel_l2(mel, t["mel"])
+    print(f"ms_mel_spec rel-L2 vs reference {e:.3e}")
+    assert mel.shape == t["mel"].shape and e < 1e-5
+    # mono, and a length whose last workgroup is ragged
+    a1 = t["audio"][:1, :1, :256 * 100 + 17]
+    assert rel_l2(fmt.raw_to_mel_spec(a1), M.raw_to_ms_mel_spec(a1)) < 1e-5
+    psd = fmt.mel_spec_to_mdct_psd(t["mel"])
+    e2 = rel_l2(psd[..., ::16], t["mdct_psd_frames16"])
+    print(f"mel_spec_to_mdct_psd rel-L2 vs reference {e2:.3e}")
+    assert psd.shape == (2, 2, 2048, 128) and e2 < 2e-3     # (the reference's float32 gels solve is itself ~1e-4 off float64)
+    # ln_freqs of the UNet come from this format's scale (unet_edm2_b4.py:246)
+    assert fmt.ms_freq_scale.num_stft_bins == 2049 and fmt.ms_freq_scale.filter_norm == "slaney"
+
+
+def test_unmel_and_one_fgla_iteration_vs_fixture():
+    """un-mel (pseudo-inverse as a 1x1 conv) against the oracle's minimum-norm solve, and ONE FGLA iteration against the reference's
+    waveform fixture bound: the 4-iteration fixture is the only waveform the reference run produced, so the single iteration is
+    judged against the float64 oracle with the float32 oracle's own distance as the yardstick, and the final 4-iteration waveform
+    directly against the fixture with the reference's float32-vs-float64 distance as tolerance."""
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd import ops
+    from dualdiffusion_amd._lib import check, current_stream, lib, ptr
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    t, m = load_golden("mel_stft")
+    g, gm = load_golden("fgla")
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
+    mel = t["mel"][:1]
+    c = fmt.config
+    B, Cn, n_mel, T = mel.shape
+    amp = torch.empty(B * Cn, 1, T, n_mel, device="cuda")
+    check(lib().ddx_mel_to_amplitude(ptr(mel.cuda().contiguous()), ptr(amp), B * Cn, n_mel, T, c.raw_to_sample_scale, c.sample_mean,
+                                     1.0 / c.abs_exponent, current_stream()))
+    mags = ops.conv2d(amp, fmt._unmel_weights())[..., :c.num_stft_bins]          # [B*C][1][T][nb]
+    fb = M.mel_filterbank(3201, 256, 20.0, 16000.0, 32000)
+    amp_ref = ((mel / c.raw_to_sample_scale + c.sample_mean).clamp(min=0) ** (1 / c.abs_exponent))
+    ref = M.unmel(amp_ref.double(), fb.double()).float()                          # (B, C, nb, T): lstsq + relu
+    got = torch.relu(mags).view(B, Cn, T, -1).permute(0, 1, 3, 2)
+    e = rel_l2(got, ref)
+    print(f"un-mel (pinv conv + relu) vs minimum-norm lstsq: {e:.3e}")
+    assert e < 2e-4
+    win = M.hann_power_window(6400, 32.0)
+    raw = fmt.sample_to_raw(mel, n_fgla_iters=gm["n_iter"], quiet=True)
+    truth = M.mel_to_raw(mel, window=win, hop=256, filters=fb, n_iter=gm["n_iter"], stereo_coherence=0.67, dtype=torch.float64)
+    e_fix, e_ref = rel_l2(raw, g["default.raw"]), rel_l2(g["default.raw"], truth)
+    print(f"FGLA x{gm['n_iter']}: HIP vs the reference's waveform {e_fix:.3e} (reference fp32 vs fp64: {e_ref:.3e})")
+    assert e_fix < 2.5 * e_ref + 1e-3

@@ -202,3 +202,17 @@ def test_ema_step_golden():
         for k in names:
             assert rel_l2(et[k], t[f"ema_{name}.{k}"]) < 2e-6, (name, k)
     assert abs(TO.power_function_beta(0.05, 32, 16) - m["betas"][1][1]) < 1e-12
+
+
+def test_ms_mel_spec_golden():
+    """MS_MDCT_DualFormat.raw_to_mel_spec (dual-window mel spectrogram of the live format) and mel_spec_to_mdct_psd: the restatement
+    against the reference's outputs; the slaney bank's integer band edges through the host table class."""
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    t, m = load_golden("ms_mel_spec")
+    assert rel_l2(M.raw_to_ms_mel_spec(t["audio"]), t["mel"]) < 2e-5
+    assert rel_l2(M.ms_mel_to_mdct_psd(t["mel"])[..., ::16], t["mdct_psd_frames16"]) < 2e-3
+    fs = FrequencyScale("mel", 0.0, 16000.0, 32000, 2049, 256, "slaney")
+    assert torch.equal(fs.band_edges(), t["band_edges"]) and int((fs.filters > 0).sum()) == m["nnz"] == 4067
+    assert rel_l2(fs.filters.sum(dim=0), t["filter_colsum"]) < 1e-7
+    assert torch.equal(fs.filters, M.slaney_mel_filterbank(2049, 256, 0.0, 16000.0, 32000))

@@ -473,6 +473,38 @@ def gen_mel() -> None:
     save("fgla", t, dict(n_iter=4, coherence={"default": 0.67, "anneal": 0.3}, note="input = mel_stft.safetensors mel[:1]"))
 
 
+def gen_msmel() -> None:
+    """MS_MDCT_DualFormat.raw_to_mel_spec (formats/ms_mdct_dual.py:229-257) on short stereo audio + the integer band edges of its
+    slaney bank (2049 x 256)."""
+    print("ms_mel_spec")
+    from oracle import mel_oracle as M
+    from modules.formats.ms_mdct_dual import MS_MDCT_DualFormat, MS_MDCT_DualFormatConfig
+    fmt = MS_MDCT_DualFormat(MS_MDCT_DualFormatConfig())
+    g = torch.Generator().manual_seed(57)
+    Lr = 256 * 127
+    audio = torch.randn(2, 2, Lr, generator=g) * 0.1
+    audio[1] *= torch.linspace(0.05, 2.0, Lr)
+    tt = torch.arange(Lr) / 32000.0
+    audio[0, 0] += 0.2 * torch.sin(2 * torch.pi * 220.0 * tt)
+    with torch.no_grad():
+        mel = fmt.raw_to_mel_spec(audio)
+    assert tuple(mel.shape) == (2, 2, 256, 128), mel.shape
+    fb = fmt.ms_freq_scale.filters
+    assert torch.equal(M.slaney_mel_filterbank(2049, 256, 0.0, 16000.0, 32000), fb), "slaney bank differs"
+    assert torch.equal(M.blackman_harris_window(4096, 17.0), fmt.ms_spectrogram_func_low.window)
+    ours = M.raw_to_ms_mel_spec(audio)
+    check("raw_to_mel_spec", ours, mel, 2e-5)
+    nz = fb > 0
+    idx = torch.arange(2049).unsqueeze(1)
+    edges = torch.stack([torch.where(nz, idx, 2049).min(dim=0).values, torch.where(nz, idx, -1).max(dim=0).values], 1).to(torch.int32)
+    assert fmt.get_raw_crop_width() == 1408768 and tuple(fmt.get_mel_spec_shape(bsz=3)) == (3, 2, 256, 5504)
+    with torch.no_grad():
+        psd = fmt.mel_spec_to_mdct_psd(mel)
+    check("mel_spec_to_mdct_psd", M.ms_mel_to_mdct_psd(mel), psd, 2e-3)
+    save("ms_mel_spec", {"audio": audio, "mel": mel, "band_edges": edges, "filter_colsum": fb.sum(dim=0), "mdct_psd_frames16": psd[..., ::16].clone()},
+         dict(n_fft=4096, hop=256, nnz=int(nz.sum()), crop_width=fmt.get_raw_crop_width(1408768), shape_45s=list(fmt.get_mel_spec_shape(bsz=1))))
+
+
 def gen_sigma() -> None:
     """SigmaSampler (training/sigma_sampler.py): every distribution's inverse CDF on stratified quantiles."""
     print("sigma")
@@ -706,7 +738,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "ddec": gen_ddec}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "ddec": gen_ddec}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
