@@ -26,7 +26,8 @@ template <> struct AttnMma<float> {
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
-                                                       const float* __restrict__ out_cs, int B, int Tn, int heads, float eps, int qk_ld, int v_ld) {
+                                                       const float* __restrict__ out_cs, int B, int Tn, int heads, float eps, int qk_ld, int v_ld,
+                                                       int fold) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int VPR = D / EV;           // 16-byte vectors per token row
   constexpr int RPP = 256 / VPR;        // rows staged per pass
@@ -47,6 +48,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   const int l31 = lane & 31, khalf = lane >> 5;
   const int q0 = blockIdx.x * 128;
   const int head = blockIdx.y, b = blockIdx.z;
+  // token t of batch entry b lives in row rbase + t * fold of the [rows][channels] tensors.  fold = 1: the H*W tokens of image b
+  // (rbase = b * T); fold = W > 1: AXIS-FOLDED attention -- the batch entries are the (image, column) pairs of [N][H][W] maps and
+  // the tokens run along H (reference modules/daes/dae_edm2_g1.py:209-228: attention over h for every (b, z, w)).
+  const int b_img = b / fold;
+  const size_t rbase = (size_t)b_img * Tn * fold + (size_t)(b - b_img * fold);
   const int C = heads * D;
   const float inv_sqrt_d = rsqrtf((float)D);
 
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
       VT z = {};
       kreg[i] = z; vreg[i] = z;
       if (key < Tn) {
-        kreg[i] = *reinterpret_cast<const VT*>(qk + ((size_t)b * Tn + key) * qk_ld + head * 2 * D + D + sv * EV);
-        vreg[i] = *reinterpret_cast<const VT*>(v + ((size_t)b * Tn + key) * v_ld + head * D + sv * EV);
+        kreg[i] = *reinterpret_cast<const VT*>(qk + (rbase + (size_t)key * fold) * qk_ld + head * 2 * D + D + sv * EV);
+        vreg[i] = *reinterpret_cast<const VT*>(v + (rbase + (size_t)key * fold) * v_ld + head * D + sv * EV);
       }
     }
   };
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
     const int q = q0 + sr + i * RPP;
     VT z = {};
     qreg[i] = z;
-    if (q < Tn) qreg[i] = *reinterpret_cast<const VT*>(qk + ((size_t)b * Tn + q) * qk_ld + head * 2 * D + sv * EV);
+    if (q < Tn) qreg[i] = *reinterpret_cast<const VT*>(qk + (rbase + (size_t)q * fold) * qk_ld + head * 2 * D + sv * EV);
   }
   issue_kv(0);
 
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   const float inv_l = 1.0f / l_tot;
   const int q = q0 + wave * 32 + l31;
   if (q < Tn) {
-    T* orow = out + ((size_t)b * Tn + q) * C + head * D;
+    T* orow = out + (rbase + (size_t)q * fold) * C + head * D;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
         Vec4<T> ov;
         const int dd = dt * 32 + 8 * g4 + 4 * khalf;
         if (out_cs) {  // producer-side activation of attn_proj's operand: mp_silu(o * c_v)
-          const f32x4 c4v = *reinterpret_cast<const f32x4*>(out_cs + (size_t)b * C + head * D + dd);
+          const f32x4 c4v = *reinterpret_cast<const f32x4*>(out_cs + (size_t)b_img * C + head * D + dd);
 #pragma unroll
           for (int e = 0; e < 4; ++e) ov.set(e, mp_silu_f(oacc[dt][4 * g4 + e] * inv_l * c4v[e]));
         } else {
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 
 template <typename T, int D>
 static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
-                       int v_ld) {
+                       int v_ld, int fold = 1) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int KC = 128;
   const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + (size_t)D * (KC + AttnMma<T>::VPAD)) * sizeof(T);
@@ -266,7 +272,7 @@ static int launch_attn(const void* qk, const void* v, void* out, const float* cs
     attr_done = true;
   }
   dim3 grid((Tn + 127) / 128, heads, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps, qk_ld, v_ld);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps, qk_ld, v_ld, fold);
   return check_launch("attn_fwd");
 }
 
@@ -286,19 +292,27 @@ extern "C" int ddx_attn_act_fwd(const void* qk, const void* v, void* out, const 
 
 extern "C" int ddx_attn_act_fwd_ld(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t B,
                                    int32_t T, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream) {
+  return ddx_attn_fold_fwd(qk, qk_ld, v, v_ld, out, out_scale, B, T, 1, heads, head_dim, eps, dtype, stream);
+}
+
+extern "C" int ddx_attn_fold_fwd(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t N,
+                                 int32_t T, int32_t fold, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream) {
+  if (fold <= 0 || N <= 0 || (int64_t)N * fold > 0x7fffffff) return set_error(DDX_ERR_ARG, "attn: bad fold");
+  const int32_t B = N * fold;
+  if (B > 65535) return set_error(DDX_ERR_UNSUPPORTED, "attn: more than 65535 batch entries (gridDim.z)");
   if (!qk || !v || !out || B <= 0 || T <= 0 || heads <= 0) return set_error(DDX_ERR_ARG, "attn: bad args");
   if (head_dim != 32 && head_dim != 64 && head_dim != 128) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim must be 32, 64 or 128");
   const int ev = dtype == DDX_BF16 ? 8 : 4;
   if (qk_ld < 2 * heads * head_dim || v_ld < heads * head_dim || qk_ld % ev || v_ld % ev) return set_error(DDX_ERR_ARG, "attn: bad row strides");
   return dispatch([=](hipStream_t s) -> int {
     if (dtype == DDX_BF16) {
-      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
-      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
-      return launch_attn<bf16, 128>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
+      if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
+      if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
+      return launch_attn<bf16, 128>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
     }
-    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
-    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
-    return launch_attn<float, 128>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld);
+    if (head_dim == 32) return launch_attn<float, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
+    if (head_dim == 64) return launch_attn<float, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
+    return launch_attn<float, 128>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
   }, stream, "attention", 4.0 * B * heads * (double)T * T * head_dim,
      (double)dtype_size(dtype) * 4.0 * B * T * heads * head_dim);
 }

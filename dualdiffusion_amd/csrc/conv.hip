@@ -61,7 +61,7 @@ extern "C" int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype
 extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
   if (!dp || !dp->w || !dp->wp) return set_error(DDX_ERR_ARG, "wprep: null");
   const ddx_wprep_desc d = *dp;
-  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3) || (d.CK != 16 && d.CK != 32 && d.CK != 64 && d.CK != 128))
+  if (d.groups <= 0 || d.Cout % d.groups || (d.ksize != 1 && d.ksize != 3 && d.ksize != 5) || (d.CK != 16 && d.CK != 32 && d.CK != 64 && d.CK != 128))
     return set_error(DDX_ERR_ARG, "wprep: bad shape");
   if (d.qk_head_dim > 0 && (d.groups != 1 || d.Cout % (2 * d.qk_head_dim))) return set_error(DDX_ERR_ARG, "wprep: bad qk_head_dim");
   if (d.rows_total != 0 && (d.groups != 1 || d.transpose || d.row_offset < 0 || d.row_offset + d.Cout > d.rows_total))
@@ -142,7 +142,8 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   if ((d.C1 > 0) != (d.src1 != nullptr)) return set_error(DDX_ERR_ARG, "conv: src1/C1 mismatch");
   const int Cin = (d.C0 + d.C1) * ((d.pad_mode & DDX_PAD_SWAP_PAIRED) ? 2 : 1);
   if (Cin % d.groups || d.Cout % d.groups) return set_error(DDX_ERR_ARG, "conv: channels not divisible by groups");
-  if (d.ksize != 1 && d.ksize != 3) return set_error(DDX_ERR_UNSUPPORTED, "conv: ksize must be 1 or 3");
+  if (d.ksize != 1 && d.ksize != 3 && d.ksize != 5) return set_error(DDX_ERR_UNSUPPORTED, "conv: ksize must be 1, 3 or 5");
+  // (5x5: the few-channel input / output convs of DAE_G1, dae_edm2_g1.py:274,303 -- served by the scalar kernel only)
   if ((d.prologue & DDX_PRO_SCALE) && !d.chan_scale) return set_error(DDX_ERR_ARG, "conv: chan_scale missing");
   if (d.epilogue == DDX_EPI_MPSUM && !d.residual) return set_error(DDX_ERR_ARG, "conv: residual missing");
   if (d.resample == DDX_RESAMPLE_UP && ((d.H | d.W) & 1)) return set_error(DDX_ERR_ARG, "conv: upsampled size must be even");

@@ -163,6 +163,40 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// Stereo depth axis <-> image batch (DAE_G1, reference tensor_4d_to_5d / tensor_5d_to_4d, utils/dual_diffusion_utils.py:571-575):
+// NCHW fp32 [B][C*Z][H][W] (channel = c * Z + z)  <->  NHWC images n = Z * b + z with Cpad channels: [c < C: data | c == C:
+// `fill` (the constant channel, dae_edm2_g1.py:334-335) when add_const | zeros].
+template <typename T>
+__global__ __launch_bounds__(256) void stereo_to_images_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int Z, int H, int W, int Cpad,
+                                                               int add_const) {
+  const size_t n = (size_t)B * Z * H * W * Cpad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % Cpad);
+    const size_t pix = i / Cpad;
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const int img = (int)(pix / ((size_t)W * H));
+    const int b = img / Z, z = img - b * Z;
+    float v = 0.f;
+    if (c < C) v = x[(((size_t)b * C * Z + (size_t)c * Z + z) * H + h) * W + w];
+    else if (c == C && add_const) v = 1.0f;
+    y[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void images_to_stereo_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int Z, int H, int W, int ld) {
+  const size_t n = (size_t)B * C * Z * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int cz = (int)((i / ((size_t)W * H)) % (C * Z));
+    const int b = (int)(i / ((size_t)W * H * C * Z));
+    const int c = cz / Z, z = cz - c * Z;
+    y[i] = to_f32<T>(x[((((size_t)b * Z + z) * H + h) * W + w) * ld + c]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W, int ld) {
   const size_t n = (size_t)B * C * H * W;
@@ -372,6 +406,28 @@ extern "C" int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, i
     if (dtype == DDX_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(blocks), dim3(256), 0, s, x, (bf16*)y, B, C, H, W);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, s, x, (float*)y, B, C, H, W);
     return check_launch("nchw_to_nhwc");
+  }, stream);
+}
+
+extern "C" int ddx_stereo_to_images(const float* x, void* y, int32_t B, int32_t C, int32_t Z, int32_t H, int32_t W, int32_t Cpad, int32_t add_const,
+                                    int32_t dtype, ddx_stream stream) {
+  if (!x || !y || B <= 0 || C <= 0 || Z <= 0 || Cpad < C + (add_const ? 1 : 0)) return set_error(DDX_ERR_ARG, "stereo_to_images: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * Z * H * W * Cpad);
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(stereo_to_images_kernel<bf16>, dim3(blocks), dim3(256), 0, s, x, (bf16*)y, B, C, Z, H, W, Cpad, add_const);
+    else hipLaunchKernelGGL(stereo_to_images_kernel<float>, dim3(blocks), dim3(256), 0, s, x, (float*)y, B, C, Z, H, W, Cpad, add_const);
+    return check_launch("stereo_to_images");
+  }, stream);
+}
+
+extern "C" int ddx_images_to_stereo(const void* x, int32_t ld, float* y, int32_t B, int32_t C, int32_t Z, int32_t H, int32_t W, int32_t dtype,
+                                    ddx_stream stream) {
+  if (!x || !y || B <= 0 || C <= 0 || Z <= 0 || ld < C) return set_error(DDX_ERR_ARG, "images_to_stereo: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)B * C * Z * H * W);
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(images_to_stereo_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, y, B, C, Z, H, W, ld);
+    else hipLaunchKernelGGL(images_to_stereo_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, y, B, C, Z, H, W, ld);
+    return check_launch("images_to_stereo");
   }, stream);
 }
 

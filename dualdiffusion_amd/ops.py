@@ -409,6 +409,21 @@ def attention(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch
     return out
 
 
+def attention_fold(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None, eps: float = 1e-4,
+                   out_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Axis-folded attention on NHWC maps `[N, H, W, .]`: for every (image, column) the H positions attend to each other
+    (reference DAE_G1 block, dae_edm2_g1.py:209-228).  qk `[N, H, W, 2C]` (head, {q,k}, d), v `[N, H, W, C]` (head, d) -> `[N, H, W, C]`;
+    with `out_scale` [N, C] fp32 the stored result is mp_silu(o * out_scale)."""
+    N, H, W, Cn = v.shape
+    if out is None:
+        out = torch.empty(N, H, W, Cn, dtype=v.dtype, device=v.device)
+    qk_p, qk_ld = _chan_view(qk, 2 * Cn)
+    v_p, v_ld = _chan_view(v, Cn)
+    check(lib().ddx_attn_fold_fwd(qk_p, qk_ld, v_p, v_ld, ptr(out), ptr(out_scale), N, H, W, heads, Cn // heads, eps, dtype_code(v.dtype),
+                                  current_stream()), "attn_fold_fwd")
+    return out
+
+
 def make_linear_jobs(jobs: list, device) -> torch.Tensor:
     """Pack [(weight[O,K], gain_ptr|None, out[M,O] fp32, gain, add_const, groups, normalize)] into a device job table."""
     arr = (L.LinearJob * len(jobs))()
@@ -482,4 +497,21 @@ def nhwc_to_nchw(x: torch.Tensor, out: Optional[torch.Tensor] = None, channels: 
     if out is None:
         out = torch.empty(B, Cn, H, W, dtype=torch.float32, device=x.device)
     check(lib().ddx_nhwc_to_nchw_ld(ptr(x), ld, ptr(out), B, Cn, H, W, dtype_code(x.dtype), current_stream()), "nhwc_to_nchw")
+    return out
+
+
+def stereo_to_images(x: torch.Tensor, channels: int, cpad: int, add_const: bool, dtype: torch.dtype) -> torch.Tensor:
+    """NCHW fp32 [B, channels * 2, H, W] (channel = c * 2 + z) -> NHWC images n = 2 b + z, [2B, H, W, cpad] (data | 1 | zeros)."""
+    B, CZ, H, W = x.shape
+    Z = CZ // channels
+    out = torch.empty(B * Z, H, W, cpad, dtype=dtype, device=x.device)
+    check(lib().ddx_stereo_to_images(ptr(x), ptr(out), B, channels, Z, H, W, cpad, int(add_const), dtype_code(dtype), current_stream()), "stereo_to_images")
+    return out
+
+
+def images_to_stereo(x: torch.Tensor, channels: int, Z: int = 2) -> torch.Tensor:
+    """NHWC images n = Z b + z `[Z B, H, W, ld]` -> NCHW fp32 [B, channels * Z, H, W] (channel = c * Z + z), first `channels` of ld."""
+    N, H, W, ld = x.shape
+    out = torch.empty(N // Z, channels * Z, H, W, dtype=torch.float32, device=x.device)
+    check(lib().ddx_images_to_stereo(ptr(x), ld, ptr(out), N // Z, channels, Z, H, W, dtype_code(x.dtype), current_stream()), "images_to_stereo")
     return out

@@ -324,6 +324,13 @@ int ddx_attn_act_fwd(const void* qk, const void* v, void* out, const float* out_
  * merged [B][T][3C] tensor written by a single conv. */
 int ddx_attn_act_fwd_ld(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t B,
                         int32_t T, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream);
+/* Axis-folded ("separable row / column") attention: the batch entries are the (image, column) pairs of N feature maps
+ * [N][T][fold][channels] and the T tokens of an entry are `fold` rows apart -- attention along H for every (b, z, w) of the
+ * reference's DAE_G1 block (modules/daes/dae_edm2_g1.py:209-228) without transposing the maps.  fold = 1 is ddx_attn_act_fwd_ld
+ * (tokens = the H*W pixels of image n).  out_scale, if given, is indexed by image ([N][heads * head_dim]).
+ * N * fold <= 65535. */
+int ddx_attn_fold_fwd(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t N, int32_t T,
+                      int32_t fold, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-M linear layers on raw master weights (no wprep): out[b][o] = post( sum_k x[b][k] * w'[o][k] )
@@ -379,6 +386,14 @@ int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* 
 /* Layout conversion helpers NCHW fp32 <-> NHWC dtype (module boundary). */
 int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
 int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
+/* Stereo depth axis <-> image batch (DAE_G1; reference tensor_4d_to_5d / tensor_5d_to_4d, utils/dual_diffusion_utils.py:571-575):
+ * NCHW fp32 [B][C*Z][H][W] (channel = c * Z + z) <-> NHWC images n = Z * b + z.  stereo_to_images writes Cpad channels per pixel:
+ * the C data channels, then 1.0 when add_const (the constant channel, dae_edm2_g1.py:334-335), then zeros;
+ * images_to_stereo reads the first C of `ld` channels. */
+int ddx_stereo_to_images(const float* x, void* y, int32_t B, int32_t C, int32_t Z, int32_t H, int32_t W, int32_t Cpad, int32_t add_const,
+                         int32_t dtype, ddx_stream stream);
+int ddx_images_to_stereo(const void* x, int32_t ld, float* y, int32_t B, int32_t C, int32_t Z, int32_t H, int32_t W, int32_t dtype,
+                         ddx_stream stream);
 /* Same, reading the first C channels of pixels that are `ld` channels wide (outputs of convs padded to 8 rows). */
 int ddx_nhwc_to_nchw_ld(const void* x, int32_t ld, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype,
                         ddx_stream stream);

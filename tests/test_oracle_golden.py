@@ -216,3 +216,18 @@ def test_ms_mel_spec_golden():
     assert torch.equal(fs.band_edges(), t["band_edges"]) and int((fs.filters > 0).sum()) == m["nnz"] == 4067
     assert rel_l2(fs.filters.sum(dim=0), t["filter_colsum"]) < 1e-7
     assert torch.equal(fs.filters, M.slaney_mel_filterbank(2049, 256, 0.0, 16000.0, 32000))
+
+
+def test_dae_g1_golden():
+    """DAE_G1 (the live autoencoder: (1,3,3)/(2,3,3)/(1,5,5) stereo-depth kernels, axis-folded attention, tiled encode): the restatement
+    against the reference module's outputs (tests/golden/dae_g1_small)."""
+    from oracle import dae_oracle as DO
+    t, m = load_golden("dae_g1_small")
+    cfg = DO.dae_cfg(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in m["cfg"].items()})
+    sd = DO.random_dae_state(cfg, m["seed"])
+    emb = DO.dae_embeddings(sd, t["emb_in"])
+    assert rel_l2(emb, t["emb"]) < 2e-6
+    assert rel_l2(DO.dae_encode(sd, cfg, t["x"], emb), t["latents"]) < 1e-5
+    assert rel_l2(DO.dae_encode(sd, cfg, t["x"], emb, normalize_latents=False), t["latents_raw"]) < 1e-5
+    assert rel_l2(DO.dae_decode(sd, cfg, t["latents"], emb), t["recon"]) < 1e-5
+    assert rel_l2(DO.dae_tiled_encode(sd, cfg, t["x_tiled"], emb[:1], **m["tiled"]), t["latents_tiled"]) < 1e-5

@@ -692,6 +692,50 @@ def gen_ema() -> None:
                              betas=betas_all, adam=[0.9, 0.99, 1e-8]))
 
 
+def gen_dae() -> None:
+    """DAE_G1 (modules/daes/dae_edm2_g1.py): encode / decode / tiled_encode of a small config with axis-folded attention at level 1."""
+    print("dae_g1")
+    from modules.daes.dae_edm2_g1 import DAE_G1, DAE_G1_Config
+    from oracle import dae_oracle as DO
+    over = dict(model_channels=32, channel_mult_enc=1, channel_mult_dec=(1, 2), channel_mult_emb=2, num_attn_heads=2, num_enc_layers=2,
+                num_dec_layers_per_block=1, in_channels_emb=32, attn_levels=(1,))
+    cfg = DO.dae_cfg(**over)
+    dae = DAE_G1(DAE_G1_Config(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in over.items()})).requires_grad_(False).train(False)
+    ref_shapes = {k: tuple(v.shape) for k, v in dae.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in DO.dae_param_shapes(cfg).items()}, (set(ref_shapes) ^ set(DO.dae_param_shapes(cfg)))
+    sd = DO.random_dae_state(cfg, seed=41)
+    dae.load_state_dict(sd)
+    # normalize_weights of MPConv3D_E is over dim = 1 (input channels) -- the state above is already a fixed point of it
+    before = {k: v.clone() for k, v in dae.state_dict().items()}
+    dae.normalize_weights() if hasattr(dae, "normalize_weights") else None
+    for k, v in dae.state_dict().items():
+        if v.ndim > 1:
+            check(f"normalize_weights fixed point {k}", before[k], v, 5e-3)
+    dae.load_state_dict(sd)
+    g = torch.Generator().manual_seed(42)
+    B, H, W = 2, 16, 24
+    x = torch.randn(B, 2, H, W, generator=g).abs() * 2.0
+    emb_in = torch.randn(B, 32, generator=g)
+    with torch.no_grad():
+        emb = dae.get_embeddings(emb_in)
+        lat = dae.encode(x, emb)
+        lat_raw = dae.encode(x, emb, normalize_latents=False)
+        rec = dae.decode(lat, emb)
+        xt = torch.randn(1, 2, H, 96, generator=g).abs()
+        lat_t = dae.tiled_encode(xt, emb[:1], max_chunk=48, overlap=8)
+    o_emb = DO.dae_embeddings(sd, emb_in)
+    check("dae embeddings", o_emb, emb, 2e-6)
+    check("dae encode", DO.dae_encode(sd, cfg, x, o_emb), lat, 5e-6)
+    check("dae encode raw", DO.dae_encode(sd, cfg, x, o_emb, normalize_latents=False), lat_raw, 5e-6)
+    coll = {}
+    check("dae decode", DO.dae_decode(sd, cfg, lat, o_emb, collect=coll), rec, 1e-5)
+    check("dae tiled_encode", DO.dae_tiled_encode(sd, cfg, xt, o_emb[:1], max_chunk=48, overlap=8), lat_t, 5e-6)
+    assert tuple(dae.get_latent_shape(x.shape)) == (B, 8, H // 2, W // 2) and tuple(dae.get_mel_spec_shape(lat.shape)) == (B, 2, H, W)
+    save("dae_g1_small", {"x": x, "emb_in": emb_in, "emb": emb, "latents": lat, "latents_raw": lat_raw, "recon": rec, "x_tiled": xt, "latents_tiled": lat_t},
+         dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in over.items()}, seed=41, weights="oracle.dae_oracle.random_dae_state(cfg, seed)",
+              tiled=dict(max_chunk=48, overlap=8)))
+
+
 def gen_ddec() -> None:
     """MCLT diffusion-decoder UNet (modules/unets/unet_edm2_ddec_mclt_b1.py): eval-mode forward, small config."""
     print("ddec")
@@ -738,7 +782,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "ddec": gen_ddec}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
