@@ -88,3 +88,38 @@ def _qk_full(qkv, heads, d):
 def _v_full(qkv, heads, d):
     B, C3, Z, H, W = qkv.shape
     return qkv[:, :, 0].view(B, heads, d, 3, H, W)[:, :, :, 2].reshape(B, heads * d, H, W)
+
+
+def test_latent_pre_encode_pipeline(tmp_path):
+    """audio -> offset / mirror augmented crops -> raw_to_mel_spec -> dae.encode -> safetensors `latents[variation, C, h, w]` ->
+    sliced read (reference dataset/processes/encode.py:306-353, training/dataset.py:192-201), against the same chain through the oracles."""
+    import numpy as np
+    from oracle import mel_oracle as M
+    from dualdiffusion_amd.dataset.latents import EncodeProcessConfig, LatentPreEncoder, LatentsLoader, LatentsLoaderConfig, _normalize
+    from dualdiffusion_amd.modules.formats.ms_mdct_dual import MS_MDCT_DualFormat, MS_MDCT_DualFormatConfig
+    dae, t, m, cfg, sd = _build(torch.float32)
+    fmt = MS_MDCT_DualFormat(MS_MDCT_DualFormatConfig(ms_width_alignment=16)).to(device="cuda")
+    enc = LatentPreEncoder(fmt, dae, EncodeProcessConfig(latents_batch_size=1, latents_num_time_offset_augmentations=2,
+                                                         latents_stereo_mirroring_augmentation=True))
+    g = torch.Generator().manual_seed(3)
+    audio = torch.randn(2, 256 * 40, generator=g) * 0.1
+    clap = torch.randn(3, 32, generator=g)
+    out = enc.encode(audio, clap)
+    lat = out["latents"]
+    # the reference sizes its batches from the number of OFFSETS (encode.py:262), so with mirroring on only the first
+    # `offsets` crops of the interleaved [as is, mirrored, as is, mirrored, ...] list are encoded -- reproduced as it is
+    assert lat.dtype == torch.bfloat16 and lat.shape[0] == 2 and lat.shape[1] == 8
+    # the same chain through the oracles
+    crop = fmt.get_raw_crop_width(audio.shape[-1] - enc.offset_padding)
+    emb = DO.dae_embeddings(sd, _normalize(clap.mean(dim=0, keepdim=True)))
+    for v, (off, flip) in enumerate([(0, False), (0, True)]):
+        x = audio[:, off:off + crop].unsqueeze(0)
+        if flip:
+            x = torch.flip(x, dims=(1,))
+        ref = DO.dae_encode(sd, cfg, M.raw_to_ms_mel_spec(x), emb)
+        assert ref.shape[1:] == lat.shape[1:]
+        assert rel_l2(lat[v].float(), ref[0]) < 6e-3, v                                      # (bf16 storage of the latents)
+    path = str(tmp_path / "a" / "track.safetensors")
+    LatentPreEncoder.save(path, out, {"prompt": "none"})
+    got = LatentsLoader(LatentsLoaderConfig(latents_crop_width=lat.shape[-1] - 2, raw_crop_width=crop), rng=np.random.default_rng(0)).load(path)
+    assert torch.equal(got["latents"], lat[got["variation"], ..., got["t_offset"]:got["t_offset"] + lat.shape[-1] - 2])
