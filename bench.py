@@ -39,6 +39,17 @@ DEFAULT_UNET = dict(in_channels=4, out_channels=4, in_channels_emb=512, dropout=
                     res_balance=0.3, attn_balance=0.3, attn_levels=[3, 4], mlp_multiplier=2, mlp_groups=8)
 
 
+def csrc_hash() -> str:
+    """sha256 over the kernel sources and the C ABI header: ties a committed PMC traffic number to the code that produced it."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dualdiffusion_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "ddx_hip.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def build_model(device, dtype, seed: int):
     from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
     torch.manual_seed(seed)
@@ -227,16 +238,25 @@ def main() -> None:
         achieved = fl / (ms * 1e-3) / 1e12
         # HBM-side traffic per launch of the same kernel family: PMC counters cannot be read from inside the process, so
         # the number comes from the committed rocprofv3 --pmc run of this very command (tools/profile_round.sh)
+        # (tools/make_traffic.py); it is only reported when the kernel sources still hash to what that run measured
+        import glob
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if os.path.isfile(tpath):
-            with open(tpath) as fh:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+        if cands:
+            with open(cands[-1]) as fh:
                 tj = json.load(fh)
-            if tj.get("family") == dom[0]:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            name = os.path.relpath(cands[-1], ROOT)
+            if tj.get("family") != dom[0]:
+                print(f"# roofline.traffic: {name} is for {tj.get('family')}, the dominant family is {dom[0]} -> null", file=sys.stderr)
+            elif tj.get("csrc_sha256") != csrc_hash():
+                print(f"# roofline.traffic: STALE -- {name} was measured on other kernel sources (csrc hash mismatch): re-run tools/profile_round.sh "
+                      "-> null", file=sys.stderr)
+                traffic_src = f"{name} is stale (kernel sources changed since its PMC run)"
+            else:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], f"{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources)"
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": int(by / n),
+                    "algorithmic_bytes_per_launch": int(by / n), "traffic_ratio": round(traffic / (by / n), 3) if traffic else None,
                     "kernel": dom[0], "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms / total_ms, 3),
                     "step_tflops": round(B * FLOP_PER_SAMPLE / (elapsed / a.steps) / 1e12, 1),

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmParams p) {
 }
 
 // one wave per row: P = softmax(S * scale)  (S fp32 from the GEMM, P bf16 = operand of the next GEMMs)
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16* __restrict__ p, long rows, int n, long ld, float scale) {
+template <typename TP>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, TP* __restrict__ p, long rows, int n, long ld, float scale) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -121,19 +122,42 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int j = lane; j < n; j += 64) sum += __expf((float)sr[j] * scale - mx);
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
-  for (int j = lane; j < n; j += 64) p[row * ld + j] = (bf16)(__expf((float)sr[j] * scale - mx) * inv);
+  for (int j = lane; j < n; j += 64) p[row * ld + j] = from_f32<TP>(__expf((float)sr[j] * scale - mx) * inv);
 }
 
 // dS = P o (dP - sum_j P dP) * scale   (dP fp32 from the GEMM, dS bf16)
-__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const bf16* __restrict__ p, const float* __restrict__ dp, bf16* __restrict__ ds, long rows,
+template <typename TP>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const TP* __restrict__ p, const float* __restrict__ dp, TP* __restrict__ ds, long rows,
                                                                int n, long ld, float scale) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   float dot = 0.f;
-  for (int j = lane; j < n; j += 64) dot += (float)p[row * ld + j] * dp[row * ld + j];
+  for (int j = lane; j < n; j += 64) dot += to_f32<TP>(p[row * ld + j]) * dp[row * ld + j];
   dot = wave_sum(dot);
-  for (int j = lane; j < n; j += 64) ds[row * ld + j] = (bf16)((float)p[row * ld + j] * (dp[row * ld + j] - dot) * scale);
+  for (int j = lane; j < n; j += 64) ds[row * ld + j] = from_f32<TP>(to_f32<TP>(p[row * ld + j]) * (dp[row * ld + j] - dot) * scale);
+}
+
+// float32 parity path of the batched GEMM (same descriptor, operands and result fp32): one thread per output element, plain fp32
+// fused multiply-adds in k order.  Correctness tool for the fp32 backward pass, not a fast path.
+__global__ __launch_bounds__(256) void bgemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, long lda,
+                                                        long ldb, long ldc, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1, int M, int N, int K,
+                                                        int nb1, int a_kmajor, int b_kmajor, float alpha) {
+  const int bi = blockIdx.z, b0 = bi / nb1, b1 = bi - b0 * nb1;
+  const float* a = A + b0 * sA0 + b1 * sA1;
+  const float* b = B + b0 * sB0 + b1 * sB1;
+  float* c = C + b0 * sC0 + b1 * sC1;
+  const long total = (long)M * N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / N), n = (int)(i - (long)m * N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float av = a_kmajor ? a[(long)k * lda + m] : a[(long)m * lda + k];
+      const float bv = b_kmajor ? b[(long)k * ldb + n] : b[(long)n * ldb + k];
+      acc = fmaf(av, bv, acc);
+    }
+    c[(long)m * ldc + n] = alpha * acc;
+  }
 }
 
 }  // namespace
@@ -165,15 +189,44 @@ extern "C" int ddx_bgemm_bf16(const ddx_bgemm_desc* dp, ddx_stream stream) {
 extern "C" int ddx_softmax_rows(const void* s, void* p, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream) {
   if (!s || !p || rows <= 0 || n <= 0) return set_error(DDX_ERR_ARG, "softmax_rows: bad args");
   return dispatch([=](hipStream_t st) -> int {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)s, (bf16*)p, (long)rows, n, (long)ld, scale);
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)s, (bf16*)p, (long)rows, n, (long)ld, scale);
     return check_launch("softmax_rows");
   }, stream, "softmax_rows");
+}
+
+extern "C" int ddx_softmax_rows_f32(const void* s, void* p, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream) {
+  if (!s || !p || rows <= 0 || n <= 0) return set_error(DDX_ERR_ARG, "softmax_rows: bad args");
+  return dispatch([=](hipStream_t st) -> int {
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)s, (float*)p, (long)rows, n, (long)ld, scale);
+    return check_launch("softmax_rows_f32");
+  }, stream, "softmax_rows");
+}
+
+extern "C" int ddx_softmax_bwd_rows_f32(const void* p, const void* dp, void* ds, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream) {
+  if (!p || !dp || !ds || rows <= 0 || n <= 0) return set_error(DDX_ERR_ARG, "softmax_bwd_rows: bad args");
+  return dispatch([=](hipStream_t st) -> int {
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)p, (const float*)dp, (float*)ds, (long)rows, n,
+                       (long)ld, scale);
+    return check_launch("softmax_bwd_rows_f32");
+  }, stream, "softmax_bwd_rows");
+}
+
+extern "C" int ddx_bgemm_f32(const ddx_bgemm_desc* dp, ddx_stream stream) {
+  if (!dp || !dp->A || !dp->B || !dp->C) return set_error(DDX_ERR_ARG, "bgemm: null");
+  const ddx_bgemm_desc d = *dp;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nb0 <= 0 || d.nb1 <= 0 || (long)d.nb0 * d.nb1 > 65535) return set_error(DDX_ERR_ARG, "bgemm: bad size");
+  return dispatch([d](hipStream_t s) -> int {
+    dim3 grid((unsigned)std::min<long>(((long)d.M * d.N + 255) / 256, 4096), 1, (unsigned)(d.nb0 * d.nb1));
+    hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, s, (const float*)d.A, (const float*)d.B, (float*)d.C, d.lda, d.ldb, d.ldc, d.sA0, d.sA1, d.sB0, d.sB1,
+                       d.sC0, d.sC1, d.M, d.N, d.K, d.nb1, d.a_kmajor, d.b_kmajor, d.alpha);
+    return check_launch("bgemm_f32");
+  }, stream, "bgemm_f32");
 }
 
 extern "C" int ddx_softmax_bwd_rows(const void* p, const void* dp, void* ds, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream) {
   if (!p || !dp || !ds || rows <= 0 || n <= 0) return set_error(DDX_ERR_ARG, "softmax_bwd_rows: bad args");
   return dispatch([=](hipStream_t st) -> int {
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)p, (const float*)dp, (bf16*)ds, (long)rows, n, (long)ld, scale);
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)p, (const float*)dp, (bf16*)ds, (long)rows, n, (long)ld, scale);
     return check_launch("softmax_bwd_rows");
   }, stream, "softmax_bwd_rows");
 }

@@ -418,10 +418,53 @@ int launch_wgrad(const WgradParams& p, hipStream_t s) {
   return check_launch("conv_wgrad");
 }
 
+// ---- float32 parity path: one workgroup per (output channel, input channel of the group, tap), plain fp32 products summed over all
+// pixels (block tree + fixed order).  No tiling, no matrix cores: it exists so that gradient parity can be asserted at fp32 tolerance
+// (tests/test_gpu_backward.py), not for speed.
+__global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x0, const float* __restrict__ x1,
+                                                             float* __restrict__ dw, int B, int H, int W, int sH, int sW, int C0, int C1, int Cout, int G,
+                                                             int KS, int up, int accumulate) {
+  __shared__ float scratch[4];
+  const int taps = KS * KS, pad = KS / 2;
+  const int Cg = (C0 + C1) / G, Ng = Cout / G;
+  const int idx = blockIdx.x;                      // ((o * Cg + c) * taps + tap)
+  const int tap = idx % taps, c = (idx / taps) % Cg, o = idx / (taps * Cg);
+  const int g = o / Ng, cabs = g * Cg + c;
+  const float* xs = cabs < C0 ? x0 : x1;
+  const int Cs = cabs < C0 ? C0 : C1, cc = cabs < C0 ? cabs : cabs - C0;
+  const int dh = tap / KS - pad, dwo = tap % KS - pad;
+  float acc = 0.f;
+  const long npx = (long)B * H * W;
+  for (long pix = threadIdx.x; pix < npx; pix += 256) {
+    const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    const int ih = h + dh, iw = w + dwo;
+    if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+    const int shh = up ? (ih >> 1) : ih, sww = up ? (iw >> 1) : iw;
+    acc += dy[pix * Cout + o] * xs[(((long)b * sH + shh) * sW + sww) * Cs + cc];
+  }
+  acc = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) dw[idx] = accumulate ? dw[idx] + acc : acc;
+}
+
 }  // namespace
 }  // namespace ddx
 
 using namespace ddx;
+
+static int wgrad_f32(const ddx_wgrad_desc& d, ddx_stream stream) {
+  if (!d.dy || !d.x0 || !d.dw) return set_error(DDX_ERR_ARG, "wgrad: null buffer");
+  if (d.ksize != 1 && d.ksize != 3) return set_error(DDX_ERR_UNSUPPORTED, "wgrad: ksize must be 1 or 3");
+  if ((d.C1 > 0) != (d.x1 != nullptr) || d.groups <= 0 || (d.C0 + d.C1) % d.groups || d.Cout % d.groups) return set_error(DDX_ERR_ARG, "wgrad: bad channels");
+  if (d.resample == DDX_RESAMPLE_DOWN) return set_error(DDX_ERR_UNSUPPORTED, "wgrad: avg-pool gather not built");
+  const ddx_wgrad_desc q = d;
+  const int up = d.resample == DDX_RESAMPLE_UP;
+  const size_t n = (size_t)d.Cout * ((d.C0 + d.C1) / d.groups) * d.ksize * d.ksize;
+  return dispatch([q, up, n](hipStream_t s) -> int {
+    hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3((unsigned)n), dim3(256), 0, s, (const float*)q.dy, (const float*)q.x0, (const float*)q.x1, q.dw, q.B, q.H,
+                       q.W, up ? q.H / 2 : q.H, up ? q.W / 2 : q.W, q.C0, q.C1, q.Cout, q.groups, q.ksize, up, q.accumulate);
+    return check_launch("conv_wgrad_f32");
+  }, stream, "conv_wgrad_f32");
+}
 
 static int wgrad_fill(const ddx_wgrad_desc& d, WgradParams* pp) {
   if (!d.dy || !d.x0 || !d.dw) return set_error(DDX_ERR_ARG, "wgrad: null buffer");
@@ -463,6 +506,7 @@ static int wgrad_fill(const ddx_wgrad_desc& d, WgradParams* pp) {
 
 extern "C" size_t ddx_wgrad_workspace_bytes(const ddx_wgrad_desc* dp) {
   if (!dp) return 0;
+  if (dp->dtype == DDX_F32) return 16;   // (the fp32 parity kernel needs none; non-zero = supported)
   WgradParams p{};
   ddx_wgrad_desc d = *dp;
   static float dummy;
@@ -477,6 +521,7 @@ extern "C" size_t ddx_wgrad_workspace_bytes(const ddx_wgrad_desc* dp) {
 extern "C" int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* dp, ddx_stream stream) {
   if (!dp) return set_error(DDX_ERR_ARG, "wgrad: null descriptor");
   const ddx_wgrad_desc d = *dp;
+  if (d.dtype == DDX_F32) return wgrad_f32(d, stream);
   WgradParams p{};
   if (int rc = wgrad_fill(d, &p)) return rc;
   if (!d.workspace) return set_error(DDX_ERR_ARG, "wgrad: workspace missing (ddx_wgrad_workspace_bytes)");

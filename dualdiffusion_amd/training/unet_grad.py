@@ -39,9 +39,15 @@ def _block_weights(blk, groups: int, bank=None, prefix: str = "", cvec=None) -> 
 class UNetTrainer:
     """forward(x_in, sigma, format, embeddings) -> D_x (NCHW fp32); backward(dD) -> {parameter name: gradient}."""
 
-    def __init__(self, unet) -> None:
+    def __init__(self, unet, compute_dtype: torch.dtype = torch.bfloat16) -> None:
         # mixed precision as the reference trains (accelerate bf16 autocast over fp32 parameters, trainer.py:375): the module
-        # keeps fp32 master weights, every activation / prepared weight on the device is bf16
+        # keeps fp32 master weights, every activation / prepared weight on the device is bf16.
+        # compute_dtype = torch.float32: the PARITY path -- activations, prepared weights and every gradient kernel in fp32 (exact-fp32
+        # MFMA forward / data gradient, scalar fp32 weight-gradient and attention-backward kernels): slow, but gradients can be
+        # asserted at fp32 tolerance against autograd through the oracle (tests/test_gpu_backward.py)
+        if compute_dtype not in (torch.bfloat16, torch.float32):
+            raise DDXError("UNetTrainer: compute_dtype must be bfloat16 or float32")
+        self.dt = compute_dtype
         if unet.device.type != "cuda" or next(unet.parameters()).dtype != torch.float32:
             raise DDXError("UNetTrainer: module must be on the ROCm device with float32 (master) parameters")
         self.u = unet
@@ -142,7 +148,7 @@ class UNetTrainer:
         for mname, m in u.named_modules():
             if hasattr(m, "disable_weight_norm") and hasattr(m, "weight") and mname + ".weight" not in seen and not m.disable_weight_norm:
                 entries.append(BankEntry(name=mname + ".weight", weight=m.weight.data, prep=False, transpose=False, grad=False))
-        self.bank = WeightBank(entries, torch.bfloat16, self.grad_views, early={e.name for e in entries if e.name.startswith("dec.")})
+        self.bank = WeightBank(entries, self.dt, self.grad_views, early={e.name for e in entries if e.name.startswith("dec.")})
         self._bank_key = (B, H, W)
         # every emb_linear* (all read emb): persistent outputs / output gradients, one job table for the forward and one for the backward
         lin = [e for e in entries if ".emb_linear" in e.name]
@@ -185,7 +191,7 @@ class UNetTrainer:
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor,
                 perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
-        u, cfg, dev, dt = self.u, self.u.config, self.u.device, torch.bfloat16
+        u, cfg, dev, dt = self.u, self.u.config, self.u.device, self.dt
         B, _, H, W = x_in.shape
         G = cfg.mlp_groups
         x_in = x_in.to(dev, torch.float32).contiguous()
@@ -262,7 +268,7 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------------------------------------ backward
     def backward(self, dD: torch.Tensor) -> dict:
-        u, cfg, t, dev, dt = self.u, self.u.config, self.tape, self.u.device, torch.bfloat16
+        u, cfg, t, dev, dt = self.u, self.u.config, self.tape, self.u.device, self.dt
         if t is None:
             raise DDXError("UNetTrainer.backward before forward")
         B, H, W, Co = t["B"], t["H"], t["W"], t["Co"]

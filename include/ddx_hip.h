@@ -202,7 +202,7 @@ typedef struct {
   int32_t B, H, W;          /* size of dY (= conv output) */
   int32_t C0, C1, Cout, groups, ksize;
   int32_t resample;         /* DDX_RESAMPLE_KEEP | DDX_RESAMPLE_UP */
-  int32_t dtype;            /* DDX_BF16 */
+  int32_t dtype;            /* DDX_BF16 (matrix cores) | DDX_F32 (scalar parity kernel, no workspace needed) */
   int32_t accumulate;
 } ddx_wgrad_desc;
 
@@ -510,6 +510,11 @@ typedef struct {
 int ddx_bgemm_bf16(const ddx_bgemm_desc* d, ddx_stream stream);
 int ddx_softmax_rows(const void* s, void* p, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream);
 int ddx_softmax_bwd_rows(const void* p, const void* dp, void* ds, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream);
+/* float32 parity path of the three calls above (operands, P / dS and the result fp32; scalar kernels): lets the whole backward pass
+ * run in fp32 so that gradient parity is asserted at fp32 tolerance.  Same descriptor / argument meaning. */
+int ddx_bgemm_f32(const ddx_bgemm_desc* d, ddx_stream stream);
+int ddx_softmax_rows_f32(const void* s, void* p, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream);
+int ddx_softmax_bwd_rows_f32(const void* p, const void* dp, void* ds, int64_t rows, int32_t n, int64_t ld, float scale, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-scale 2-D spectral loss, one block width per call  (training/loss/multiscale_spectral.py:213-294 `MSSLoss2D.stft2d`

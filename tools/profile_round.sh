@@ -15,6 +15,8 @@ done
 cd $root
 python tools/pmc_summary.py $out/${tag}_pmc_FETCH_SIZE conv_ > $out/${tag}_pmc_summary.txt
 python tools/pmc_summary.py $out/${tag}_pmc_WRITE_SIZE conv_ >> $out/${tag}_pmc_summary.txt
+python tools/make_traffic.py $tag $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE > $out/${tag}_traffic.log 2>&1
+cp profiles/${tag}_traffic.json $out/${tag}_traffic.json 2>/dev/null
 find $out/${tag}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/${tag}_kernel_stats.csv
 cat $out/${tag}_bench.json
 head -12 $out/${tag}_kernel_stats.csv
