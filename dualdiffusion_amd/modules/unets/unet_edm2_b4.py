@@ -290,7 +290,7 @@ class _UNetEngine:
         self.lnf = pb.f32(H)
 
         # ---- front end: preconditioning + embedding (reference unet_edm2_b4.py:257-277)
-        Cpad = 8
+        Cpad = (cfg.in_channels + 2 + 7) // 8 * 8      # x, the constant channel and the ln-frequency channel, padded to 16-byte vectors
         x0 = pb.act(H, W, Cpad)
         four, e0, emb = pb.f32(B, unet.cnoise), pb.f32(B, cemb), pb.f32(B, cemb)
         freqs, phases = unet.emb_fourier.freqs.float().contiguous(), unet.emb_fourier.phases.float().contiguous()
