@@ -19,6 +19,7 @@ RESAMPLE_KEEP, RESAMPLE_UP, RESAMPLE_DOWN = 0, 1, 2
 RESAMPLE_UP_BWD, RESAMPLE_DOWN_BWD = 3, 4
 PRO_NONE, PRO_SILU, PRO_SCALE, PRO_SCALE_SILU = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT_W, PAD_SWAP_SRC1, PAD_SWAP_PAIRED = 0, 1, 2, 4
+LAYOUT_SRC0_C16, LAYOUT_SRC1_C16, LAYOUT_OUT_C16, LAYOUT_OUT2_C16 = 1, 2, 4, 8
 EPI_STORE, EPI_MPSUM, EPI_PIXELNORM = 0, 1, 3
 
 
@@ -59,7 +60,7 @@ class ConvDesc(C.Structure):
                 ("dtype", C.c_int32), ("force_direct", C.c_int32),
                 ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float),
                 ("pad_mode", C.c_int32), ("prologue_rows", C.c_int32),
-                ("out2_linear", C.c_int32), ("out2_chan_scale", C.c_void_p), ("src0_alt", C.c_void_p)]
+                ("out2_linear", C.c_int32), ("layout", C.c_int32), ("out2_chan_scale", C.c_void_p), ("src0_alt", C.c_void_p)]
 
 
 class DgradActDesc(C.Structure):
@@ -145,6 +146,7 @@ PROTOTYPES = {
     "ddx_mpconv_wprep": (C.c_int, [C.POINTER(WPrepDesc), C.c_void_p]),
     "ddx_normalize_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "ddx_mpconv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "ddx_mpconv2d_path": (C.c_int, [C.POINTER(ConvDesc)]),
     "ddx_mpconv2d_pick_ck": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "ddx_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_pixelnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),

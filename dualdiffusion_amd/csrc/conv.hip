@@ -167,6 +167,14 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.src0_alt = d.src0_alt; p.out2_cs = d.out2_chan_scale; p.out2_linear = d.out2_linear;
   if (d.out2_linear && (!d.out2 || !d.out2_chan_scale)) return set_error(DDX_ERR_ARG, "conv: out2_linear needs out2 and out2_chan_scale");
   if ((d.src0_alt || d.out2_linear) && d.CK != 16) return set_error(DDX_ERR_UNSUPPORTED, "conv: src0_alt / out2_linear are served by the small-M kernel only (CK = 16)");
+  p.layout = d.layout;
+  if (d.layout) {
+    if (d.layout & ~15) return set_error(DDX_ERR_ARG, "conv: layout");
+    if (d.dtype != DDX_BF16 || d.ksize != 3) return set_error(DDX_ERR_UNSUPPORTED, "conv: channel-blocked tensors are served by the 3x3 bf16 LDS-DMA kernel");
+    if (((d.layout & DDX_LAYOUT_SRC0_C16) && d.C0 % 16) || ((d.layout & DDX_LAYOUT_SRC1_C16) && (!d.src1 || d.C1 % 16)) ||
+        ((d.layout & (DDX_LAYOUT_OUT_C16 | DDX_LAYOUT_OUT2_C16)) && d.Cout % 16) || ((d.layout & DDX_LAYOUT_OUT2_C16) && !d.out2))
+      return set_error(DDX_ERR_ARG, "conv: a channel-blocked tensor needs a multiple of 16 channels");
+  }
   p.reflect_w = (d.pad_mode & DDX_PAD_REFLECT_W) ? 1 : 0;
   p.swap1 = (d.pad_mode & DDX_PAD_SWAP_SRC1) ? 1 : 0;
   p.paired = (d.pad_mode & DDX_PAD_SWAP_PAIRED) ? 1 : 0;
@@ -179,9 +187,22 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   return 0;
 }
 
+static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query);
+
 extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   if (!dp) return set_error(DDX_ERR_ARG, "conv: null descriptor");
-  const ddx_conv_desc d = *dp;
+  return conv_fwd_impl(*dp, stream, false);
+}
+
+extern "C" int ddx_mpconv2d_path(const ddx_conv_desc* dp) {
+  if (!dp) return set_error(DDX_ERR_ARG, "conv: null descriptor");
+  ddx_conv_desc d = *dp;
+  d.layout = 0;
+  return conv_fwd_impl(d, nullptr, true);
+}
+
+// query: return the kernel the descriptor selects (1 scalar, 2 register-staged MFMA, 3 LDS-DMA, 4 small-M) instead of launching it
+static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) {
   if (d.epilogue != DDX_EPI_STORE && d.epilogue != DDX_EPI_MPSUM && d.epilogue != DDX_EPI_PIXELNORM) return set_error(DDX_ERR_ARG, "conv: epilogue");
   if (d.epilogue == DDX_EPI_PIXELNORM && (d.residual || d.out_act || d.out_scale || !(d.res_t > 0.f)))
     return set_error(DDX_ERR_ARG, "conv: the pixel-norm epilogue takes eps in res_t and no residual / output activation");
@@ -198,9 +219,11 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   // >= 16: the register-staged kernel with tile / split-K configuration (force_direct - 16), see ConvParams::force_cfg
   if (d.force_direct >= 16) p.force_cfg = d.force_direct - 16 + 1;
   // CK = 16 is the weight layout of the small-M weight-streaming kernel (conv_sm.hip): the choice was made when the weights were prepared
-  if (d.CK == 16 && d.force_direct != 1) {
+  if (d.CK == 16 && d.force_direct != 1 && d.force_direct != 3 && !d.layout) {
     if ((d.force_direct != 0 && d.force_direct != 4) || !conv_sm_supported(p, ks, dt))
       return set_error(DDX_ERR_UNSUPPORTED, "conv: weights prepared with CK = 16 run on the small-M kernel only, and this layer does not qualify");
+    if (query) return 4;
+    if (d.layout) return set_error(DDX_ERR_UNSUPPORTED, "conv: channel-blocked tensors need the LDS-DMA kernel");
     const double flops_sm = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
     const double bytes_sm = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) + (double)p.Cout * p.Cg * ks * ks);
     return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_sm(p, ks, s); }, stream, ks == 3 ? "conv3x3_sm" : "conv1x1_sm", flops_sm, bytes_sm);
@@ -213,6 +236,8 @@ extern "C" int ddx_mpconv2d_fwd(const ddx_conv_desc* dp, ddx_stream stream) {
   const bool dma = d.force_direct == 3 || d.epilogue == DDX_EPI_PIXELNORM ||
                    (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
   if (d.force_direct >= 16 && !mfma) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the register-staged MFMA kernel");
+  if (query) return dma ? 3 : mfma ? 2 : 1;
+  if (d.layout && (!dma || p.epilogue == DDX_EPI_PIXELNORM)) return set_error(DDX_ERR_UNSUPPORTED, "conv: channel-blocked tensors need the LDS-DMA kernel (ddx_mpconv2d_path)");
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double es = (double)dtype_size(dt);
   const double bytes = es * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) +

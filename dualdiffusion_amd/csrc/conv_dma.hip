@@ -269,14 +269,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     const int swapped = (p.paired && cabs >= half) ? 1 : 0;   // [src0 | src1 | src0' | src1']: second half from image b ^ 1
     if (swapped) cabs -= half;
     const int src_id = cabs >= p.C0 ? 1 : 0;
+    const bool c16 = KS == 3 && ((p.layout >> src_id) & 1);   // channel-blocked source [B][C/16][sH][sW][16]: a stage is one plane
     if (src_id + 2 * swapped != isrc) {  // (re)compute the per-lane row offsets for this source's channel stride
       isrc = src_id + 2 * swapped;
       const int cs2 = (src_id ? p.C1 : p.C0) * 2;
       const int dpix = (swapped || (src_id && p.swap1)) ? ((it.b ^ 1) - it.b) * p.sH * p.sW : 0;   // pair-swapped image
+      if (c16) {
+        const int hw = p.sH * p.sW;
+        const int ibase = (it.b * hw + dpix) * cs2 - it.b * hw * 32;   // image base of the (swapped) image minus the image part of apix
 #pragma unroll
-      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+        for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * 32 + ibase + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+      } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+      }
     }
-    const int soff_a = (src_id ? cabs - p.C0 : cabs) * 2;
+    const int cin_src = src_id ? cabs - p.C0 : cabs;
+    const int soff_a = c16 ? (cin_src >> 4) * p.sH * p.sW * 32 : cin_src * 2;
     const rsrc_t rsa = src_id ? rs1 : rs0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -524,23 +533,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 #pragma unroll
         for (int e = 0; e < 8; ++e) dcacc[i][e] = 0.f;
     }
-    // epilogue addressing: items of a 32 pixel x 32 channel patch are (pixel, 8-channel run); 128 items, 2 per lane
+    // epilogue addressing: items of a 32 pixel x 32 channel patch are (pixel, 8-channel run); 128 items, 2 per lane.
+    // Item idx = lane + 64 * tt is (pixel idx >> 2, run idx & 3): four lanes cover the 64-byte NHWC row of a pixel.  When the
+    // main output is channel-blocked and nothing NHWC is read or written, (pixel (idx >> 1) & 31, run 2 * (idx >> 6) + (idx & 1)):
+    // the 64 lanes of a store instruction write the 32-byte pieces of 32 consecutive pixels of ONE 16-channel plane = 1 KiB.
+    constexpr bool C16_OUT = !EB && WN == 1 && NF <= 2 && MF <= 2;
+    const bool map16 = C16_OUT && (p.layout & 4) && p.epilogue != DDX_EPI_MPSUM && (!p.out2 || (p.layout & 8));
+    auto item_px = [&](int tt) { return map16 ? (lane >> 1) : (lane >> 2) + 16 * tt; };
+    auto item_c8 = [&](int tt) { return map16 ? (2 * tt + (lane & 1)) * 8 : (lane & 3) * 8; };
     long eoff[MF][2];
+    [[maybe_unused]] int epx[C16_OUT ? MF : 1][2];   // pixel index of the item (channel-blocked stores)
     auto epilogue_offsets = [&]() {
 #pragma unroll
       for (int j = 0; j < MF; ++j)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          const int idx = lane + 64 * tt;
-          const int ml = (wm * MF + j) * 32 + (idx >> 2);
+          const int ml = (wm * MF + j) * 32 + item_px(tt);
           const int th = (int)(((float)ml + 0.5f) * inv_TW);
           const int tw = ml - th * TW;
           const int h = t.h0 + th, w = t.w0 + tw;
           const bool ok = h < p.H && w < p.W;
           const int pix = (t.b * p.H + h) * p.W + w;
-          eoff[j][tt] = ok ? (long)((size_t)pix * ld_u + (size_t)t.g * p.Ng + t.n0 - cofs + wn * (NF * 32) + (idx & 3) * 8) : -1;
+          eoff[j][tt] = ok ? (long)((size_t)pix * ld_u + (size_t)t.g * p.Ng + t.n0 - cofs + wn * (NF * 32) + item_c8(tt)) : -1;
           if constexpr (EB) epix[j][tt] = ok ? pix : -1;
+          if constexpr (C16_OUT) epx[j][tt] = pix;
         }
+    };
+    // element offset of channel c of the item's pixel in a channel-blocked [B][Cout/16][H][W][16] tensor
+    [[maybe_unused]] const long c16_img = (long)t.b * (p.Cout / 16 - 1) * p.H * p.W * 16;
+    [[maybe_unused]] auto c16_off = [&](int j, int tt, int c) {
+      if constexpr (C16_OUT) return (long)epx[j][tt] * 16 + c16_img + (long)(c >> 4) * p.H * p.W * 16 + (c & 15);
+      else return 0l;
     };
     if constexpr (!LATE_RES) epilogue_offsets();  // needed by the residual prefetch inside the last matrix phase
     u32x4 rres[LATE_RES ? (NF > 2 ? 2 : 1) : NF][MF][2];
@@ -563,7 +586,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
             for (int j = 0; j < MF; ++j)
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt) {
-                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + item_c8(tt) < p.Ng;
                 rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
               }
         }
@@ -598,7 +621,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
             for (int j = 0; j < MF; ++j)
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt) {
-                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + item_c8(tt) < p.Ng;
                 rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
               }
         }
@@ -646,7 +669,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         for (int j = 0; j < MF; ++j)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
-            const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + (((lane + 64 * tt) & 3) * 8) < p.Ng;
+            const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + item_c8(tt) < p.Ng;
             rres[rslot(i)][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
           }
       }
@@ -663,9 +686,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         DDX_TR(6);   // (epilogue sub-phases: 6 = accumulators -> LDS patch, 7 = patch rows -> registers + math, 8 = stores)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          const int idx = lane + 64 * tt;
-          const int c8 = (idx & 3) * 8;
-          const float* srow = sE + (idx >> 2) * 36 + c8;
+          const int c8 = item_c8(tt);
+          const float* srow = sE + item_px(tt) * 36 + c8;
           const f32x4 ya = *reinterpret_cast<const f32x4*>(srow);
           const f32x4 yb = *reinterpret_cast<const f32x4*>(srow + 4);
           float y[8];
@@ -736,7 +758,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
               for (int e = 0; e < 8; ++e) tv.set(e, mp_silu_f(y[e] * p.out2_scale));
             }
 #ifndef DDX_ABL_NOSTORE
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + off) = tv.v;
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + ((C16_OUT && (p.layout & 8)) ? c16_off(j, tt, t.g * p.Ng + nch) : off)) = tv.v;
 #else
             if (tv.v[0] == (bf16)12345.f) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out2) + off) = tv.v;   // (keeps the math alive)
 #endif
@@ -758,7 +780,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
           for (int e = 0; e < 8; ++e) ov.set(e, y[e]);
           DDX_TR(7);
 #ifndef DDX_ABL_NOSTORE
-          *reinterpret_cast<bf16x8*>(out + off) = ov.v;
+          *reinterpret_cast<bf16x8*>(out + ((C16_OUT && (p.layout & 4)) ? c16_off(j, tt, t.g * p.Ng + nch) : off)) = ov.v;
 #else
           if (ov.v[0] == (bf16)12345.f) *reinterpret_cast<bf16x8*>(out + off) = ov.v;   // (keeps the math alive)
 #endif
@@ -982,7 +1004,7 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     static const int big_knob = std::getenv("DDX_DMA_BIG") ? atoi(std::getenv("DDX_DMA_BIG")) : 0;  // experiment knob: 2 = wherever it fits
     using BIG = DmaGeom<3, 16, 2, 1, 4, 4>;
     int bth = 0, btw = 0; double butil = 0;
-    if (big_knob && dma_tile(p, 3, &bth, &btw, &butil, BIG::BM, BIG::AROWS)) {
+    if (big_knob && !p.layout && dma_tile(p, 3, &bth, &btw, &butil, BIG::BM, BIG::AROWS)) {
       const int bn = p.Ng <= 32 ? 32 : 64;
       const long units = (long)p.B * ceil_div(p.H, bth) * ceil_div(p.W, btw) * p.G * ceil_div(p.Ng, bn);
       if (big_knob == 2 && units > 0) {   // (no automatic rule: both channel widths measured slower than the 256-pixel units)
@@ -1006,7 +1028,7 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
       return bn == 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 0, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 0, 1>(p, s);
   }
   static const int deep_knob = std::getenv("DDX_DMA_DEEP") ? atoi(std::getenv("DDX_DMA_DEEP")) : 0;
-  if (ksize == 3 && deep_knob) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
+  if (ksize == 3 && deep_knob && !p.layout) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
   const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);

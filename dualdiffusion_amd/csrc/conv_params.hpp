@@ -30,6 +30,7 @@ struct ConvParams {
   const void* src0_alt; // small-M kernel: source of the output-channel tiles below pro_rows (x * c twin), or null
   const float* out2_cs; // small-M kernel: per-(b, channel) scale of a LINEAR twin (out2 = y * out2_cs), with out2_linear
   int out2_linear;
+  int layout;           // DDX_LAYOUT_* bits: which tensors are channel-blocked [B][C/16][H][W][16] (LDS-DMA kernel)
   int swap1;            // src1 is read from image b ^ 1 (DDX_PAD_SWAP_SRC1)
   int paired;           // input = [src0 | src1 | src0' | src1'], ' = image b ^ 1 (DDX_PAD_SWAP_PAIRED); Cin = 2 * (C0 + C1)
   // DDX_EPI_SILU_BWD (data-gradient conv fused with the backward of the producer-side activation; `res` = y of the first part)

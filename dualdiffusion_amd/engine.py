@@ -42,6 +42,11 @@ AUTOTUNE = os.environ.get("DDX_AUTOTUNE", "0") != "0"
 # registers.  Measured on MI355X (tools/conv_bench.py --cases small, graph-chained launches, B=4): level-4 1x1 layers (344 pixels)
 # 7.0-12.9 us against 9.1-17.2 us on the register-staged split-K kernel; level-3 1x1 layers (1376 pixels) 13-31 us against 12-26 us,
 # and the 3x3 variant (DDX_SM_3X3=1) 10-33 us against 9-28 us -> the default covers what is faster.  0 switches it off.
+# Channel-blocked [B, C/16, H, W, 16] storage of the tensors that only 3x3 LDS-DMA convs read (conv_res0's output, the activated
+# twins written by conv_res1): a K-stage of the consumer is then one contiguous plane slice instead of 32-byte granules a pixel
+# stride apart.  Measured on MI355X (tools/conv_bench.py --epi real --path dma+dma16, B=4): conv_res1 at level 0 63.2 -> 49.3 us
+# (512 -> 256 channels) and 166.6 -> 151.2 us (1024 -> 512), level 1 42.9 -> 38.7 us; conv_res0 layers 3-8 %; bit-identical results.
+C16 = os.environ.get("DDX_C16", "1") != "0"
 SM_MAX_PIXELS = int(os.environ.get("DDX_SM_MAX_PIXELS", "512"))
 SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
 
@@ -78,6 +83,9 @@ class PlanBuilder:
                 ((SM_3X3 and Cg % 16 == 0) if ks == 3 else Cg % 256 == 0)):
             return 16
         return ops.pick_ck(Cg, ks, self.dt, npix)
+
+    def c16_ok(self) -> bool:
+        return C16 and not self.training and self.dt == torch.bfloat16
 
     def gain_slot(self, p) -> int:
         self.gains.append(p)
@@ -181,13 +189,18 @@ class PlanBuilder:
                 S(lambda: ops.pixelnorm(src0, out=x1, out_act=x1a))
             if self.first_cvec_step is None:
                 self.first_cvec_step = len(self.steps)     # conv_res0 is the first reader of a modulation vector
-            S(lambda: ops.conv2d(x1a, pw_res0, out_act=True, out_scale=c_emb, out=y0))
-            S(lambda: ops.conv2d(y0, pw_res1, residual=x1, res_t=res_balance, clip=last_clip, out=xo, **tw_res1))
+            kw0 = dict(out_act=True, out_scale=c_emb, out=y0)
+            kw1 = dict(residual=x1, res_t=res_balance, clip=last_clip, out=xo, **tw_res1)
+            self._block_layouts(None, None, x1a, pw_res0, kw0, y0, pw_res1, kw1, twin if not attn else None)
+            S(lambda: ops.conv2d(x1a, pw_res0, **kw0))
+            S(lambda: ops.conv2d(y0, pw_res1, **kw1))
         else:
             if self.first_cvec_step is None:
                 self.first_cvec_step = len(self.steps)
+            kw0 = None
             if act0 is not None and (src1 is None or act1 is not None):
-                S(lambda: ops.conv2d(act0, pw_res0, out_hw=(h, w), src1=act1, resample=rs, out_act=True, out_scale=c_emb, out=y0))
+                kw0 = dict(out_hw=(h, w), src1=act1, resample=rs, out_act=True, out_scale=c_emb, out=y0)
+                S(lambda: ops.conv2d(act0, pw_res0, **kw0))
             elif pw_res0.CK == 16 and src1 is None:
                 # small-M kernel (raw operands only): one element-wise pass makes the activated operand the producer did not write
                 a0 = self.act(src0.shape[1], src0.shape[2], src0.shape[3])
@@ -214,7 +227,9 @@ class PlanBuilder:
             else:
                 assert src1 is None, "a concatenated input always changes the channel count, i.e. has a skip conv"
                 sk = src0
-            S(lambda: ops.conv2d(y0, pw_res1, residual=sk, res_t=res_balance, clip=last_clip, out=xo, **tw_res1))
+            kw1 = dict(residual=sk, res_t=res_balance, clip=last_clip, out=xo, **tw_res1)
+            self._block_layouts(act0, act1, act0 if kw0 is not None else None, pw_res0, kw0, y0, pw_res1, kw1, twin if not attn else None)
+            S(lambda: ops.conv2d(y0, pw_res1, **kw1))
         if not attn:
             return xo, twin
         heads = blk.num_heads
@@ -240,6 +255,26 @@ class PlanBuilder:
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
+
+    def _block_layouts(self, act0, act1, in0, pw_res0, kw0, y0, pw_res1, kw1, twin) -> None:
+        """Decide which tensors of a block are channel-blocked (ops.mark_c16): the library is asked which kernel each of the two 3x3
+        convs will run on (`query`); only the LDS-DMA kernel reads / writes the blocked layout.
+          * y0 (conv_res0 -> conv_res1): blocked when both run there;
+          * the twin conv_res1 writes for the NEXT block: blocked when conv_res1 runs there -- the consumer takes the mark back when
+            its own conv_res0 does not (the marks are read when the plan is recorded, after every block was declared);
+          * act0 / act1 (twins this block consumes): un-marked when this block's conv_res0 is not an LDS-DMA launch."""
+        q0 = ops.conv2d(in0, pw_res0, query=True, **kw0) if (in0 is not None and kw0 is not None) else 0
+        if q0 != 3:
+            for t in (act0, act1):
+                if t is not None:
+                    ops.mark_c16(t, False)
+        if not self.c16_ok():
+            return
+        q1 = ops.conv2d(y0, pw_res1, query=True, **kw1)
+        if q0 == 3 and q1 == 3 and y0.shape[3] % 16 == 0:
+            ops.mark_c16(y0)
+        if twin is not None and q1 == 3 and twin.shape[3] % 16 == 0 and kw1.get("out2") is twin:
+            ops.mark_c16(twin)
 
     # B*H*W up to which independent convs of a block (skip conv || conv_res0, attn_v || attn_qk) are put on two lanes of
     # the plan.  Measured on MI355X (hipGraph): every fork/join pair costs more cross-queue synchronisation than the

@@ -147,13 +147,34 @@ def _tune_conv(d: "L.ConvDesc") -> int:
     return best_code if best_t < 0.96 * t_auto else 0
 
 
+def mark_c16(t: torch.Tensor, on: bool = True) -> torch.Tensor:
+    """Declare that the bytes of NHWC-shaped `t` [B, H, W, C] are (to be) laid out channel-blocked as [B, C/16, H, W, 16]."""
+    t._ddx_c16 = bool(on)
+    return t
+
+
+def is_c16(t: Optional[torch.Tensor]) -> bool:
+    return t is not None and getattr(t, "_ddx_c16", False)
+
+
+def to_c16(x: torch.Tensor) -> torch.Tensor:
+    """NHWC values -> a marked channel-blocked tensor of the same shape attribute (host-side helper for tests and tools)."""
+    B, H, W, Cn = x.shape
+    return mark_c16(x.reshape(B, H, W, Cn // 16, 16).permute(0, 3, 1, 2, 4).contiguous().reshape(B, H, W, Cn))
+
+
+def from_c16(x: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cn = x.shape
+    return x.reshape(B, Cn // 16, H, W, 16).permute(0, 2, 3, 1, 4).contiguous().reshape(B, H, W, Cn)
+
+
 def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = None, src1: Optional[torch.Tensor] = None,
            scale0: float = 1.0, scale1: float = 1.0, resample: int = L.RESAMPLE_KEEP, prologue: int = L.PRO_NONE,
            chan_scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, res_t: float = 0.0,
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
            path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False, pixelnorm_eps: float = 0.0,
-           out2_chan_scale: Optional[torch.Tensor] = None, src0_alt: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out2_chan_scale: Optional[torch.Tensor] = None, src0_alt: Optional[torch.Tensor] = None, query: bool = False):
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | "sm" (small-M weight-streaming kernel; weights prepared with CK = 16, which also selects it automatically)
@@ -164,7 +185,9 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     swap_paired: the input is [src0 | src1 | src0' | src1'] (' = image b ^ 1): both depth taps over a two-source (mp_cat) operand.
     pixelnorm_eps > 0: the stored output is normalize(y, dim=channels) (DDX_EPI_PIXELNORM; LDS-DMA kernel, one group, Cout <= 64).
     Small-M kernel only: out2_chan_scale [B, Cout] makes out2 the LINEAR twin y_final * out2_chan_scale (operand of attn_qk);
-    src0_alt (with prologue_rows > 0): output channels below prologue_rows read src0_alt instead of src0."""
+    src0_alt (with prologue_rows > 0): output channels below prologue_rows read src0_alt instead of src0.
+    Tensors marked with `mark_c16` are channel-blocked [B, C/16, H, W, 16] (same shape attribute, same bytes; 3x3 LDS-DMA kernel only).
+    query=True: no launch, returns the kernel code the library would choose (2 register-staged, 3 LDS-DMA, 4 small-M, 1 scalar)."""
     B, sH, sW, C0 = src0.shape
     if out_hw is None:
         out_hw = {L.RESAMPLE_KEEP: (sH, sW), L.RESAMPLE_UP: (sH * 2, sW * 2), L.RESAMPLE_DOWN: (sH // 2, sW // 2)}[resample]
@@ -180,7 +203,11 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=(L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO) | (L.PAD_SWAP_SRC1 if swap_src1 else 0) | (L.PAD_SWAP_PAIRED if swap_paired else 0),
                    prologue_rows=prologue_rows, out2_linear=int(out2_chan_scale is not None), out2_chan_scale=ptr(out2_chan_scale), src0_alt=ptr(src0_alt))
-    if d.force_direct == 0 and d.CK != 16 and (_tuning or _conv_choice):
+    if query:
+        return int(lib().ddx_mpconv2d_path(C.byref(d)))
+    d.layout = ((L.LAYOUT_SRC0_C16 if is_c16(src0) else 0) | (L.LAYOUT_SRC1_C16 if is_c16(src1) else 0) |
+                (L.LAYOUT_OUT_C16 if is_c16(out) else 0) | (L.LAYOUT_OUT2_C16 if is_c16(out2) else 0))
+    if d.force_direct == 0 and d.CK != 16 and not d.layout and (_tuning or _conv_choice):
         sig = _conv_signature(d)
         if _tuning and sig not in _conv_choice:
             _conv_choice[sig] = _tune_conv(d)

@@ -104,6 +104,8 @@ enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1,
         * depth taps of a (2,k,k) MPConv3D over an mp_cat operand that is never materialised */
        DDX_PAD_SWAP_PAIRED = 4 };
 
+enum { DDX_LAYOUT_SRC0_C16 = 1, DDX_LAYOUT_SRC1_C16 = 2, DDX_LAYOUT_OUT_C16 = 4, DDX_LAYOUT_OUT2_C16 = 8 };
+
 typedef struct {
   const void* src0;         /* NHWC [B][sH][sW][C0] */
   const void* src1;         /* NHWC [B][sH][sW][C1] or NULL */
@@ -148,11 +150,21 @@ typedef struct {
    *   src0_alt != NULL (with prologue == NONE and prologue_rows > 0): output channels below prologue_rows read src0_alt instead
    *                of src0 -- merged attn_qk | attn_v conv over [x * c_qk | x] without a per-element prologue. */
   int32_t out2_linear;
+  /* Channel-blocked tensors (LDS-DMA kernel, bf16 inference plans): a flagged tensor is stored [B][C/16][H][W][16] instead of NHWC,
+   * so that a K-stage of the 3x3 kernel (16 input channels of a halo row) is ONE contiguous run of (TW+2) * 32 bytes instead of
+   * TW+2 granules of 32 bytes a pixel stride apart (4x fewer cache-line requests per staged byte), and an epilogue store
+   * instruction writes 1 KiB contiguously.  Only tensors whose every reader is a 3x3 LDS-DMA conv qualify (conv_res0's output,
+   * the activated twins): the host decides per tensor (engine.PlanBuilder).  DDX_LAYOUT_* bits; the channel count of a flagged
+   * tensor must be a multiple of 16; DDX_ERR_UNSUPPORTED when the layer does not run on the LDS-DMA kernel. */
+  int32_t layout;
   const float* out2_chan_scale;   /* [B][Cout] fp32 or NULL */
   const void* src0_alt;           /* NHWC like src0, or NULL */
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
+/* Which kernel ddx_mpconv2d_fwd would run for this descriptor (no launch): 1 scalar, 2 register-staged MFMA, 3 LDS-DMA MFMA,
+ * 4 small-M; negative = error code.  The host asks before it decides the layout of a tensor (`layout` is ignored here). */
+int ddx_mpconv2d_path(const ddx_conv_desc* d);
 /* CK the library wants for a conv of this shape (call before wprep).  npix = B*H*W of the output (0 = unknown). */
 int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix);
 

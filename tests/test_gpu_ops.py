@@ -803,6 +803,63 @@ def test_conv_dma_stationary_weights(case):
     assert rel_l2(y_d[:, -1], y_m[:, -1]) < 5e-3 and rel_l2(y_d[:, :, -1], y_m[:, :, -1]) < 5e-3
 
 
+C16_CASES = {
+    # name: (B, H, W, C0, C1, Cout, groups, up, residual, out_act, twin, c16 flags (src0, src1, out, out2))
+    "src_only": (2, 16, 64, 64, 0, 128, 1, False, False, False, False, (1, 0, 0, 0)),
+    "res0_like": (3, 13, 45, 64, 0, 96, 1, False, False, True, False, (1, 0, 1, 0)),           # activated output, new item mapping, ragged tiles
+    "res1_like": (2, 16, 70, 128, 0, 64, 2, False, True, False, True, (1, 0, 0, 1)),           # NHWC residual + raw output, blocked twin
+    "cat_up_mixed": (2, 16, 40, 64, 32, 64, 1, True, False, True, True, (0, 1, 1, 1)),         # NHWC src0, blocked src1, nearest-up, both outputs blocked
+    "cat_both": (1, 8, 96, 96, 32, 128, 1, False, True, False, True, (1, 1, 0, 1)),
+    "grouped_ws": (4, 32, 688, 256, 0, 512, 8, False, False, True, False, (1, 0, 1, 0)),       # stationary-weights variant (Cg = 32), XCD unit order
+    "grouped_ws_res": (4, 32, 700, 512, 0, 256, 8, False, True, False, True, (1, 0, 0, 1)),    # 32-channel tiles (NF = 1)
+    "l1_like": (4, 16, 344, 512, 0, 1024, 8, False, False, True, False, (1, 0, 1, 0)),
+}
+
+
+@pytest.mark.parametrize("name", list(C16_CASES))
+def test_conv_dma_channel_blocked(name):
+    """Channel-blocked [B, C/16, H, W, 16] operands / results of the 3x3 LDS-DMA kernel: the same launch on NHWC tensors gives the
+    same bits (the layout only changes addresses), for every combination of blocked sources and outputs the plans use."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dt = torch.bfloat16
+    B, H, W, C0, C1, Cout, G, up, has_res, out_act, twin, (f0, f1, fo, fo2) = C16_CASES[name]
+    g = torch.Generator(device="cuda").manual_seed(sum(map(ord, name)))
+    sh, sw = (H // 2, W // 2) if up else (H, W)
+    a0 = torch.randn(B, sh, sw, C0, device="cuda", generator=g).to(dt)
+    a1 = torch.randn(B, sh, sw, C1, device="cuda", generator=g).to(dt) if C1 else None
+    w = torch.randn(Cout, (C0 + C1) // G, 3, 3, device="cuda", generator=g)
+    r = torch.randn(B, H, W, Cout, device="cuda", generator=g).to(dt) if has_res else None
+    cs = torch.rand(B, Cout, device="cuda", generator=g) + 0.5
+    pw = ops.wprep(w, G, dt, npix=B * H * W)
+    kw = dict(out_hw=(H, W), resample=L.RESAMPLE_UP if up else L.RESAMPLE_KEEP, residual=r, res_t=0.3, clip=256.0 if has_res else 0.0,
+              out_act=out_act, out_scale=cs if out_act else None, out2_scale=0.8, path="dma")
+    tw_ref = torch.zeros(B, H, W, Cout, device="cuda", dtype=dt) if twin else None
+    y_ref = ops.conv2d(a0, pw, src1=a1, out2=tw_ref, **kw)
+    out = ops.mark_c16(torch.zeros(B, H, W, Cout, device="cuda", dtype=dt), bool(fo))
+    tw = ops.mark_c16(torch.zeros(B, H, W, Cout, device="cuda", dtype=dt), bool(fo2)) if twin else None
+    y = ops.conv2d(ops.to_c16(a0) if f0 else a0, pw, src1=(ops.to_c16(a1) if f1 else a1) if C1 else None, out=out, out2=tw, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_ref.float()).all() and y_ref.float().abs().max() > 0
+    assert torch.equal(ops.from_c16(y) if fo else y, y_ref), name
+    if twin:
+        assert torch.equal(ops.from_c16(tw) if fo2 else tw, tw_ref), name
+    # the query names the kernel the automatic choice takes for this shape (what the plan builder asks before it blocks a tensor)
+    assert ops.conv2d(a0, pw, src1=a1, query=True, **{**kw, "path": "auto"}) in (2, 3)
+
+
+def test_conv_channel_blocked_needs_the_dma_kernel():
+    ops = _ops()
+    from dualdiffusion_amd._lib import DDXError
+    dt = torch.bfloat16
+    a = ops.mark_c16(torch.zeros(1, 4, 8, 64, device="cuda", dtype=dt))
+    pw = ops.wprep(torch.randn(64, 64, 3, 3, device="cuda"), 1, dt)
+    with pytest.raises(DDXError):
+        ops.conv2d(a, pw)            # 32 pixels: the automatic choice is the register-staged kernel, which reads NHWC only
+    with pytest.raises(DDXError):
+        ops.conv2d(a, ops.wprep(torch.randn(64, 64, 1, 1, device="cuda"), 1, dt), path="dma")   # 1x1: NHWC only
+
+
 SM_CASES = {
     # name: (B, H, W, C0, C1, Cout, groups, ksize, resample, residual, clip, out_act, twin, special)
     "k3_l4": (4, 2, 43, 320, 0, 128, 2, 3, "keep", True, 256.0, False, True, None),          # whole image = one 96-pixel tile, Cg = 160

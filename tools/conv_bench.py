@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--cases", default=",".join(CASES))
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--path", default="auto", help="auto | mfma | dma | both")
+    ap.add_argument("--path", default="auto", help="auto | mfma | dma | sm | dma16 (LDS-DMA kernel on channel-blocked tensors) | both; a+b runs several")
+    ap.add_argument("--epi", default="plain", help="plain | real (conv_res0: activated output with channel scales; conv_res1: residual + activated twin)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
@@ -98,9 +99,21 @@ def main():
         raw = name.endswith('_raw')
         kw = dict(out_hw=(H, W), src1=a1, scale0=1.0 if raw else 0.8, scale1=1.0 if raw else 1.1, resample=rs, prologue=pro,
                   chan_scale=cs if pro & L.PRO_SCALE else None, residual=res, res_t=0.3, clip=256.0, out=out)
+        if a.epi == "real" and raw:
+            if has_res:
+                kw.update(out2=torch.empty_like(out), out2_scale=0.8)
+            else:
+                kw.update(out_act=True, out_scale=torch.rand(B, Cout, device=dev) + 0.5, clip=0.0)
         for path in (["mfma", "dma"] if a.path == "both" else a.path.split("+")):
-            kw["path"] = path
-            pw = pw_sm if path == "sm" else pw_std
+            kw["path"] = "dma" if path in ("dma16", "dmaw", "dma16w") else path      # ..w: weights chunked by the kernel's 16-channel stage
+            pw = pw_sm if path in ("sm", "dmaw", "dma16w") else pw_std
+            blk = path in ("dma16", "dma16w")
+            a0 = ops.mark_c16(a0, blk)
+            if a1 is not None:
+                ops.mark_c16(a1, blk)
+            ops.mark_c16(out, blk and not has_res)
+            if kw.get("out2") is not None:
+                ops.mark_c16(kw["out2"], blk)
             try:
                 for _ in range(3):
                     ops.conv2d(a0, pw, **kw)

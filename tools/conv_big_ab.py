@@ -32,6 +32,9 @@ CASES = {
     "L0 128->64 x8 res": (4, 32, 688, 1024, 0, 512, 8, 0, True, False, True),
     "L1 128->64 x8 res": (4, 16, 344, 1024, 0, 512, 8, 0, True, False, False),
     "L1 96->128 x8": (4, 16, 344, 768, 0, 1024, 8, 0, False, True, False),
+    "L1 64->128 x8 act": (4, 16, 344, 512, 0, 1024, 8, 0, False, True, False),
+    "L2 96->192 x8 act": (4, 8, 172, 768, 0, 1536, 8, 0, False, True, False),
+    "L2 192->96 x8 res twin": (4, 8, 172, 1536, 0, 768, 8, 0, True, False, True),
     "ragged 30x70 64->64": (2, 30, 70, 128, 0, 128, 2, 0, True, False, True),
     "ddec L0 32->32 act": (2, 256, 5504, 32, 0, 32, 1, 0, False, True, False),
     "ddec L0 32->32 res": (2, 256, 5504, 32, 0, 32, 1, 0, True, False, False),
