@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_unet.py tests/test_gpu_ops.py tests/test_gpu_sampler.py tests/test_gpu_config3.py tests/test_gpu_dae.py tests/test_gpu_ddec.py -x -q > gpurun_out/c16_tests.log 2>&1; tail -5 gpurun_out/c16_tests.log
+timeout 300 python tools/g1_check.py 2>&1 | grep -v amdgpu | tail -3
+C=L3_v_raw,L3_proj_raw,L3_skip_cat_raw,L3_up_skip_raw,L3_qkv,L2_skip_cat_raw,L4_v_raw,L4_dec_skip_raw,L4_qkv
+for cfg in "0 0" "2 2" "2 1" "1 2" "1 1"; do set -- $cfg; echo "== NST=8 MF=$1 NF=$2"; DDX_G1_MF=$1 DDX_G1_NF=$2 timeout 300 python tools/conv_bench.py --path g1 --cases $C 2>&1 | grep -v "amdgpu\|unsupp"; done
