@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/g1_check.py 2>&1 | grep -v amdgpu | tail -3
-C=L3_v_raw,L3_proj_raw,L3_skip_cat_raw,L3_up_skip_raw,L3_qkv,L2_skip_cat_raw,L4_v_raw,L4_dec_skip_raw,L4_qkv
-for cfg in "0 0" "2 2" "2 1" "1 2" "1 1"; do set -- $cfg; echo "== NST=8 MF=$1 NF=$2"; DDX_G1_MF=$1 DDX_G1_NF=$2 timeout 300 python tools/conv_bench.py --path g1 --cases $C 2>&1 | grep -v "amdgpu\|unsupp"; done
+C=L0_skip_256_raw,L0_skip_512_raw,L0_skip_cat_raw,L1_skip_cat_raw,L0_skip_512
+echo "== default"; timeout 300 python tools/conv_bench.py --path dma --cases $C 2>&1 | grep -v amdgpu
+echo "== WIDE=0"; DDX_DMA_WIDE=0 timeout 300 python tools/conv_bench.py --path dma --cases $C 2>&1 | grep -v amdgpu
+echo "== mfma"; timeout 300 python tools/conv_bench.py --path mfma --cases $C 2>&1 | grep -v amdgpu
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default', d['ms_per_step'], d['roofline']['families_ms'])"
+DDX_DMA_WIDE=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wide0', d['ms_per_step'], d['roofline']['families_ms'])"
