@@ -146,15 +146,22 @@ class UNetTrainStep:
         self._accum: Optional[torch.Tensor] = None
         self.last_gathered: list = []        # per micro-step: [loss, sigma] of the GLOBAL micro-batch (one all_gather each)
 
-    def _train_batch_graph(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation):
+    def _train_batch_graph(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook=None, split=False):
+        """Replay the captured train batch.  With `split` (a gradient exchange exists) the batch is captured as TWO graphs, cut where the
+        trainer calls its bucket hook -- [forward, loss, decoder backward] | [encoder backward] -- and `hook` (the asynchronous
+        all-reduce of the decoder's gradient bucket; None on the micro-steps of an accumulation that do not communicate) runs between
+        the two replays, so the early collective travels on RCCL's stream while the second graph runs (a capture cannot contain the
+        collective itself)."""
         dev = self.unet.device
         ins = [samples.to(dev, torch.float32), audio_embeddings.to(dev, torch.float32), sigma.flatten().to(dev, torch.float32),
                noise.to(dev, torch.float32), conditioning_mask.to(dev), perturbation.to(dev, torch.float32) if perturbation is not None else None]
-        key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in ins)
+        key = (bool(split),) + tuple((tuple(t.shape), t.dtype) if t is not None else None for t in ins)
+        tr = self.trainer
         if self._graph is None or key != self._graph_key:
             self._static = [t.clone() if t is not None else None for t in ins]
             st = self._static
-            run = lambda: self.trainer.train_batch(st[0], st[1], st[2], st[3], st[4], self.format, st[5], self.input_perturbation)   # noqa: E731
+            run = lambda: tr.train_batch(st[0], st[1], st[2], st[3], st[4], self.format, st[5], self.input_perturbation)   # noqa: E731
+            tr.bucket_hook = None
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # eager warm-up on a side stream: weight bank, job tables, kernel attributes
@@ -162,22 +169,47 @@ class UNetTrainStep:
                 run()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._graph_out = run()
+            self._graph, self._graph_tail = torch.cuda.CUDAGraph(), None
+            if not split:
+                with torch.cuda.graph(self._graph):
+                    self._graph_out = run()
+            else:
+                tail = torch.cuda.CUDAGraph()
+                split = {"done": False}
+
+                def split_here():            # called by the trainer once the early part of the gradient bucket is final
+                    self._graph.capture_end()
+                    tail.capture_begin(pool=self._graph.pool())
+                    split["done"] = True
+
+                tr.bucket_hook = split_here
+                with torch.cuda.stream(side):
+                    self._graph.capture_begin()
+                    try:
+                        self._graph_out = run()
+                    finally:
+                        (tail if split["done"] else self._graph).capture_end()
+                        tr.bucket_hook = None
+                torch.cuda.current_stream().wait_stream(side)
+                self._graph_tail = tail if split["done"] else None
             self._graph_key = key
         for d, t in zip(self._static, ins):
             if d is not None:
                 d.copy_(t)
         self._graph.replay()
+        if self._graph_tail is not None:
+            if hook is not None:
+                hook()
+            self._graph_tail.replay()
+        # (no split point -- the trainer never called the hook, e.g. an empty early bucket: GradientExchange.finish sends everything)
         return self._graph_out
 
     # ------------------------------------------------------------------------------------------------ micro-steps
-    def _micro(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook):
+    def _micro(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook, split=False):
         tr = self.trainer
         tr.bucket_hook = hook
         if self.use_graph:
-            return self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation)
+            return self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook, split or hook is not None)
         return tr.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation, self.input_perturbation)
 
     def _finish(self, loss, grads, world: int, n_micro: int, ex: Optional[GradientExchange], device_batch: int) -> dict:
@@ -220,8 +252,8 @@ class UNetTrainStep:
         """One optimizer step on this rank's batch, ONE micro-step (the random draws are inputs: the caller owns the generators)."""
         world = _world_size()
         ex = self._exchange(world, 1)
-        # eager: the decoder's bucket travels while the encoder is back-propagated; graph replay: one collective after the replay
-        hook = ex.start_early if (ex is not None and not self.use_graph) else None
+        # the decoder's bucket travels while the encoder is back-propagated (graph mode: between the two captured halves)
+        hook = ex.start_early if ex is not None else None
         loss, grads = self._micro(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook)
         return self._finish(loss, grads, world, 1, ex, int(samples.shape[0]))
 
@@ -255,8 +287,8 @@ class UNetTrainStep:
             mask = torch.rand(Bd, generator=generator, device=generator.device if generator is not None else dev) > self.conditioning_dropout
             noise = torch.randn(x.shape, generator=generator, device=mask.device)
             pert = torch.randn(x.shape, generator=generator, device=mask.device) if self.input_perturbation > 0 else None
-            hook = ex.start_early if (ex is not None and last and not self.use_graph) else None
-            loss, grads = self._micro(x, e, sig, noise, mask, pert, hook)
+            hook = ex.start_early if (ex is not None and last) else None
+            loss, grads = self._micro(x, e, sig, noise, mask, pert, hook, split=ex is not None)
             if not last:                      # no_sync micro-step: gradients stay local
                 self._accum.add_(self.trainer.grad_flat)
             self.last_gathered.append(D.gather_scalars([loss, sig]))       # one small collective per micro-step
