@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r02_gpu_tests.log 2>&1; grep -n "passed\|failed" gpurun_out/r02_gpu_tests.log | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -2
-python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_final.json 2> gpurun_out/r02_bench_final.err; cat gpurun_out/r02_bench_final.json | cut -c1-1800
+C=L4_res0_raw,L4_res1_raw,L4_dec_res0_raw,L4_qkv_raw,L4_v_raw,L4_dec_skip_raw,L3_res0_raw,L3_res1_raw,L3_dec_res0_raw,L3_qkv_raw,L3_v_raw,L3_skip_cat_raw,L2_res0_raw,L2_skip_cat_raw
+echo "== hot"; timeout 600 python tools/conv_bench.py --iters 80 --cases $C 2>&1 | grep -v amdgpu
+echo "== cold (80 weight buffers)"; timeout 600 python tools/conv_bench.py --iters 80 --cold 80 --cases $C 2>&1 | grep -v amdgpu

@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--path", default="auto", help="auto | mfma | dma | sm | dma16 (LDS-DMA kernel on channel-blocked tensors) | both; a+b runs several")
+    ap.add_argument("--cold", type=int, default=0, help="N > 0: cycle through N distinct prepared-weight buffers inside the timed graph (weights stream from HBM as in the network, instead of staying cache-resident)")
     ap.add_argument("--epi", default="plain", help="plain | real (conv_res0: activated output with channel scales; conv_res1: residual + activated twin)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -122,10 +123,13 @@ def main():
                 continue
             torch.cuda.synchronize()
             # the host cannot enqueue a 10 us kernel every 10 us through ctypes: time a hipGraph of `iters` back-to-back launches
+            pws = [pw]
+            if a.cold > 0:
+                pws = [ops.wprep(torch.randn_like(w), G, dt, CK=pw.CK) for _ in range(a.cold)]
             plan = L.Plan()
             with plan.record():
-                for _ in range(a.iters):
-                    ops.conv2d(a0, pw, **kw)
+                for it in range(a.iters):
+                    ops.conv2d(a0, pws[it % len(pws)], **kw)
             cap = torch.cuda.Stream()
             plan.graph_build(cap.cuda_stream)
             cap.synchronize()
