@@ -1,6 +1,8 @@
 // Row-level device functions of the weight path (reference src/modules/mp_tools.py:359-364 forward, :375-378 forced
 // normalisation) shared by the single-tensor kernels (conv.hip, backward.hip) and the multi-tensor launches (wpath.hip).
-// Every function is executed by ONE 256-thread workgroup for one row; `scratch` = 4 floats of LDS.
+// Every function is executed by ONE 256-thread workgroup for one row; `scratch` = 4 floats of LDS.  The `_w` variants below are
+// executed by ONE WAVE per row (multi-tensor launches: rows are 1-15 KB, a workgroup with two block reductions per row spends its time
+// in set-up and barriers), with 16-byte accesses where the row length allows it; same arithmetic, wave-strided summation order.
 #pragma once
 #include "conv_params.hpp"
 
@@ -127,6 +129,137 @@ __device__ __forceinline__ void wprep_bwd_row(const float* __restrict__ dwp, con
   }
   // d(loss)/d(gain parameter): g_eff = gain * (*gain_ptr)
   if (dgain && threadIdx.x == 0) atomicAdd(dgain, gain * su * rfan / nu);
+}
+
+// ------------------------------------------------------------------------------------------------ one wave per row (fp32 master weights)
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ float wave_row_sumsq(const float* __restrict__ wr, int fan, int lane) {
+  float ss = 0.f;
+  if ((fan & 3) == 0 && aligned16(wr)) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(wr);
+    for (int i = lane; i < (fan >> 2); i += 64) { const f32x4 v = p[i]; ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+  } else {
+    for (int i = lane; i < fan; i += 64) { const float x = wr[i]; ss += x * x; }
+  }
+  return wave_sum(ss);
+}
+
+__device__ __forceinline__ void normalize_row_w(float* w, int64_t fan, float eps, int64_t row, int lane) {
+  float* wr = w + (size_t)row * fan;
+  const float ss = wave_row_sumsq(wr, (int)fan, lane);
+  const float nrm = eps + sqrtf(ss) * sqrtf(1.0f / (float)fan);
+  if ((fan & 3) == 0 && aligned16(wr)) {
+    f32x4* p = reinterpret_cast<f32x4*>(wr);
+    for (int i = lane; i < (int)(fan >> 2); i += 64) { f32x4 v = p[i]; v[0] /= nrm; v[1] /= nrm; v[2] /= nrm; v[3] /= nrm; p[i] = v; }
+  } else {
+    for (int i = lane; i < (int)fan; i += 64) wr[i] = wr[i] / nrm;
+  }
+}
+
+template <typename TP>
+__device__ __forceinline__ void wprep_row_w(const float* __restrict__ w, TP* __restrict__ wp, const float* gain_ptr, float gain, int Cout, int Cg,
+                                            int taps, int G, int CK, int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1,
+                                            int od, int lane, float* row_scale) {
+  const int Ng = Cout / G, NgP = (Ng + 31) / 32 * 32, nchunk = (Cg + CK - 1) / CK;
+  const int g = od / Ng, n = od - g * Ng;
+  const int os = wpath_src_row(od, qk_d);
+  const int fan = Cg * taps;
+  const float* wr = w + (size_t)os * fan;
+  float inv = 1.f;
+  if (normalize) inv = eps + sqrtf(wave_row_sumsq(wr, fan, lane)) * sqrtf(1.0f / (float)fan);
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float sc = gn / sqrtf((float)fan);
+  if (row_scale && lane == 0) row_scale[os] = sc / inv;
+  auto put = [&](int i, float x) {
+    const int c = i / taps, tap = i - c * taps;
+    if (normalize) x = x / inv;
+    float scc = sc;
+    if (in_split > 0) scc *= (g * Cg + c < in_split) ? in_s0 : in_s1;
+    wp[wp_index(g, n, tap, c, nchunk, taps, NgP, CK)] = from_f32<TP>(x * scc);
+  };
+  if ((fan & 3) == 0 && aligned16(wr)) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(wr);
+    for (int i = lane; i < (fan >> 2); i += 64) {
+      const f32x4 v = p[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put(4 * i + e, v[e]);
+    }
+  } else {
+    for (int i = lane; i < fan; i += 64) put(i, wr[i]);
+  }
+}
+
+__device__ __forceinline__ void wprep_rowscale_row_w(const float* __restrict__ w, float* __restrict__ row_scale, const float* gain_ptr, float gain,
+                                                     int fan, int normalize, float eps, int row, int lane) {
+  float inv = 1.f;
+  if (normalize) inv = eps + sqrtf(wave_row_sumsq(w + (size_t)row * fan, fan, lane)) * sqrtf(1.0f / (float)fan);
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  if (lane == 0) row_scale[row] = gn / sqrtf((float)fan) / inv;
+}
+
+template <typename TP>
+__device__ __forceinline__ void wprep_transposed_row_w(const float* __restrict__ w, TP* __restrict__ wp, const float* __restrict__ row_scale, int Cout,
+                                                       int Cg, int taps, int G, int CK, int qk_d, int in_split, float in_s0, float in_s1, int ci, int lane) {
+  const int Ng = Cout / G, CgP = (Cg + 31) / 32 * 32, nchunk = (Ng + CK - 1) / CK;
+  const int g = ci / Cg, c = ci - g * Cg;
+  const float cscale = in_split > 0 ? (ci < in_split ? in_s0 : in_s1) : 1.0f;
+  for (int i = lane; i < Ng * taps; i += 64) {
+    const int n = i / taps, tap = i - n * taps;
+    const int os = wpath_src_row(g * Ng + n, qk_d);
+    const float x = w[((size_t)os * Cg + c) * taps + tap] * row_scale[os] * cscale;
+    wp[wp_index(g, c, taps - 1 - tap, n, nchunk, taps, CgP, CK)] = from_f32<TP>(x);
+  }
+}
+
+__device__ __forceinline__ void wprep_bwd_row_w(const float* __restrict__ dwp, const float* __restrict__ w, const float* gain_ptr, float gain,
+                                                float* __restrict__ dw, float* __restrict__ dgain, int Cout, int Cg, int taps, int G, int normalize,
+                                                int qk_d, float eps, int in_split, float in_s0, float in_s1, int od, int lane) {
+  const int Ng = Cout / G;
+  const int g = od / Ng;
+  const int os = wpath_src_row(od, qk_d);
+  const int fan = Cg * taps;
+  const float* wr = w + (size_t)os * fan;
+  const float* gr = dwp + (size_t)od * fan;
+  auto cat_scale = [&](int i) { return in_split > 0 ? ((g * Cg + i / taps < in_split) ? in_s0 : in_s1) : 1.0f; };
+  float* dr = dw + (size_t)os * fan;
+  const bool vec = (fan & 3) == 0 && aligned16(wr) && aligned16(gr) && aligned16(dr);
+  float ss = 0.f, su = 0.f;
+  if (vec) {
+    const f32x4 *pw = reinterpret_cast<const f32x4*>(wr), *pg = reinterpret_cast<const f32x4*>(gr);
+    for (int i = lane; i < (fan >> 2); i += 64) {
+      const f32x4 x = pw[i], gv = pg[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ss += x[e] * x[e]; su += gv[e] * cat_scale(4 * i + e) * x[e]; }
+    }
+  } else {
+    for (int i = lane; i < fan; i += 64) { const float x = wr[i]; ss += x * x; su += gr[i] * cat_scale(i) * x; }
+  }
+  ss = wave_sum(ss);
+  su = wave_sum(su);
+  const float rfan = sqrtf(1.0f / (float)fan);
+  const float n = sqrtf(ss);
+  const float nu = normalize ? eps + n * rfan : 1.0f;
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float s = gn * rfan;
+  const float k = (normalize && n > 0.f) ? su * rfan / (nu * n) : 0.f;
+  if (vec) {
+    const f32x4 *pw = reinterpret_cast<const f32x4*>(wr), *pg = reinterpret_cast<const f32x4*>(gr);
+    f32x4* pd = reinterpret_cast<f32x4*>(dr);
+    for (int i = lane; i < (fan >> 2); i += 64) {
+      const f32x4 x = pw[i], gv = pg[i];
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (s / nu) * (gv[e] * cat_scale(4 * i + e) - x[e] * k);
+      pd[i] = v;
+    }
+  } else {
+    for (int i = lane; i < fan; i += 64) dr[i] = (s / nu) * (gr[i] * cat_scale(i) - wr[i] * k);
+  }
+  if (dgain && lane == 0) atomicAdd(dgain, gain * su * rfan / nu);
 }
 
 }  // namespace ddx
