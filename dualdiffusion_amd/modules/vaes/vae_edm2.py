@@ -245,7 +245,9 @@ class _VAEEngine:
         # the reference standardises ln_freqs over the WHOLE batch tensor (unbiased std: depends on the element count), so a
         # chunk of a larger batch asks for the table of the full batch size
         nb = full_batch or self.B
-        lkey = (id(format), nb)
+        fs = getattr(format, "freq_scale", None)          # by value: an id() can be recycled by a different format object
+        lkey = (type(format).__name__, type(fs).__name__, getattr(fs, "freq_scale", None), float(getattr(fs, "freq_min", 0.0)),
+                float(getattr(fs, "freq_max", 0.0)), int(getattr(fs, "num_filters", 0)), nb) if fs is not None else (id(format), nb)
         if lkey != self._lnf_key:
             rows = format.get_ln_freqs(torch.empty(nb, 1, self.H, self.W))[0, 0, :, 0]   # host-side table, same dtype sequence
             self.lnf.copy_(rows.float())
