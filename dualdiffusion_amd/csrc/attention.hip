@@ -10,6 +10,8 @@
 //   O^T tile (32 dims x 32 queries) += V^T . P^T     : A operand = V^T rows (dims), B operand = P straight from the
 //   S^T accumulator registers (the key order inside an MFMA k-slot is arbitrary as long as A and B agree, so no
 //   cross-lane permutation of P is needed; V^T is staged transposed so the matching keys are contiguous).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ddx {
@@ -24,7 +26,7 @@ template <> struct AttnMma<float> {
   using Frag = float;
 };
 
-template <typename T, int D>
+template <typename T, int D, int KC_>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
                                                        const float* __restrict__ out_cs, int B, int Tn, int heads, float eps, int qk_ld, int v_ld,
                                                        int fold) {
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   constexpr int VPR = D / EV;           // 16-byte vectors per token row
   constexpr int RPP = 256 / VPR;        // rows staged per pass
   constexpr int QS = D + EV;            // Q / K row stride (elements)
-  constexpr int KC = 128;               // keys per chunk
+  constexpr int KC = KC_;               // keys per chunk (128; 64 keeps the D = 64 bf16 kernel under 256 registers)
   constexpr int VS = KC + AttnMma<T>::VPAD;
   constexpr int KM = AttnMma<T>::KM;
   constexpr int NDT = D / 32;           // 32-row tiles of O^T
@@ -62,13 +64,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   // Global loads of a staging phase are ALL issued before the first of them is consumed (Q tile and the first K / V chunk
   // together, later chunks while the previous one is multiplied): the loops below used to expose one memory latency per
   // 32-row pass, i.e. 8 in a row for a 128-query tile with one key chunk (the L4 / L3 attention layers are latency-bound).
-  constexpr int NP = 128 / RPP;
-  static_assert(KC == 128, "the staging passes assume 128-row tiles");
+  constexpr int NP = 128 / RPP;          // staging passes of the 128-query tile
+  constexpr int NPK = KC / RPP;          // ... of a key chunk
+  static_assert(KC % RPP == 0 && NPK >= 1, "a key chunk is a whole number of staging passes");
   using VT = decltype(Vec16<T>::v);
-  VT qreg[NP], kreg[NP], vreg[NP];
+  VT qreg[NP], kreg[NPK], vreg[NPK];
   auto issue_kv = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < NPK; ++i) {
       const int key = c0 + sr + i * RPP;
       VT z = {};
       kreg[i] = z; vreg[i] = z;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
     __syncthreads();  // previous chunk fully consumed
     // ---- stage K (normalised) and V^T (normalised, transposed) from the registers loaded ahead
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < NPK; ++i) {
       const int r = sr + i * RPP;
       float fk[EV], fv[EV];
       float ssk = 0.f, ssv = 0.f;
@@ -257,14 +260,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   }
 }
 
-template <typename T, int D>
-static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
-                       int v_ld, int fold = 1) {
+template <typename T, int D, int KC>
+static int launch_attn_kc(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
+                          int v_ld, int fold) {
   constexpr int EV = 16 / (int)sizeof(T);
-  constexpr int KC = 128;
   const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + (size_t)D * (KC + AttnMma<T>::VPAD)) * sizeof(T);
   if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim too large for this dtype");
-  auto kern = attn_fwd_kernel<T, D>;
+  auto kern = attn_fwd_kernel<T, D, KC>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -274,6 +276,17 @@ static int launch_attn(const void* qk, const void* v, void* out, const float* cs
   dim3 grid((Tn + 127) / 128, heads, B);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps, qk_ld, v_ld, fold);
   return check_launch("attn_fwd");
+}
+
+template <typename T, int D>
+static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
+                       int v_ld, int fold = 1) {
+  // 64-key chunks for the bf16 head_dim-64 kernel of the UNet (experiment knob DDX_ATTN_KC=128: the former 128-key chunks)
+  static const int kc_knob = std::getenv("DDX_ATTN_KC") ? atoi(std::getenv("DDX_ATTN_KC")) : 64;
+  if constexpr (sizeof(T) == 2 && D == 64) {
+    if (kc_knob == 64) return launch_attn_kc<T, D, 64>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+  }
+  return launch_attn_kc<T, D, 128>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
 }
 
 }  // namespace ddx
