@@ -1,4 +1,4 @@
-# Build libddx_hip.so (gfx950 only) and the C oracle helpers.  `python -c "import __graft_entry__ as g; g.build()"` calls this.
+# Build libddx_hip.so (gfx950 only).  `python -c "import __graft_entry__ as g; g.build()"` calls this.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := dualdiffusion_amd/csrc
@@ -19,7 +19,7 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 # one-off hardware probes quoted in DESIGN.md (run on the GPU box)
-probes: tools/probe/bufload_lds_probe tools/probe/ds_read_tr_probe tools/probe/launch_floor_probe tools/probe/stage_bw_probe tools/probe/grid_barrier_probe
+probes: tools/probe/bufload_lds_probe tools/probe/ds_read_tr_probe tools/probe/launch_floor_probe tools/probe/stage_bw_probe tools/probe/grid_barrier_probe tools/probe/store_pattern_probe
 tools/probe/%: tools/probe/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 

@@ -100,16 +100,39 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
 // starts half a unit late so that one workgroup's memory phases (epilogue stores, first-stage latency) fall into the
 // other's matrix phase instead of both doing the same thing at the same time.
 // EB = 1: the epilogue is the backward of a = mp_silu(y * s) instead of mp_sum / activation (DDX_EPI_SILU_BWD, see ddx_hip.h).
-// DEEP = 1: activation ring of three stages and weight ring of two (see the DEEP main loop)
+// NK > 0 ("resident" mode, 3x3 layers with NK * 16 <= 64 input channels per group): like WS the workgroup keeps ONE (group, channel
+// tile) and all NK weight stages for the whole launch; in addition the WHOLE halo tile of a unit (all NK 16-channel planes) is
+// fetched at once into one of two tile buffers while the previous unit is multiplied -- one barrier and one batch of fat DMA
+// requests per unit instead of one per 16-channel stage (the full-resolution layers are bound by bytes in flight per CU, not
+// by the matrix pipe).  Eight waves, one tile row of 32 pixels each (WM = 8, MF = 1), one workgroup per CU.
+// REG = 1 (NK > 0): the epilogue stays in registers (v_cvt_pk + v_permlane32_swap give every lane 8 consecutive channels of its
+// pixel) and stores 1-KiB runs of a channel-blocked output; no LDS patches (the 64 -> 64-channel-tile case needs all 160 KiB).
+// PC = 1 (NK > 0): one extra PRODUCER wave issues every tile DMA; the eight consumer waves never touch the load path and run free
+// (no workgroup barrier after the prologue): tile buffers are handed over through two LDS counters per buffer (`full`: tiles the
+// producer has landed, `empty`: consumer waves done reading).  A wave that sits at a vector-memory instruction while the CU's
+// memory pipe is saturated (a full-resolution layer moves ~75 KB per unit at ~10 B/clk/CU) then stalls only itself: the loads
+// stall the producer, an epilogue's stores stall one consumer while the other wave of its SIMD keeps the matrix pipe busy.
 // WS = 1: weights stationary -- a workgroup keeps ONE (group, channel tile), its nk weight stages stay in LDS for the whole launch
 // and only activations stream (layers with few input channels per group, where the weight slices are most of the staged bytes)
-template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0, int WS = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd, const int tile_order) {
+template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int WS = 0, int NK = 0, int REG = 0, int PC = 0>
+__global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
   constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
   constexpr int KSTEPS = SK / 16;
+  constexpr bool RES = NK > 0;
+  constexpr bool WSMAP = WS || RES;          // workgroup <-> (group, channel tile) mapping of the stationary-weights variants
+  // resident mode: 8 x 32 pixel tiles, halo 10 x 34 = 340 rows of RB bytes per 16-channel plane, planes packed (the 11th DMA piece
+  // of a plane starts at row 308 and rewrites 12 rows of the 10th with the same bytes instead of running into the next plane)
+  constexpr int RROWS = 340, RA = RROWS * RB;
+  constexpr int R_WOFF = 2 * NK * RA;                                            // weight stages behind the two tile buffers
+  constexpr int R_EOFF = R_WOFF + NK * GEO::B_BYTES;                             // epilogue patches (REG = 0)
+  constexpr int R_FLOFF = R_EOFF + (REG ? 0 : NW * GEO::EPI_WAVE);               // hand-over counters (PC): full[2], empty[2]
+  constexpr int R_CSOFF = R_FLOFF + 64;                                          // channel scales of all images, loaded once
+  static_assert(!PC || RES, "producer wave: resident mode only");
+  static_assert(!RES || (KS == 3 && SK == 16 && WN == 1 && WM == 8 && MF == 1 && !EB && !WS), "resident mode: 3x3, eight waves of one tile row");
+  static_assert(!REG || RES, "register epilogue: resident mode only");
   constexpr bool LATE_RES = NF * MF > 4;  // too many fragments to hold every residual row during the last matrix phase
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -136,19 +159,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   auto order = [&](int u) { return per_xcd ? (u & 7) * per_xcd + (u >> 3) : u; };
   // WS order: workgroup w owns combo (w >> 3) % gn = (channel tile, group) and the tiles j, j + stride, ... with
   // j = (w & 7) + 8 * (w / (8 * gn)), stride = gridDim.x / gn: every XCD (w & 7) sees all groups of its own tiles
-  const int ws_c = WS ? (int)((blockIdx.x >> 3) % gn) : 0;
-  const int ws_j = WS ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x / (8 * gn))) : 0;
-  const int ws_stride = WS ? (int)(gridDim.x / gn) : 1;
+  const int ws_c = WSMAP ? (int)((blockIdx.x >> 3) % gn) : 0;
+  const int ws_j = WSMAP ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x / (8 * gn))) : 0;
+  const int ws_stride = WSMAP ? (int)(gridDim.x / gn) : 1;
   const float inv_grid = 1.0f / (float)gridDim.x;
   auto ws_tile = [&](int u) { return ws_j + fdiv(u, inv_grid) * ws_stride; };
   auto live = [&](int u) {
-    if constexpr (WS) return ws_tile(u) < ntile_px;
+    if constexpr (WSMAP) return ws_tile(u) < ntile_px;
     else return per_xcd ? ((u >> 3) < per_xcd && order(u) < total_units) : u < total_units;
   };
   auto decode = [&](int u) {
     Unit t;
     int tile;
-    if constexpr (WS) {
+    if constexpr (WSMAP) {
       tile = ws_tile(u);
       const int nt = fdiv(ws_c, inv_G);
       t.g = ws_c - nt * p.G;
@@ -166,30 +189,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
       t.g = fdiv(r, inv_nn);
       t.n0 = (r - t.g * ntile_n) * BN;
     }
-    // tile -> (image, tile row, tile column).  tile_order 0: row-major.  1: column-major inside an image (the XCD-contiguous
-    // order walks consecutive tiles, so vertical neighbours -- which share 2 of the 10 halo rows -- run back to back in one L2).
-    // 2: plain order, where tile T runs on XCD T % 8 at time T / 8: columns of tiles_h tiles are dealt to the XCDs as runs
-    // (run r = image * tiles_w + column -> XCD r % 8), so a column's tiles are resident together in one L2.
-    if (tile_order == 0) {
-      const int row = fdiv(tile, inv_tw);
-      t.w0 = (tile - row * p.tiles_w) * p.TW;
-      t.b = fdiv(row, inv_th);
-      t.h0 = (row - t.b * p.tiles_h) * p.TH;
-    } else {
-      int run, th;
-      if (tile_order == 1) {
-        run = fdiv(tile, inv_th);
-        th = tile - run * p.tiles_h;
-      } else {
-        const int k = tile >> 3;
-        const int kr = fdiv(k, inv_th);
-        th = k - kr * p.tiles_h;
-        run = kr * 8 + (tile & 7);
-      }
-      t.b = fdiv(run, inv_tw);
-      t.w0 = (run - t.b * p.tiles_w) * p.TW;
-      t.h0 = th * p.TH;
-    }
+    // tile -> (image, tile row, tile column), row-major
+    const int row = fdiv(tile, inv_tw);
+    t.w0 = (tile - row * p.tiles_w) * p.TW;
+    t.b = fdiv(row, inv_th);
+    t.h0 = (row - t.b * p.tiles_h) * p.TH;
     return t;
   };
 
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   // laundered lane row, so that the compiler does not turn it back into a table) where the registers go to accumulators
   constexpr bool DMA_TABLE = MF <= 2;
   auto a_row = [&](int i, int lr, int& hh_out, int& ww_out, int& slot_out) {
-    const int r = (wave + NW * i) * RPW + lr;
+    const int r = (RES ? min((wave + NW * i) * RPW, RROWS - RPW) : (wave + NW * i) * RPW) + lr;
     const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
     hh_out = r < R ? hh - PAD : -(1 << 20);
     ww_out = r - hh * TWP - PAD;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   const bool cs_lds = CS_LDS && p.out_cs != nullptr;
   // LDS map of the WS variant: [A stage 0 | A stage 1 | nk weight stages | epilogue patches | channel scales]
   const int ws_boff = 2 * GEO::A_BYTES, ws_eoff = ws_boff + (p.Cg / SK) * GEO::B_BYTES;
-  const int cs_base = WS ? ws_eoff + NW * GEO::EPI_WAVE : (DEEP ? 3 * GEO::A_BYTES + 2 * GEO::B_BYTES + (NW * GEO::EPI_WAVE <= GEO::B_BYTES ? 0 : NW * GEO::EPI_WAVE) : GEO::CS_OFF);
+  const int cs_base = RES ? R_CSOFF : (WS ? ws_eoff + NW * GEO::EPI_WAVE : GEO::CS_OFF);
 
   // issue cursor: (unit, stage) of the next DMA batch.  Per lane only byte offsets inside the tensors are kept; the
   // stage (input-channel) advance is a scalar offset, so one batch costs one m0 write + one buffer_load per piece.
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   };
   auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
     if (!live(iu)) return;
-    char* sbase = smem + (int)stage * (WS ? GEO::A_BYTES : GEO::STAGE);
+    char* sbase = RES ? smem + ((int)stage * NK + iq) * RA : smem + (int)stage * (WS ? GEO::A_BYTES : GEO::STAGE);   // (resident: stage = tile buffer, iq = plane)
     int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
     const int half = p.C0 + p.C1;
     const int swapped = (p.paired && cabs >= half) ? 1 : 0;   // [src0 | src1 | src0' | src1']: second half from image b ^ 1
@@ -290,11 +294,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int piece = wave + NW * i;
-      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
+      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + (RES ? min(piece * RPW, RROWS - RPW) * RB : piece * 1024));
     }
-    if (cs_lds && iq == 0 && wave == 0)   // (rides with the unit's first stage: landed at that stage's barrier)
+    if (!RES && cs_lds && iq == 0 && wave == 0)   // (rides with the unit's first stage: landed at that stage's barrier)
       dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((it.b * p.Cout + it.g * p.Ng + it.n0) * 4), smem + cs_base + (iunit & 1) * 1024);
-    if constexpr (!WS) {
+    if constexpr (!WSMAP) {
       const int k0 = iq * SK;
       const int soff_b = ((((it.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
 #pragma unroll
@@ -309,86 +313,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
       iu += gridDim.x;
       if (live(iu)) issue_setup(iu);
     }
-  };
-
-  // ---- DEEP pipeline: the activation stages (HBM latency) run TWO ahead in a ring of three slots, the weight stages (L2) one
-  // ahead in a ring of two.  Timing ablations (tools/dma_ablate.sh) show why: with one stage in flight per workgroup the DMA
-  // side alone takes stages x latency (44 us for 64->64 x8) -- as long as the matrix side alone (50 us) -- and the two overlap
-  // only to 72 us.  LDS: 3 x A + 2 x B (+ separate epilogue patches for 32-channel tiles; 64-channel tiles overlay the idle
-  // weight slot) + channel scales = 71 KB, still two workgroups per CU.  The A cursor is (iu, iq, it, ...) above; the weights
-  // have their own cursor.  One barrier per stage as before; the wait leaves exactly the younger activation batch in flight.
-  constexpr int D_BOFF = 3 * GEO::A_BYTES;                                             // weight slots
-  constexpr int D_EOFF = D_BOFF + 2 * GEO::B_BYTES;                                    // epilogue patches (32-channel tiles)
-  constexpr bool D_OVERLAY = NW * GEO::EPI_WAVE <= GEO::B_BYTES;                       // patches fit a weight slot
-  constexpr int D_CSOFF = D_EOFF + (D_OVERLAY ? 0 : NW * GEO::EPI_WAVE);
-  int iuB = blockIdx.x, iqB = 0, iunitB = 0;
-  Unit itB{};
-  [[maybe_unused]] int bvoffB[BI];
-  auto setup_B = [&](int u) {
-    itB = decode(u);
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int tp, nn, sl;
-      if constexpr (DMA_TABLE) { tp = btap[i]; nn = bn[i]; sl = bslot[i]; }
-      else b_row(i, lrow, tp, nn, sl);
-      const int n = min(itB.n0 + nn, p.NgP - 1);
-      bvoffB[i] = (((tp * p.NgP + n) << ck_shift) + sl) * 2;
-    }
-  };
-  auto issue_B = [&](int slot) {
-    if (!live(iuB)) return;
-    char* sb = smem + D_BOFF + slot * GEO::B_BYTES;
-    if (cs_lds && iqB == 0 && wave == 0)
-      dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((itB.b * p.Cout + itB.g * p.Ng + itB.n0) * 4), smem + cs_base + (iunitB & 1) * 1024);
-    const int k0 = iqB * SK;
-    const int soff_b = ((((itB.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int piece = wave + NW * i;
-      if (piece < GEO::BPIECES) dma16(rsw, bvoffB[i], soff_b, sb + piece * 1024);
-    }
-    if (++iqB == nk) {
-      iqB = 0;
-      ++iunitB;
-      iuB += gridDim.x;
-      if (live(iuB)) setup_B(iuB);
-    }
-  };
-  auto issue_A = [&](int slot) -> bool {
-    if (!live(iu)) return false;
-    char* sbase = smem + slot * GEO::A_BYTES;
-    int cabs = it.g * p.Cg + iq * SK;
-    const int half = p.C0 + p.C1;
-    const int swapped = (p.paired && cabs >= half) ? 1 : 0;
-    if (swapped) cabs -= half;
-    const int src_id = cabs >= p.C0 ? 1 : 0;
-    if (src_id + 2 * swapped != isrc) {
-      isrc = src_id + 2 * swapped;
-      const int cs2 = (src_id ? p.C1 : p.C0) * 2;
-      const int dpix = (swapped || (src_id && p.swap1)) ? ((it.b ^ 1) - it.b) * p.sH * p.sW : 0;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
-    }
-    const int soff_a = (src_id ? cabs - p.C0 : cabs) * 2;
-    const rsrc_t rsa = src_id ? rs1 : rs0;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int piece = wave + NW * i;
-      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
-    }
-    if (++iq == nk) {
-      iq = 0;
-      iu += gridDim.x;
-      if (live(iu)) issue_setup(iu);
-    }
-    return true;
-  };
-  // (waves 0 .. APIECES % NW - 1 move one activation piece more than the others: the younger batch this wave may leave in flight)
-  auto wait_stage = [&](bool younger_a) {
-    if (!younger_a) { wait_vmcnt<0>(); return; }
-    constexpr int REM = GEO::APIECES % NW;
-    if (REM == 0 || wave < REM) wait_vmcnt<AI>();
-    else wait_vmcnt<(AI > 1 ? AI - 1 : 0)>();
   };
 
   // ---- fragment read addresses (bytes inside a stage); the tile geometry is the same for every unit
@@ -465,25 +389,26 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
   };
 
   static_assert(!GEO::EPI_OVERLAY || NW * GEO::EPI_WAVE <= GEO::STAGE, "epilogue patches overlay stage 1");
-  float* sE = reinterpret_cast<float*>(smem + (WS ? ws_eoff : (DEEP ? D_EOFF : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE))) + wave * GEO::EPI_WAVE);
+  float* sE = reinterpret_cast<float*>(smem + (RES ? R_EOFF : (WS ? ws_eoff : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE))) + wave * GEO::EPI_WAVE);
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   DDX_TR_INIT;
-  if (live(iu)) issue_setup(iu);
-  [[maybe_unused]] bool a_ahead = false;   // DEEP: the activation batch after the next one is in flight
-  [[maybe_unused]] int gs = 0, sa = 0;     // DEEP: global stage counter of the compute side (weight slot gs & 1), gs % 3
-  if constexpr (DEEP) {
-    static_assert(!EB && NF * MF <= 4 && WN == 1, "deep ring: forward epilogues of the 4-fragment variants");
-    if (live(iuB)) setup_B(iuB);
-    issue_A(0);
-    issue_B(0);
-    a_ahead = issue_A(1);
-  } else {
-    if constexpr (WS) {
-      static_assert(!EB && !DEEP && NF * MF <= 4 && WN == 1, "stationary weights: forward epilogues of the 4-fragment variants");
+  // (LDS address space on the pointer: a generic volatile access would be a flat load, which also waits for this wave's vmcnt)
+  typedef __attribute__((address_space(3))) volatile unsigned lds_vu32_t;
+  typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+  [[maybe_unused]] lds_vu32_t* flags = (lds_vu32_t*)(smem + R_FLOFF);
+  if constexpr (PC) {
+    if (wave == 0 && lane < 16) flags[lane] = 0u;
+  }
+  if (!PC || wave < NW) {
+    if (live(iu)) issue_setup(iu);
+  }
+  if (!PC || wave < NW) {
+    if constexpr (WSMAP) {
+      static_assert(!EB && NF * MF <= 4 && WN == 1, "stationary weights: forward epilogues of the 4-fragment variants");
       if (live(iu)) {   // all nk weight stages of this workgroup's (group, channel tile), once
         for (int q = 0; q < nk; ++q) {
           const int k0 = q * SK;
@@ -491,19 +416,95 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 #pragma unroll
           for (int i = 0; i < BI; ++i) {
             const int piece = wave + NW * i;
-            if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, smem + ws_boff + q * GEO::B_BYTES + piece * 1024);
+            if (piece < GEO::BPIECES) dma16(rsw, bvoff[i], soff_b, smem + (RES ? R_WOFF : ws_boff) + q * GEO::B_BYTES + piece * 1024);
+          }
+        }
+        if constexpr (RES) {
+          // output channel scales of this channel tile for every image [B][BN] (fp32), once: piece c holds entries 64 c .. 64 c + 63,
+          // entry e = (image e / (BN / 4), 4-float run e % (BN / 4))
+          if (p.out_cs) {
+            const int npc = (p.B * (BN / 4) + 63) >> 6;
+            for (int c = wave; c < npc; c += NW) {
+              const int e = c * 64 + lane, bi = e / (BN / 4), k4 = e % (BN / 4);
+              dma16(rscs, bi < p.B ? (bi * p.Cout + k4 * 4) * 4 : kOobOffset, (it.g * p.Ng + it.n0) * 4, smem + R_CSOFF + c * 1024);
+            }
           }
         }
       }
     }
-    issue_next(S0{});
+    if constexpr (RES) {
+      if constexpr (!PC) {
+        for (int q = 0; q < NK; ++q) issue_next(0);
+      }
+    } else {
+      issue_next(S0{});
+    }
+  }
+  if constexpr (PC) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // weights, scales and the zeroed counters are in LDS for every wave; no barrier from here on
+    if (wave == NW) {
+      // ---- producer: for every unit of this workgroup, the whole halo tile (NK planes x 11 pieces) into buffer n & 1
+      constexpr int NP = (RROWS + RPW - 1) / RPW;   // 11 pieces per plane
+      const int half = p.C0 + p.C1;
+      int n = 0;
+      for (int u = blockIdx.x; live(u); u += gridDim.x, ++n) {
+        const Unit pt = decode(u);
+        int ppix[NP], pslot[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int r = min(i * RPW, RROWS - RPW) + lrow;
+          const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
+          const int ww = r - hh * TWP - PAD;
+          const int ih = pt.h0 + hh - PAD;
+          int iw = pt.w0 + ww;
+          if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W && iw < p.W + PAD ? 2 * (p.W - 1) - iw : iw);
+          const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+          const int pix = p.resample == DDX_RESAMPLE_UP ? (pt.b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (pt.b * p.sH + ih) * p.sW + iw;
+          ppix[i] = ok ? pix : -1;
+          pslot[i] = (lslot ^ GEO::swz(r)) * 8;
+        }
+        if (n >= 2) {   // every consumer wave is done with the tile that lived in this buffer
+          const unsigned need = (unsigned)(NW * (n >> 1));
+          while (flags[2 + (n & 1)] < need) __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        for (int q = 0; q < NK; ++q) {
+          int cabs = pt.g * p.Cg + q * SK;
+          const int swapped = (p.paired && cabs >= half) ? 1 : 0;
+          if (swapped) cabs -= half;
+          const int src_id = cabs >= p.C0 ? 1 : 0;
+          const bool c16 = (p.layout >> src_id) & 1;
+          const int cs2 = (src_id ? p.C1 : p.C0) * 2;
+          const int dpix = (swapped || (src_id && p.swap1)) ? ((pt.b ^ 1) - pt.b) * p.sH * p.sW : 0;
+          const int hw = p.sH * p.sW;
+          const int ibase = (pt.b * hw + dpix) * cs2 - pt.b * hw * 32;
+          const int cin_src = src_id ? cabs - p.C0 : cabs;
+          // (wave-uniform by construction; readfirstlane makes it provable, else every DMA sits in a waterfall loop)
+          const int soff_a = __builtin_amdgcn_readfirstlane(c16 ? (cin_src >> 4) * hw * 32 : cin_src * 2);
+          const int pmul = __builtin_amdgcn_readfirstlane(c16 ? 32 : cs2);          // bytes per pixel step of this source
+          const int padd = __builtin_amdgcn_readfirstlane(c16 ? ibase : dpix * cs2);
+          const rsrc_t rsa = src_id ? rs1 : rs0;
+          char* sbase = smem + ((n & 1) * NK + q) * RA;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) {
+            const int voff = ppix[i] < 0 ? kOobOffset : ppix[i] * pmul + padd + pslot[i] * 2;
+            dma16(rsa, voff, soff_a, sbase + min(i * RPW, RROWS - RPW) * RB);
+          }
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flags + (n & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
+    }
   }
   DDX_TR(2);
   int cunit = -1;
   for (int u = blockIdx.x; live(u); u += gridDim.x) {
     ++cunit;
-    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + cs_base + (cunit & 1) * 1024);
-    const Unit t = DEEP ? decode(u) : it;  // (two-stage pipeline: the issue cursor is still on this unit, it moves on during the last stage)
+    const Unit t = RES ? decode(u) : it;   // (resident mode: the issue cursor is already one unit ahead)
+    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + cs_base + (RES ? t.b * (BN * 4) : (cunit & 1) * 1024));  // (the issue cursor is still on this unit, it moves on during the last stage)
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -569,17 +570,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     u32x4 rres[LATE_RES ? (NF > 2 ? 2 : 1) : NF][MF][2];
     auto rslot = [](int i) { return LATE_RES ? (NF > 2 ? (i & 1) : 0) : i; };
 
-    if constexpr (DEEP) {
-      for (int q = 0; q < nk; ++q) {
-        DDX_TR(5);
-        wait_stage(a_ahead);             // stage gs landed (its weights were issued before the younger activation batch)
+    if constexpr (RES) {
+      DDX_TR(5);
+      if constexpr (PC) {
+        const unsigned need = (unsigned)((cunit >> 1) + 1);   // tiles landed in this buffer so far, this unit's included
+        while (flags[cunit & 1] < need) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         DDX_TR(0);
-        __builtin_amdgcn_s_barrier();    // ... for every wave, and everyone is done reading the slots of stage gs - 1
+      } else {
+        wait_vmcnt<0>();
+        DDX_TR(0);
+        __builtin_amdgcn_s_barrier();  // this unit's tile (the first time: weights, scales) landed for every wave; everyone is done reading the other tile buffer
         DDX_TR(1);
-        issue_B((gs + 1) & 1);                                   // weights one stage ahead (slot of stage gs - 1)
-        a_ahead = issue_A(sa == 0 ? 2 : sa - 1);                 // activations two ahead: slot (gs + 2) % 3 = (gs - 1) % 3
-        DDX_TR(2);
-        if (q + 1 == nk && p.epilogue == DDX_EPI_MPSUM) {        // residual rows ride along with the last matrix phase
+      }
+      const int bufoff = (cunit & 1) * (NK * RA);
+      if constexpr (!PC) {
+        for (int q = 0; q < NK; ++q) issue_next((cunit + 1) & 1);   // the next unit's whole tile
+      }
+      DDX_TR(2);
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        if (!REG && q + 1 == NK && p.epilogue == DDX_EPI_MPSUM) {  // residual rows ride along with the last plane
 #pragma unroll
           for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -590,11 +601,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
                 rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
               }
         }
-        compute_at(smem + sa * GEO::A_BYTES, smem + D_BOFF + (gs & 1) * GEO::B_BYTES);
-        DDX_TR(3);
-        ++gs;
-        sa = sa == 2 ? 0 : sa + 1;
+        compute_at(smem + bufoff + q * RA, smem + R_WOFF + q * GEO::B_BYTES);
       }
+      if constexpr (PC) {   // this wave is done reading the tile buffer (its fragment reads were consumed by the MFMAs above)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flags + 2 + (cunit & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      DDX_TR(3);
     } else {
       // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
       for (int q = 0; q < nk; q += 2) {
@@ -634,13 +647,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
     if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
     if constexpr (GEO::EPI_OVERLAY) __builtin_amdgcn_s_barrier();  // every wave is done reading stage 1: the patches live there
-    if constexpr (DEEP) {
-      // 64-channel tiles: the patches overlay the weight slot of the stage just multiplied (idle until the next stage's barrier)
-      if constexpr (D_OVERLAY) {
-        __builtin_amdgcn_s_barrier();
-        sE = reinterpret_cast<float*>(smem + D_BOFF + ((gs - 1) & 1) * GEO::B_BYTES + wave * GEO::EPI_WAVE);
-      }
-    }
     if constexpr (!EB && WN == 1 && NF <= 2 && MF <= 2) {
       if (p.epilogue == DDX_EPI_PIXELNORM) {
         // normalize(y, dim = channels) on the accumulators: a lane holds 16 of the 32 channels of pixel (lane & 31) per fragment,
@@ -662,6 +668,62 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         }
       }
     }
+    if constexpr (REG) {
+      // Register epilogue (resident mode, MF = 1, channel-blocked main output, no residual / twin): lane (khalf, l31) holds
+      // channels 8 jj + 4 khalf + e (jj, e < 4) of pixel (tile row `wave`, column l31) per fragment.  After the bf16 packing, one
+      // v_permlane32_swap per dword gives the lower half-wave channels 16 pp .. 16 pp + 7 and the upper half-wave 16 pp + 8 .. + 15
+      // of its pixel: one 16-byte store per lane and plane, 32 consecutive pixels x 32 bytes = 1 KiB contiguous per instruction.
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      const int eh = t.h0 + wm, ew = t.w0 + l31;
+      const bool pok = eh < p.H && ew < p.W;
+      const long plane = (long)p.H * p.W * 16;
+      const long pbase = ((long)(t.b * p.H + eh) * p.W + ew) * 16 + (long)t.b * (p.Cout / 16 - 1) * plane + khalf * 8;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][0][r];
+        if (p.clip > 0.f) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fminf(fmaxf(v[r], -p.clip), p.clip);
+        }
+        if (p.out_act) {
+          if (p.out_cs) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs_l + i * 32 + 8 * jj + 4 * khalf);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * jj + e] *= c4[e];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = mp_silu_f(v[r]);
+        }
+        DDX_TR(6);   // (register epilogue sub-phases: 6 = scale / clip / activation, 7 = pack + lane exchange, 8 = stores)
+        unsigned pk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const f32x2_t f2 = {v[2 * k], v[2 * k + 1]};
+          pk[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2, bf16x2_t));
+        }
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          // dwords 4 pp, 4 pp + 1: channels 16 pp + 4 khalf + 0..3; dwords 4 pp + 2, 4 pp + 3: channels 16 pp + 8 + 4 khalf + 0..3
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * pp], pk[4 * pp + 2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * pp + 1], pk[4 * pp + 3], false, false);
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          const int cpl = t.n0 + i * 32 + 16 * pp;  // first channel (inside the group) of this 16-channel plane
+          DDX_TR(7);
+#ifndef DDX_ABL_NOSTORE
+          if (pok && cpl < p.Ng) *reinterpret_cast<u32x4*>(out + pbase + (long)((t.g * p.Ng + cpl) >> 4) * plane) = o;
+#else
+          if (o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(out + pbase) = o;
+#endif
+          DDX_TR(8);
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       if (LATE_RES && p.epilogue == DDX_EPI_MPSUM) {  // wide tiles: no registers to prefetch all residual rows, load per column
@@ -789,6 +851,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // patch is rewritten by the next fragment
       }
     }
+    }
     DDX_TR(4);
     if constexpr (EB) {
       if (p.bwd_ws) {
@@ -831,6 +894,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_dma
 #endif
 }
 
+// DDX_DMA_TRACE builds: print (and reset) the per-wave phase cycles after a launch
+static void dma_trace_report(long total) {
+#ifdef DDX_DMA_TRACE
+  if (getenv("DDX_DMA_TRACE")) {
+    unsigned long long h[12] = {0}, z[12] = {0};
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) == hipSuccess && h[9]) {
+      const double w = (double)h[9];
+      fprintf(stderr, "[dma trace] %d units, cycles per wave: dma-wait %.0f barrier %.0f dma-issue %.0f matrix %.0f epilogue %.0f (patch write %.0f, "
+              "read + math %.0f, stores %.0f, rest %.0f) unit-setup %.0f\n",
+              (int)total, h[0] / w, h[1] / w, h[2] / w, h[3] / w, (h[4] + h[6] + h[7] + h[8]) / w, h[6] / w, h[7] / w, h[8] / w, h[4] / w, h[5] / w);
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z));
+  }
+#else
+  (void)total;
+#endif
+}
+
 // dc[b][c] += scale * sum over the (pixel tile, wave) partial rows of image b written by the EB epilogue.
 // Row index = unit * NW + wave with unit = (g * ntile_n + nt) * ntile_px + b * tiles_per_image + tile.
 __global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dc, int rows_per_image, int rows_per_gn,
@@ -851,16 +932,15 @@ __global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __rest
   }
 }
 
-template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int DEEP = 0, int WS = 0>
+template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int WS = 0>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
-  constexpr int DEEP_SMEM = 3 * GEO::A_BYTES + 2 * GEO::B_BYTES + (GEO::NW * GEO::EPI_WAVE <= GEO::B_BYTES ? 0 : GEO::NW * GEO::EPI_WAVE) + 2048;
   constexpr int WS_NK_MAX = (80 * 1024 - 2 * GEO::A_BYTES - GEO::NW * GEO::EPI_WAVE - 2048) / GEO::B_BYTES;   // weight stages that fit
-  const int SMEM_BYTES = WS ? 2 * GEO::A_BYTES + (p.Cg / SK) * GEO::B_BYTES + GEO::NW * GEO::EPI_WAVE + 2048 : (DEEP ? DEEP_SMEM : GEO::SMEM);
-  static_assert((DEEP ? DEEP_SMEM : GEO::SMEM) <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
+  const int SMEM_BYTES = WS ? 2 * GEO::A_BYTES + (p.Cg / SK) * GEO::B_BYTES + GEO::NW * GEO::EPI_WAVE + 2048 : GEO::SMEM;
+  static_assert(GEO::SMEM <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
   if (WS && (p.Cg / SK > WS_NK_MAX)) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma: weights do not fit LDS");
   static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF, DEEP, WS>;  // (no fragment prefetch only where 128 accumulators leave no registers)
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF, WS>;  // (no fragment prefetch only where 128 accumulators leave no registers)
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WS ? 80 * 1024 : SMEM_BYTES) != hipSuccess)
@@ -882,34 +962,61 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
     grid &= ~7;
     per_xcd = (int)((total + 7) / 8);
   }
-  // vertical halo sharing (see `decode`): column-major tiles for the XCD-contiguous order; run-dealt columns for the plain
-  // order when tiles and columns split evenly over the 8 XCDs
-  static const int col_knob = getenv("DDX_DMA_COL") ? atoi(getenv("DDX_DMA_COL")) : 0;  // measured neutral: off
-  int tile_order = 0;
-  if (!EB && KS == 3 && col_knob && p.tiles_h > 1) {  // (EB: the dc reduction relies on image-major unit rows)
-    const int ntile_px = p.B * p.tiles_h * p.tiles_w;
-    if (per_xcd) tile_order = 1;
-    else if (ntile_px % 8 == 0 && (p.B * p.tiles_w) % 8 == 0 && grid % 8 == 0) tile_order = 2;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), SMEM_BYTES, s, p, (int)total, ntile_n, per_xcd, tile_order);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), SMEM_BYTES, s, p, (int)total, ntile_n, per_xcd);
   if (EB && p.bwd_ws && p.bwd_dc) {
     const int tpi = p.tiles_h * p.tiles_w;
     hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
                        p.B * tpi * GEO::NW, GEO::BN, ntile_n, p.Ng, p.Cout, p.bwd_s0);
   }
-#ifdef DDX_DMA_TRACE
-  if (getenv("DDX_DMA_TRACE")) {
-    unsigned long long h[12] = {0}, z[12] = {0};
-    if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) == hipSuccess && h[9]) {
-      const double w = (double)h[9];
-      fprintf(stderr, "[dma trace] %d units, cycles per wave: dma-wait %.0f barrier %.0f dma-issue %.0f matrix %.0f epilogue %.0f (patch write %.0f, "
-              "read + math %.0f, stores %.0f, rest %.0f) unit-setup %.0f\n",
-              (int)total, h[0] / w, h[1] / w, h[2] / w, h[3] / w, (h[4] + h[6] + h[7] + h[8]) / w, h[6] / w, h[7] / w, h[8] / w, h[4] / w, h[5] / w);
-    }
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof(z));
-  }
-#endif
+  dma_trace_report(total);
   return check_launch("conv_dma");
+}
+
+// Resident mode (NK > 0 in conv_dma_kernel): one workgroup of eight waves per CU, grid 256.
+template <int NF, int NK, int REG, int PC>
+int launch_dma_res_t(const ConvParams& p, hipStream_t s) {
+  using GEO = DmaGeom<3, 16, NF, 1, 8, 1>;
+  constexpr int RA = 340 * GEO::RB;
+  const int cs_pieces = p.out_cs ? (p.B * (GEO::BN / 4) + 63) / 64 : 0;
+  const int SMEM_BYTES = 2 * NK * RA + NK * GEO::B_BYTES + (REG ? 0 : GEO::NW * GEO::EPI_WAVE) + 64 + cs_pieces * 1024;
+  if (SMEM_BYTES > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma (resident): LDS budget");
+  auto kern = conv_dma_kernel<3, 16, NF, 1, 1, 0, 8, 1, 0, NK, REG, PC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_dma resident)");
+    attr_done = true;
+  }
+  const int ntile_n = ceil_div(p.Ng, GEO::BN);
+  const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(64 * (GEO::NW + PC)), SMEM_BYTES, s, p, (int)total, ntile_n, 0);
+  dma_trace_report(total);
+  return check_launch("conv_dma_res");
+}
+template <int NF, int NK, int REG>
+int launch_dma_res(const ConvParams& p, hipStream_t s) {
+  static const int pc_knob = std::getenv("DDX_DMA_PC") ? atoi(std::getenv("DDX_DMA_PC")) : 1;   // 0: all eight waves issue the tile DMA, one barrier per unit
+  return pc_knob ? launch_dma_res_t<NF, NK, REG, 1>(p, s) : launch_dma_res_t<NF, NK, REG, 0>(p, s);
+}
+
+// which resident variant serves the layer: 0 none, else 1 + (NF - 1) + 2 * (NK == 4) + 4 * REG
+int dma_res_variant(const ConvParams& p, int TH, int TW) {
+  static const int knob = std::getenv("DDX_DMA_RES") ? atoi(std::getenv("DDX_DMA_RES")) : 1;   // 0: off; 2: patch epilogue wherever it fits (A/B of the register epilogue)
+  if (!knob || p.epilogue == DDX_EPI_SILU_BWD || TH != 8 || TW != 32) return 0;
+  const int nk = p.Cg / 16;
+  if (p.Cg % 16 || (nk != 2 && nk != 4)) return 0;
+  const int bn = p.Ng <= 32 ? 32 : 64, nf = bn / 32;
+  const int gn = p.G * ceil_div(p.Ng, bn);
+  const long tiles = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW);
+  if (256 % (8 * gn) != 0 || tiles * gn < 512) return 0;
+  const bool reg_ok = p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 16 == 0 && p.Cout % 16 == 0;
+  const int cs_bytes = p.out_cs ? ((p.B * (bn / 4) + 63) / 64) * 1024 : 0;
+  const int base = 2 * nk * 340 * 32 + nk * 9 * bn * 32 + 64 + cs_bytes;
+  const bool patch_fits = base + 8 * DmaGeom<3, 16, 1, 1, 8, 1>::EPI_WAVE <= 160 * 1024;
+  const bool reg = reg_ok && (knob != 2 || !patch_fits);
+  if (!reg && !patch_fits) return 0;
+  if (reg && base > 160 * 1024) return 0;
+  return 1 + (nf - 1) + 2 * (nk == 4 ? 1 : 0) + 4 * (reg ? 1 : 0);
 }
 
 // 1x1 layers with >= 192 output channels per group run as 256 x 256 GEMM tiles (8 waves) when that still leaves
@@ -1016,6 +1123,18 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
       }
     }
   }
+  if (ksize == 3) {
+    switch (dma_res_variant(p, TH, TW)) {
+      case 1: return launch_dma_res<1, 2, 0>(p, s);
+      case 2: return launch_dma_res<2, 2, 0>(p, s);
+      case 3: return launch_dma_res<1, 4, 0>(p, s);
+      case 5: return launch_dma_res<1, 2, 1>(p, s);
+      case 6: return launch_dma_res<2, 2, 1>(p, s);
+      case 7: return launch_dma_res<1, 4, 1>(p, s);
+      case 8: return launch_dma_res<2, 4, 1>(p, s);
+      default: break;
+    }
+  }
   // stationary weights where all K-stages of a channel tile fit beside two activation stages (Cg <= 32 with 64-channel tiles,
   // Cg <= 64 with 32-channel tiles): -7 ... -15 % on those layers.  DDX_DMA_WS=0 off, 2 = also 32-channel tiles for
   // Ng = 64 layers with Cg = 64 (experiment)
@@ -1025,10 +1144,8 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     const int bn = (p.Ng <= 32 || (ws_knob == 2 && p.Ng == 64 && nk == 4)) ? 32 : 64, combos = p.G * ceil_div(p.Ng, bn);
     const long tiles = (long)p.B * p.tiles_h * p.tiles_w;
     if (combos <= 64 && 512 % (8 * combos) == 0 && tiles * combos >= 1024 && nk <= (bn == 32 ? 4 : 2))
-      return bn == 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 0, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 0, 1>(p, s);
+      return bn == 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
   }
-  static const int deep_knob = std::getenv("DDX_DMA_DEEP") ? atoi(std::getenv("DDX_DMA_DEEP")) : 0;
-  if (ksize == 3 && deep_knob && !p.layout) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
   const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);

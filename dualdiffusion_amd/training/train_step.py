@@ -292,5 +292,6 @@ class UNetTrainStep:
             if not last:                      # no_sync micro-step: gradients stay local
                 self._accum.add_(self.trainer.grad_flat)
             self.last_gathered.append(D.gather_scalars([loss, sig]))       # one small collective per micro-step
-            losses.append(loss)
+            # (graph mode returns the captured static loss buffer, which the next replay overwrites: keep a copy per micro-step)
+            losses.append(loss.clone() if (self.use_graph and A > 1) else loss)
         return self._finish(torch.cat(losses) if A > 1 else losses[0], grads, world, A, ex, Bd)

@@ -753,10 +753,11 @@ print("WORST", worst)
 """
 
 
-@pytest.mark.parametrize("knob", ["DDX_DMA_DEEP=1", "DDX_DMA_BIG=2", "DDX_DMA_COL=1", "DDX_DMA_XCD=2"])
+@pytest.mark.parametrize("knob", ["DDX_DMA_BIG=2", "DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_RES=2"])
 def test_conv_dma_experiment_knobs_stay_correct(knob):
-    """The experimental LDS-DMA variants kept behind environment knobs (deep DMA ring, 512-pixel units, tile orders; read once per
-    process, so each runs in its own interpreter) against the register-staged kernel on grouped / two-source / residual layers."""
+    """The LDS-DMA variants behind environment knobs (512-pixel units, XCD unit order, resident mode off / with the patch epilogue;
+    read once per process, so each runs in its own interpreter) against the register-staged kernel on grouped / two-source /
+    residual layers."""
     import os
     import subprocess
     import sys
@@ -813,6 +814,12 @@ C16_CASES = {
     "grouped_ws": (4, 32, 688, 256, 0, 512, 8, False, False, True, False, (1, 0, 1, 0)),       # stationary-weights variant (Cg = 32), XCD unit order
     "grouped_ws_res": (4, 32, 700, 512, 0, 256, 8, False, True, False, True, (1, 0, 0, 1)),    # 32-channel tiles (NF = 1)
     "l1_like": (4, 16, 344, 512, 0, 1024, 8, False, False, True, False, (1, 0, 1, 0)),
+    # resident mode (whole-K tiles, stationary weights, eight waves): register epilogue on blocked outputs vs the NHWC launch
+    "res_64_64_cat": (4, 32, 688, 256, 256, 512, 8, False, False, True, False, (1, 1, 1, 0)),  # Cg = 64, 64-channel tiles: all 160 KiB
+    "res_64_128_up": (4, 32, 700, 512, 0, 1024, 8, True, False, True, False, (1, 0, 1, 0)),    # nearest-up source, two channel tiles, ragged W
+    "res_32_64_b5": (5, 37, 650, 64, 0, 128, 2, False, False, True, False, (1, 0, 1, 0)),      # five images of channel scales, ragged H and W
+    "res_64_32_b5": (5, 37, 650, 128, 0, 64, 2, False, True, False, True, (1, 0, 0, 1)),       # residual + blocked twin on the patch epilogue
+    "res_plain_clip": (4, 32, 688, 512, 0, 512, 8, False, False, False, False, (0, 0, 1, 0)),  # NHWC source, plain blocked output
 }
 
 
@@ -832,7 +839,7 @@ def test_conv_dma_channel_blocked(name):
     r = torch.randn(B, H, W, Cout, device="cuda", generator=g).to(dt) if has_res else None
     cs = torch.rand(B, Cout, device="cuda", generator=g) + 0.5
     pw = ops.wprep(w, G, dt, npix=B * H * W)
-    kw = dict(out_hw=(H, W), resample=L.RESAMPLE_UP if up else L.RESAMPLE_KEEP, residual=r, res_t=0.3, clip=256.0 if has_res else 0.0,
+    kw = dict(out_hw=(H, W), resample=L.RESAMPLE_UP if up else L.RESAMPLE_KEEP, residual=r, res_t=0.3, clip=256.0 if has_res else (1.5 if name == "res_plain_clip" else 0.0),
               out_act=out_act, out_scale=cs if out_act else None, out2_scale=0.8, path="dma")
     tw_ref = torch.zeros(B, H, W, Cout, device="cuda", dtype=dt) if twin else None
     y_ref = ops.conv2d(a0, pw, src1=a1, out2=tw_ref, **kw)

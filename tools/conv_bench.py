@@ -69,7 +69,43 @@ CASES = {
     "L3_dec_res1_raw": (4, 4, 86, 2048, 0, 1024, 8, 3, 0, L.PRO_NONE, True),
     "L4_down_res0_raw": (4, 2, 43, 1024, 0, 2048, 8, 3, 0, L.PRO_NONE, False),
     "L4_down_skip_raw": (4, 2, 43, 1024, 0, 1024, 1, 1, 0, L.PRO_NONE, False),
+    # remaining 3x3 / 1x1 shapes of the default UNet at B=4 (round 3: per-layer table of the whole LDS-DMA family)
+    "L0_dec1_res0_raw": (4, 32, 688, 256, 256, 512, 8, 3, 0, L.PRO_NONE, False),
+    "L1_down_res0_raw": (4, 16, 344, 256, 0, 512, 8, 3, 0, L.PRO_NONE, False),
+    "L1_down_res1_raw": (4, 16, 344, 512, 0, 256, 8, 3, 0, L.PRO_NONE, True),
+    "L1_enc_res0_raw": (4, 16, 344, 512, 0, 1024, 8, 3, 0, L.PRO_NONE, False),
+    "L1_up_res0_raw": (4, 16, 344, 768, 0, 1536, 8, 3, 1, L.PRO_NONE, False),
+    "L1_up_res1_raw": (4, 16, 344, 1536, 0, 768, 8, 3, 0, L.PRO_NONE, True),
+    "L1_dec1_res0_raw": (4, 16, 344, 512, 512, 1024, 8, 3, 0, L.PRO_NONE, False),
+    "L1_dec2_res0_raw": (4, 16, 344, 512, 256, 1024, 8, 3, 0, L.PRO_NONE, False),
+    "L2_down_res0_raw": (4, 8, 172, 512, 0, 1024, 8, 3, 0, L.PRO_NONE, False),
+    "L2_down_res1_raw": (4, 8, 172, 1024, 0, 512, 8, 3, 0, L.PRO_NONE, True),
+    "L2_up_res0_raw": (4, 8, 172, 1024, 0, 2048, 8, 3, 1, L.PRO_NONE, False),
+    "L2_up_res1_raw": (4, 8, 172, 2048, 0, 1024, 8, 3, 0, L.PRO_NONE, True),
+    "L2_dec_res0_raw": (4, 8, 172, 1024, 768, 1536, 8, 3, 0, L.PRO_NONE, False),
+    "L2_dec1_res0_raw": (4, 8, 172, 768, 768, 1536, 8, 3, 0, L.PRO_NONE, False),
+    "L2_dec2_res0_raw": (4, 8, 172, 768, 512, 1536, 8, 3, 0, L.PRO_NONE, False),
+    "L0_skip_cat2_raw": (4, 32, 688, 256, 256, 256, 1, 1, 0, L.PRO_NONE, False),
+    "L0_up_skip_raw": (4, 32, 688, 512, 0, 512, 1, 1, 1, L.PRO_NONE, False),
+    "L1_skip_256_raw": (4, 16, 344, 256, 0, 512, 1, 1, 0, L.PRO_NONE, False),
+    "L1_skip_512_raw": (4, 16, 344, 512, 0, 512, 1, 1, 0, L.PRO_NONE, False),
+    "L1_up_skip_raw": (4, 16, 344, 768, 0, 768, 1, 1, 1, L.PRO_NONE, False),
+    "L1_skip_cat1_raw": (4, 16, 344, 512, 512, 512, 1, 1, 0, L.PRO_NONE, False),
+    "L1_skip_cat2_raw": (4, 16, 344, 512, 256, 512, 1, 1, 0, L.PRO_NONE, False),
+    "L2_skip_512_raw": (4, 8, 172, 512, 0, 768, 1, 1, 0, L.PRO_NONE, False),
+    "L2_skip_768_raw": (4, 8, 172, 768, 0, 768, 1, 1, 0, L.PRO_NONE, False),
+    "L2_up_skip_raw": (4, 8, 172, 1024, 0, 1024, 1, 1, 1, L.PRO_NONE, False),
+    "L2_skip_cat1_raw": (4, 8, 172, 768, 768, 768, 1, 1, 0, L.PRO_NONE, False),
+    "L2_skip_cat2_raw": (4, 8, 172, 768, 512, 768, 1, 1, 0, L.PRO_NONE, False),
 }
+# the 3x3 layers of the default UNet that run on the LDS-DMA kernel (levels 0-2) and its 1x1 layers of levels 0-2, in network order
+DMA3 = ["L0_res0_enc_raw", "L0_res1_enc_raw", "L1_down_res0_raw", "L1_down_res1_raw", "L1_enc_res0_raw", "L1_res1_raw", "L2_down_res0_raw",
+        "L2_down_res1_raw", "L2_res0_raw", "L2_res1_raw", "L2_up_res0_raw", "L2_up_res1_raw", "L2_dec_res0_raw", "L2_dec1_res0_raw",
+        "L2_dec2_res0_raw", "L1_up_res0_raw", "L1_up_res1_raw", "L1_dec_res0_raw", "L1_dec1_res0_raw", "L1_dec2_res0_raw", "L0_up_res0_raw",
+        "L0_up_res1_raw", "L0_dec_res0_raw", "L0_dec1_res0_raw"]
+ONE = ["L0_skip_256_raw", "L0_up_skip_raw", "L0_skip_cat_raw", "L0_skip_cat2_raw", "L1_skip_256_raw", "L1_skip_512_raw", "L1_up_skip_raw",
+       "L1_skip_cat_raw", "L1_skip_cat1_raw", "L1_skip_cat2_raw", "L2_skip_512_raw", "L2_skip_768_raw", "L2_up_skip_raw", "L2_skip_cat_raw",
+       "L2_skip_cat1_raw", "L2_skip_cat2_raw", "L3_qkv_raw", "L3_v_raw", "L3_proj_raw", "L3_skip_cat_raw", "L3_up_skip_raw"]
 SMALL_M = ["L3_res0_raw", "L3_res1_raw", "L3_dec_res0_raw", "L3_up_res0_raw", "L3_up_res1_raw", "L3_v_raw", "L3_skip_cat_raw", "L3_proj_raw",
            "L3_qkv_raw", "L3_up_skip_raw", "L4_res0_raw", "L4_res1_raw", "L4_dec_res0_raw", "L4_down_res0_raw", "L4_qkv_raw", "L4_proj_raw",
            "L4_v_raw", "L4_dec_skip_raw", "L4_down_skip_raw"]
@@ -86,7 +122,7 @@ def main():
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
-    for name in (SMALL_M if a.cases == "small" else a.cases.split(",")):
+    for name in ({"small": SMALL_M, "dma3": DMA3, "one": ONE}.get(a.cases) or a.cases.split(",")):
         B, H, W, C0, C1, Cout, G, ks, rs, pro, has_res = CASES[name]
         sh, sw = (H // 2, W // 2) if rs == 1 else ((H * 2, W * 2) if rs == 2 else (H, W))
         a0 = torch.randn(B, sh, sw, C0, device=dev).to(dt)

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--check")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--cases", default="", help="comma-separated substrings; empty = all")
+    ap.add_argument("--c16", action="store_true", help="channel-blocked sources / conv_res0-style outputs / twins (as the inference plans mark them)")
     a = ap.parse_args()
     dt, dev = torch.bfloat16, "cuda"
     saved = torch.load(a.check) if a.check else {}
@@ -68,6 +69,13 @@ def main():
         out = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
         out2 = torch.empty_like(out) if twin else None
         pw = ops.wprep(w, G, dt, npix=B * H * W)
+        if a.c16:
+            a0 = ops.to_c16(a0)
+            a1 = ops.to_c16(a1) if a1 is not None else None
+            if not has_res:
+                ops.mark_c16(out)
+            if twin:
+                ops.mark_c16(out2)
         kw = dict(out_hw=(H, W), src1=a1, resample=rs, residual=res, res_t=0.3, clip=256.0, out=out, path="dma")
         if act:
             kw.update(out_act=True, out_scale=ocs)

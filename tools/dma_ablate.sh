@@ -10,6 +10,6 @@ cp $L variants/lib_keep.so
 for v in FULL NODMA NOMATRIX NOSTORE "NODMA -DDDX_ABL_NOSTORE" "NOMATRIX -DDDX_ABL_NOSTORE"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDDX_ABL_$v -c dualdiffusion_amd/csrc/conv_dma.hip -Idualdiffusion_amd/csrc -Iinclude -o build/abl/conv_dma.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L $(ls build/obj/*.o | grep -v conv_dma.o) build/abl/conv_dma.o
-  echo "== $v"; python tools/conv_big_ab.py --cases "$1" | cut -c1-52
+  echo "== $v"; python tools/conv_big_ab.py $2 --cases "$1" | cut -c1-52
 done
 cp variants/lib_keep.so $L
