@@ -112,9 +112,13 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
 // producer has landed, `empty`: consumer waves done reading).  A wave that sits at a vector-memory instruction while the CU's
 // memory pipe is saturated (a full-resolution layer moves ~75 KB per unit at ~10 B/clk/CU) then stalls only itself: the loads
 // stall the producer, an epilogue's stores stall one consumer while the other wave of its SIMD keeps the matrix pipe busy.
+// RING > 0 ("streaming producer / consumer" mode, any channel count): 512-pixel units (eight consumer waves of 64 pixels x BN
+// channels, WM = 8, MF = 2), a ring of RING stage slots (one 16-channel plane of the halo tile + its weight slice), PC = 2 producer
+// waves that fill alternate stages (while one waits for its stage to land the other issues the next), consumers that run free:
+// per stage one LDS counter poll and one LDS atomic instead of a workgroup barrier, no vector-memory instruction in the matrix loop.
 // WS = 1: weights stationary -- a workgroup keeps ONE (group, channel tile), its nk weight stages stay in LDS for the whole launch
 // and only activations stream (layers with few input channels per group, where the weight slices are most of the staged bytes)
-template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int WS = 0, int NK = 0, int REG = 0, int PC = 0>
+template <int KS, int SK, int NF, int WN, int PD, int EB = 0, int WM = 4, int MF = 2, int WS = 0, int NK = 0, int REG = 0, int PC = 0, int RING = 0>
 __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void conv_dma_kernel(const ConvParams p, const int total_units, const int ntile_n, const int per_xcd) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
   constexpr int KSTEPS = SK / 16;
   constexpr bool RES = NK > 0;
+  constexpr bool PCS = RING > 0;
   constexpr bool WSMAP = WS || RES;          // workgroup <-> (group, channel tile) mapping of the stationary-weights variants
   // resident mode: 8 x 32 pixel tiles, halo 10 x 34 = 340 rows of RB bytes per 16-channel plane, planes packed (the 11th DMA piece
   // of a plane starts at row 308 and rewrites 12 rows of the 10th with the same bytes instead of running into the next plane)
@@ -130,10 +135,15 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   constexpr int R_EOFF = R_WOFF + NK * GEO::B_BYTES;                             // epilogue patches (REG = 0)
   constexpr int R_FLOFF = R_EOFF + (REG ? 0 : NW * GEO::EPI_WAVE);               // hand-over counters (PC): full[2], empty[2]
   constexpr int R_CSOFF = R_FLOFF + 64;                                          // channel scales of all images, loaded once
-  static_assert(!PC || RES, "producer wave: resident mode only");
+  static_assert(!PC || RES || PCS, "producer waves: resident / streaming producer-consumer modes only");
+  static_assert(!PCS || (KS == 3 && SK == 16 && WN == 1 && WM == 8 && MF == 2 && !EB && !WS && !RES && PC == 2), "streaming producer / consumer mode: 3x3, eight consumer waves of two pixel fragments, two producers");
+  constexpr int P_SLOT = GEO::A_BYTES + GEO::B_BYTES;                            // one stage slot of the ring
+  constexpr int P_EOFF = RING * P_SLOT;                                          // epilogue patches (REG = 0)
+  constexpr int P_FLOFF = P_EOFF + (REG ? 0 : NW * GEO::EPI_WAVE);               // hand-over counters: full[RING], empty[RING]
+  constexpr int P_CSOFF = P_FLOFF + 64;                                          // output channel scales of four units in a row (1 KiB each)
   static_assert(!RES || (KS == 3 && SK == 16 && WN == 1 && WM == 8 && MF == 1 && !EB && !WS), "resident mode: 3x3, eight waves of one tile row");
-  static_assert(!REG || RES, "register epilogue: resident mode only");
-  constexpr bool LATE_RES = NF * MF > 4;  // too many fragments to hold every residual row during the last matrix phase
+  static_assert(!REG || RES || PCS, "register epilogue: resident / streaming producer-consumer modes only");
+  constexpr bool LATE_RES = NF * MF > 4 || PCS;  // too many fragments to hold every residual row during the last matrix phase (PCS: register budget of 3 waves per SIMD)
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   const bool cs_lds = CS_LDS && p.out_cs != nullptr;
   // LDS map of the WS variant: [A stage 0 | A stage 1 | nk weight stages | epilogue patches | channel scales]
   const int ws_boff = 2 * GEO::A_BYTES, ws_eoff = ws_boff + (p.Cg / SK) * GEO::B_BYTES;
-  const int cs_base = RES ? R_CSOFF : (WS ? ws_eoff + NW * GEO::EPI_WAVE : GEO::CS_OFF);
+  const int cs_base = PCS ? P_CSOFF : RES ? R_CSOFF : (WS ? ws_eoff + NW * GEO::EPI_WAVE : GEO::CS_OFF);
 
   // issue cursor: (unit, stage) of the next DMA batch.  Per lane only byte offsets inside the tensors are kept; the
   // stage (input-channel) advance is a scalar offset, so one batch costs one m0 write + one buffer_load per piece.
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   };
 
   static_assert(!GEO::EPI_OVERLAY || NW * GEO::EPI_WAVE <= GEO::STAGE, "epilogue patches overlay stage 1");
-  float* sE = reinterpret_cast<float*>(smem + (RES ? R_EOFF : (WS ? ws_eoff : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE))) + wave * GEO::EPI_WAVE);
+  float* sE = reinterpret_cast<float*>(smem + (PCS ? P_EOFF : RES ? R_EOFF : (WS ? ws_eoff : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE))) + wave * GEO::EPI_WAVE);
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
@@ -399,14 +409,92 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   // (LDS address space on the pointer: a generic volatile access would be a flat load, which also waits for this wave's vmcnt)
   typedef __attribute__((address_space(3))) volatile unsigned lds_vu32_t;
   typedef __attribute__((address_space(3))) unsigned lds_u32_t;
-  [[maybe_unused]] lds_vu32_t* flags = (lds_vu32_t*)(smem + R_FLOFF);
+  [[maybe_unused]] lds_vu32_t* flags = (lds_vu32_t*)(smem + (PCS ? P_FLOFF : R_FLOFF));
   if constexpr (PC) {
     if (wave == 0 && lane < 16) flags[lane] = 0u;
   }
-  if (!PC || wave < NW) {
+  if constexpr (PCS) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();   // the zeroed counters are visible to every wave; no barrier from here on
+    if (wave >= NW) {
+      // ---- producers: producer pid fills the stages with (global stage index & 1) == pid, slot = stage % RING
+      const int pid = wave - NW;
+      constexpr int NPA = GEO::APIECES, NPB = GEO::BPIECES;
+      const int half = p.C0 + p.C1;
+      int g = 0, gslot = 0, gfill = 0, pu = -1;
+      for (int u = blockIdx.x; live(u); u += gridDim.x) {
+        const Unit pt = decode(u);
+        ++pu;
+        int ppix[NPA], pslot[NPA], pbv[NPB];
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+          const int r = i * RPW + lrow;
+          const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
+          const int ww = r - hh * TWP - PAD;
+          const int ih = pt.h0 + hh - PAD;
+          int iw = pt.w0 + ww;
+          if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W && iw < p.W + PAD ? 2 * (p.W - 1) - iw : iw);
+          const bool ok = r < R && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+          const int pix = p.resample == DDX_RESAMPLE_UP ? (pt.b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (pt.b * p.sH + ih) * p.sW + iw;
+          ppix[i] = ok ? pix : -1;
+          pslot[i] = (lslot ^ GEO::swz(r)) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+          const int r = min(i * RPW + lrow, TAPS * BN - 1);
+          const int tp = r / BN, nn = r - tp * BN;
+          const int n = min(pt.n0 + nn, p.NgP - 1);
+          pbv[i] = (((tp * p.NgP + n) << ck_shift) + (lslot ^ GEO::swz(r)) * 8) * 2;
+        }
+        for (int q = 0; q < nk; ++q) {
+          if ((g & 1) == pid) {
+            if (gfill > 0) {   // every consumer wave is done with the stage that lived in this slot
+              const unsigned need = (unsigned)(NW * gfill);
+              while (flags[RING + gslot] < need) __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            char* sb = smem + gslot * P_SLOT;
+            int cabs = pt.g * p.Cg + q * SK;
+            const int swapped = (p.paired && cabs >= half) ? 1 : 0;
+            if (swapped) cabs -= half;
+            const int src_id = cabs >= p.C0 ? 1 : 0;
+            const bool c16 = (p.layout >> src_id) & 1;
+            const int cs2 = (src_id ? p.C1 : p.C0) * 2;
+            const int dpix = (swapped || (src_id && p.swap1)) ? ((pt.b ^ 1) - pt.b) * p.sH * p.sW : 0;
+            const int hw = p.sH * p.sW;
+            const int ibase = (pt.b * hw + dpix) * cs2 - pt.b * hw * 32;
+            const int cin_src = src_id ? cabs - p.C0 : cabs;
+            const int soff_a = __builtin_amdgcn_readfirstlane(c16 ? (cin_src >> 4) * hw * 32 : cin_src * 2);
+            const int pmul = __builtin_amdgcn_readfirstlane(c16 ? 32 : cs2);
+            const int padd = __builtin_amdgcn_readfirstlane(c16 ? ibase : dpix * cs2);
+            const rsrc_t rsa = src_id ? rs1 : rs0;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+              const int voff = ppix[i] < 0 ? kOobOffset : ppix[i] * pmul + padd + pslot[i] * 2;
+              dma16(rsa, voff, soff_a, sb + i * 1024);
+            }
+            const int k0 = q * SK;
+            const int soff_b = __builtin_amdgcn_readfirstlane(((((pt.g * p.nchunk + (k0 >> ck_shift)) * TAPS * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) dma16(rsw, pbv[i], soff_b, sb + GEO::A_BYTES + i * 1024);
+            // the unit's output channel scales ride with its first stage (four slots: a slot is rewritten four units later, when every
+            // consumer has released a ring slot filled after its epilogue of this unit)
+            if (q == 0 && p.out_cs) dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, __builtin_amdgcn_readfirstlane((pt.b * p.Cout + pt.g * p.Ng + pt.n0) * 4), smem + P_CSOFF + (pu & 3) * 1024);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flags + gslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          ++g;
+          if (++gslot == RING) { gslot = 0; ++gfill; }
+        }
+      }
+      return;
+    }
+  }
+  if (!PCS && (!PC || wave < NW)) {
     if (live(iu)) issue_setup(iu);
   }
-  if (!PC || wave < NW) {
+  if (!PCS && (!PC || wave < NW)) {
     if constexpr (WSMAP) {
       static_assert(!EB && NF * MF <= 4 && WN == 1, "stationary weights: forward epilogues of the 4-fragment variants");
       if (live(iu)) {   // all nk weight stages of this workgroup's (group, channel tile), once
@@ -440,7 +528,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
       issue_next(S0{});
     }
   }
-  if constexpr (PC) {
+  if constexpr (PC && RES) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // weights, scales and the zeroed counters are in LDS for every wave; no barrier from here on
     if (wave == NW) {
@@ -501,10 +589,11 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   }
   DDX_TR(2);
   int cunit = -1;
+  [[maybe_unused]] int cslot = 0, cfill = 0;   // PCS: ring slot and fill count of the consumer's next stage
   for (int u = blockIdx.x; live(u); u += gridDim.x) {
     ++cunit;
-    const Unit t = RES ? decode(u) : it;   // (resident mode: the issue cursor is already one unit ahead)
-    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + cs_base + (RES ? t.b * (BN * 4) : (cunit & 1) * 1024));  // (the issue cursor is still on this unit, it moves on during the last stage)
+    const Unit t = (RES || PCS) ? decode(u) : it;   // (resident mode: the issue cursor is already one unit ahead; PCS consumers have none)
+    [[maybe_unused]] const float* cs_l = reinterpret_cast<const float*>(smem + cs_base + (RES ? t.b * (BN * 4) : PCS ? (cunit & 3) * 1024 : (cunit & 1) * 1024));  // (the issue cursor is still on this unit, it moves on during the last stage)
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -570,7 +659,20 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     u32x4 rres[LATE_RES ? (NF > 2 ? 2 : 1) : NF][MF][2];
     auto rslot = [](int i) { return LATE_RES ? (NF > 2 ? (i & 1) : 0) : i; };
 
-    if constexpr (RES) {
+    if constexpr (PCS) {
+      for (int q = 0; q < nk; ++q) {
+        DDX_TR(5);
+        const unsigned need = (unsigned)(cfill + 1);   // fills of this slot so far, this stage's included
+        while (flags[cslot] < need) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        DDX_TR(0);
+        compute_at(smem + cslot * P_SLOT, smem + cslot * P_SLOT + GEO::A_BYTES);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's fragment reads of the slot are done (the MFMAs consumed them)
+        if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flags + RING + cslot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (++cslot == RING) { cslot = 0; ++cfill; }
+        DDX_TR(3);
+      }
+    } else if constexpr (RES) {
       DDX_TR(5);
       if constexpr (PC) {
         const unsigned need = (unsigned)((cunit >> 1) + 1);   // tiles landed in this buffer so far, this unit's included
@@ -675,24 +777,31 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
       // of its pixel: one 16-byte store per lane and plane, 32 consecutive pixels x 32 bytes = 1 KiB contiguous per instruction.
       typedef __attribute__((ext_vector_type(2))) float f32x2_t;
       typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-      const int eh = t.h0 + wm, ew = t.w0 + l31;
-      const bool pok = eh < p.H && ew < p.W;
       const long plane = (long)p.H * p.W * 16;
+#pragma unroll
+      for (int j = 0; j < MF; ++j) {
+      // fragment j of this wave: 32 consecutive pixels of one tile row
+      const int ml0 = (wm * MF + j) * 32;
+      const int eth = (int)(((float)ml0 + 0.5f) * inv_TW);
+      const int eh = t.h0 + eth, ew = t.w0 + (ml0 - eth * TW) + l31;
+      const bool pok = eh < p.H && ew < p.W;
       const long pbase = ((long)(t.b * p.H + eh) * p.W + ew) * 16 + (long)t.b * (p.Cout / 16 - 1) * plane + khalf * 8;
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[i][0][r];
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
         if (p.clip > 0.f) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = fminf(fmaxf(v[r], -p.clip), p.clip);
         }
         if (p.out_act) {
           if (p.out_cs) {
+            // LDS copy of the unit's scales (resident mode) or the global vector (consumers of the streaming mode have no DMA in flight)
+            const float* csp = cs_l + i * 32;   // LDS copy of the unit's scales
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs_l + i * 32 + 8 * jj + 4 * khalf);
+              const f32x4 c4 = *reinterpret_cast<const f32x4*>(csp + 8 * jj + 4 * khalf);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[4 * jj + e] *= c4[e];
             }
@@ -722,6 +831,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 #endif
           DDX_TR(8);
         }
+      }
       }
     } else {
 #pragma unroll
@@ -999,9 +1109,31 @@ int launch_dma_res(const ConvParams& p, hipStream_t s) {
   return pc_knob ? launch_dma_res_t<NF, NK, REG, 1>(p, s) : launch_dma_res_t<NF, NK, REG, 0>(p, s);
 }
 
+// Streaming producer / consumer mode (RING > 0 in conv_dma_kernel): 512-pixel units, eight consumer + two producer waves, grid <= 256.
+template <int NF, int REG>
+int launch_dma_pcs(const ConvParams& p, hipStream_t s) {
+  using GEO = DmaGeom<3, 16, NF, 1, 8, 2>;
+  constexpr int RING = 3;
+  constexpr int SMEM_BYTES = RING * (GEO::A_BYTES + GEO::B_BYTES) + (REG ? 0 : GEO::NW * GEO::EPI_WAVE) + 64 + 4096;
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+  auto kern = conv_dma_kernel<3, 16, NF, 1, 1, 0, 8, 2, 0, 0, REG, 2, RING>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_dma pcs)");
+    attr_done = true;
+  }
+  const int ntile_n = ceil_div(p.Ng, GEO::BN);
+  const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
+  const int grid = (int)std::min<long>(total, 256);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (GEO::NW + 2)), SMEM_BYTES, s, p, (int)total, ntile_n, 0);
+  dma_trace_report(total);
+  return check_launch("conv_dma_pcs");
+}
+
 // which resident variant serves the layer: 0 none, else 1 + (NF - 1) + 2 * (NK == 4) + 4 * REG
 int dma_res_variant(const ConvParams& p, int TH, int TW) {
-  static const int knob = std::getenv("DDX_DMA_RES") ? atoi(std::getenv("DDX_DMA_RES")) : 1;   // 0: off; 2: patch epilogue wherever it fits (A/B of the register epilogue)
+  static const int knob = std::getenv("DDX_DMA_RES") ? atoi(std::getenv("DDX_DMA_RES")) : 1;   // 0: off; 2: patch epilogue wherever it fits (A/B of the register epilogue); 3: both epilogues
   if (!knob || p.epilogue == DDX_EPI_SILU_BWD || TH != 8 || TW != 32) return 0;
   const int nk = p.Cg / 16;
   if (p.Cg % 16 || (nk != 2 && nk != 4)) return 0;
@@ -1014,7 +1146,9 @@ int dma_res_variant(const ConvParams& p, int TH, int TW) {
   const int base = 2 * nk * 340 * 32 + nk * 9 * bn * 32 + 64 + cs_bytes;
   const bool patch_fits = base + 8 * DmaGeom<3, 16, 1, 1, 8, 1>::EPI_WAVE <= 160 * 1024;
   const bool reg = reg_ok && (knob != 2 || !patch_fits);
-  if (!reg && !patch_fits) return 0;
+  // measured (same command): -10 ... -25 % on the conv_res0-type layers (register epilogue), 0 ... +7 % on the residual + twin layers
+  // (patch epilogue) -> automatic choice only for the former; DDX_DMA_RES=2 / 3 take the patch epilogue wherever it fits
+  if (!reg && (knob == 1 || !patch_fits)) return 0;
   if (reg && base > 160 * 1024) return 0;
   return 1 + (nf - 1) + 2 * (nk == 4 ? 1 : 0) + 4 * (reg ? 1 : 0);
 }
@@ -1123,6 +1257,31 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
       }
     }
   }
+  // streaming producer / consumer mode: 512-pixel units wherever they fill the chip (DDX_DMA_PCS: 0 off, 1 = layers the resident
+  // mode does not take, 2 = before the resident mode)
+  static const int pcs_knob = std::getenv("DDX_DMA_PCS") ? atoi(std::getenv("DDX_DMA_PCS")) : 1;
+  auto try_pcs = [&](int* rc) -> bool {
+    using GEO = DmaGeom<3, 16, 2, 1, 8, 2>;
+    int th = 0, tw = 0; double ut = 0;
+    if (ksize != 3 || !pcs_knob || p.epilogue == DDX_EPI_SILU_BWD || p.Cg % 16 || !dma_tile(p, 3, &th, &tw, &ut, GEO::BM, GEO::AROWS) || ut < 0.6) return false;
+    const int bn = p.Ng <= 32 ? 32 : 64;
+    const long units = (long)p.B * ceil_div(p.H, th) * ceil_div(p.W, tw) * p.G * ceil_div(p.Ng, bn);
+    if (units < 384) return false;
+    ConvParams q = p;
+    q.TH = th; q.TW = tw;
+    q.tiles_h = ceil_div(p.H, th); q.tiles_w = ceil_div(p.W, tw);
+    q.arows_alloc = (th + 2) * (tw + 2);
+    q.inv_TWP = 1.0f / (float)(tw + 2);
+    const bool reg = p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0;
+    // measured (tools/conv_bench.py --cases dma3 --epi real --path dma16, B = 4): -5 ... -11 % on the conv_res0-type layers of
+    // levels 0 / 1 (register epilogue), +6 ... +18 % on the residual + twin layers (patch epilogue at 168 registers), slower at level 2
+    // (384 units for 256 workgroups) -> automatic choice only for the former; DDX_DMA_PCS=2 takes it wherever it runs
+    if (pcs_knob == 1 && (!reg || units < 640)) return false;
+    *rc = bn == 32 ? (reg ? launch_dma_pcs<1, 1>(q, s) : launch_dma_pcs<1, 0>(q, s)) : (reg ? launch_dma_pcs<2, 1>(q, s) : launch_dma_pcs<2, 0>(q, s));
+    return true;
+  };
+  int rc_pcs = 0;
+  if (pcs_knob == 2 && try_pcs(&rc_pcs)) return rc_pcs;
   if (ksize == 3) {
     switch (dma_res_variant(p, TH, TW)) {
       case 1: return launch_dma_res<1, 2, 0>(p, s);
@@ -1135,6 +1294,7 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
       default: break;
     }
   }
+  if (pcs_knob == 1 && try_pcs(&rc_pcs)) return rc_pcs;
   // stationary weights where all K-stages of a channel tile fit beside two activation stages (Cg <= 32 with 64-channel tiles,
   // Cg <= 64 with 32-channel tiles): -7 ... -15 % on those layers.  DDX_DMA_WS=0 off, 2 = also 32-channel tiles for
   // Ng = 64 layers with Cg = 64 (experiment)

@@ -733,7 +733,8 @@ import torch
 from dualdiffusion_amd import ops
 g = torch.Generator(device="cuda").manual_seed(3)
 worst = 0.0
-for (B, H, W, C0, C1, Cout, G, res) in [(2, 40, 200, 128, 0, 128, 2, True), (2, 40, 200, 64, 64, 64, 2, False), (4, 32, 344, 256, 0, 512, 8, False)]:
+for (B, H, W, C0, C1, Cout, G, res) in [(2, 40, 200, 128, 0, 128, 2, True), (2, 40, 200, 64, 64, 64, 2, False), (4, 32, 344, 256, 0, 512, 8, False),
+                                         (4, 16, 344, 768, 0, 768, 8, True), (4, 32, 700, 512, 0, 256, 8, True)]:
     a0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
     a1 = torch.randn(B, H, W, C1, device="cuda", generator=g).bfloat16() if C1 else None
     w = torch.randn(Cout, (C0 + C1) // G, 3, 3, device="cuda", generator=g)
@@ -753,7 +754,7 @@ print("WORST", worst)
 """
 
 
-@pytest.mark.parametrize("knob", ["DDX_DMA_BIG=2", "DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_RES=2"])
+@pytest.mark.parametrize("knob", ["DDX_DMA_BIG=2", "DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_RES=2", "DDX_DMA_RES=3", "DDX_DMA_PC=0", "DDX_DMA_PCS=0", "DDX_DMA_PCS=2"])
 def test_conv_dma_experiment_knobs_stay_correct(knob):
     """The LDS-DMA variants behind environment knobs (512-pixel units, XCD unit order, resident mode off / with the patch epilogue;
     read once per process, so each runs in its own interpreter) against the register-staged kernel on grouped / two-source /
@@ -820,6 +821,12 @@ C16_CASES = {
     "res_32_64_b5": (5, 37, 650, 64, 0, 128, 2, False, False, True, False, (1, 0, 1, 0)),      # five images of channel scales, ragged H and W
     "res_64_32_b5": (5, 37, 650, 128, 0, 64, 2, False, True, False, True, (1, 0, 0, 1)),       # residual + blocked twin on the patch epilogue
     "res_plain_clip": (4, 32, 688, 512, 0, 512, 8, False, False, False, False, (0, 0, 1, 0)),  # NHWC source, plain blocked output
+    # streaming producer / consumer mode (512-pixel units, ring of stage slots, two producer waves)
+    "pcs_cat_160_128": (4, 16, 344, 768, 512, 1024, 8, False, False, True, False, (1, 1, 1, 0)),  # groups straddle the two sources
+    "pcs_res_twin": (4, 16, 344, 1024, 0, 512, 8, False, True, False, True, (1, 0, 0, 1)),
+    "pcs_up_96": (4, 16, 344, 768, 0, 1536, 8, True, False, True, False, (1, 0, 1, 0)),           # nearest-up source, three channel tiles
+    "pcs_ng32": (6, 64, 640, 96, 0, 32, 1, False, True, False, True, (1, 0, 0, 1)),               # one fragment column per wave
+    "pcs_ragged_h": (4, 20, 344, 768, 0, 768, 8, False, False, False, False, (1, 0, 1, 0)),       # ragged tile rows and columns, Ng = 96
 }
 
 
