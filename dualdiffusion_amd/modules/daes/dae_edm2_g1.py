@@ -289,6 +289,8 @@ class DAE_G1(DualDiffusionDAE):
             y = ops.conv2d(act, P[pre + ".conv_res0"], reflect_w=True, out_act=True)       # mp_silu(conv) (no embedding in the encoder, :193-194)
             act = torch.empty_like(h)
             h = ops.conv2d(y, P[pre + ".conv_res1"], residual=h, res_t=c.res_balance, clip=256.0, reflect_w=True, out2=act, out2_scale=1.0)
+            if getattr(self, "collect", None) is not None:
+                self.collect[pre] = h
         z8 = ops.conv2d(h, P["conv_latents_out"], reflect_w=True)                          # [2B, H, W, 8] (4 latent channels used)
         # avg_pool2d(ds) as repeated 2x2 means on the NHWC images, then tensor_5d_to_4d: latent channel c of slice z -> channel c * 2 + z
         ds = self.downsample_ratio
@@ -347,8 +349,11 @@ class DAE_G1(DualDiffusionDAE):
         if embeddings is not None and self.emb_label is not None:
             emb2 = embeddings.to(self.device, torch.float32).repeat_interleave(2, dim=0).contiguous()
             cs = self._emb_scales(emb2)
+        coll = getattr(self, "collect", None)       # tests: {} -> block outputs [2B, H, W, C] (image n = 2b + z)
         for pre, blk in self._blocks:
             h, act = self._dec_block(P, pre, blk, h, act, cs.get(pre))
+            if coll is not None:
+                coll[pre] = h
         y8 = ops.conv2d(h, P["conv_out"], reflect_w=True, path="direct")                     # [2B, H, W, 8] (1 channel used)
         return ops.images_to_stereo(y8, 1)                                                    # [B, 2, H, W] fp32
 

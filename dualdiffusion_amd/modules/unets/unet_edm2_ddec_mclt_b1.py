@@ -311,10 +311,15 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
         tw0 = torch.empty(B * 2, H, W, self.enc["conv_in"].out_channels, dtype=dt, device=dev)
         x = ops.conv2d(x0, P["conv_in"], src1=x0, swap_src1=True, reflect_w=True, out2=tw0, out2_scale=skip_scale[0])
         skips, skip_acts = [x], [tw0]
+        coll = getattr(self, "collect", None)       # tests: {} -> block outputs [2B, H, W, C] (image n = 2b + z)
+        if coll is not None:
+            coll["enc.conv_in"] = x
         for name in enc_names:
             x, tw = self._block(P, "enc." + name, self.enc[name], x, None, cs["enc." + name], twin_scale=skip_scale[len(skips)])
             skips.append(x)
             skip_acts.append(tw)
+            if coll is not None:
+                coll["enc." + name] = x
         # the last encoder output is also the first decoder block's input: that block reads the unit-scale twin
         x_act = ops.silu_scale_fwd(x, None, 1.0)
         for i, name in enumerate(dec_names):
@@ -325,6 +330,8 @@ class DDec_MCLT_UNet_B1(DualDiffusionUNet):
                 x, x_act = self._block(P, pre, self.dec[name], x, x_act, cs[pre], skips.pop(), skip_acts.pop(), twin_scale=tws)
             else:
                 x, x_act = self._block(P, pre, self.dec[name], x, x_act, cs[pre], twin_scale=tws)
+            if coll is not None:
+                coll[pre] = x
         y8 = ops.conv2d(x, P["conv_out"], src1=x, swap_src1=True, reflect_w=True)
         out = torch.empty(B, 2, H, W, dtype=torch.float32, device=dev)
         check(lib().ddx_ddec_output_combine(ptr(y8), y8.shape[-1], ptr(x_in), ptr(sig), ptr(out), B, 2 * H * W, cfg.sigma_data, dtype_code(dt),

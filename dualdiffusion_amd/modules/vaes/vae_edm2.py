@@ -216,8 +216,11 @@ class _VAEEngine:
         h, w = H, W
         if kind == "enc":
             first, blocks, last, last_gain = vae.enc["conv_in"], [b for n, b in vae.enc.items() if n != "conv_in"], vae.conv_latents_out, vae.latents_out_gain
+            names = [n for n in vae.enc if n != "conv_in"]
         else:
             first, blocks, last, last_gain = vae.conv_latents_in, list(vae.dec.values()), vae.conv_out, vae.out_gain
+            names = list(vae.dec)
+        self.stages: dict = {}      # "enc.<block>" / "dec.<block>" -> NHWC output buffer (static: valid after any run)
         pw_first = pb.prep(first, cg_pad=Cpad, npix=B * H * W)
         x = pb.act(H, W, first.out_channels)
         # decoder blocks read mp_silu(x) twins written by their producers; encoder blocks normalise first and need none
@@ -231,6 +234,7 @@ class _VAEEngine:
                 h, w = h * 2, w * 2
             tw = 1.0 if (kind == "dec" and bi + 1 < len(blocks)) else None
             x, x_act = pb.block(blk, x, None, 1.0, 1.0, h, w, act0=x_act, twin_scale=tw, **bk)
+            self.stages[f"{kind}.{names[bi]}"] = x
         # a 2-channel conv_out would fall to the scalar kernel: prepare it with zero rows up to 8 and read back the real ones
         cout = last.out_channels
         cpad = cout if cout % 4 == 0 else (cout + 7) // 8 * 8

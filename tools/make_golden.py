@@ -772,6 +772,148 @@ def gen_ddec() -> None:
                                weights="oracle.ddec_oracle.random_ddec_state(cfg, seed)"))
 
 
+# --------------------------------------------------------------------------------------------- default-config models at real widths
+# (the kernel variants the DEFAULT vae.json / diffusion decoder / DAE_G1 select -- dense 96 ... 480-channel 3x3 convs at
+#  256 rows, 32 ... 256-channel (1,3,3) / (2,3,3) kernels -- were only reached by isfinite checks.)  Inputs are re-drawn from the seed on
+# the GPU box (torch's CPU generator; a checksum is stored), outputs and every block output travel as strided sub-samples.
+
+def _sub(v: torch.Tensor, stride: int) -> torch.Tensor:
+    return v.detach().float().flatten()[::stride].clone()
+
+
+def _checksum(v: torch.Tensor) -> torch.Tensor:
+    v = v.double().flatten()
+    return torch.stack([v.sum(), v.abs().sum(), v[::97].sum()]).float()
+
+
+def gen_vae_default() -> None:
+    """AutoencoderKL_EDM2 with config/models/default/vae.json (96 x (1,2,3,5), 3 layers per block, mlp_groups 1) on a (1, 2, 256, 688)
+    mel-shaped sample: encode, and decode of the reference's own latents."""
+    print("vae default (real widths, B=1, 256 x 688)")
+    ref_import.install_old_vae()
+    from modules.old.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config
+    from modules.formats.frequency_scale import FrequencyScale
+    over = dict(model_channels=96, channel_mult=(1, 2, 3, 5), num_layers_per_block=3, label_dim=1612, target_snr=31.984371183438952,
+                mlp_multiplier=1, mlp_groups=1, channel_mult_emb=None)
+    cfg = O.vae_cfg(**over)
+    ref = AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}))
+    ref = ref.requires_grad_(False).train(False)
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v) for k, v in O.vae_param_shapes(cfg).items()}
+    sd = O.random_vae_state(cfg, seed=31)
+    ref.load_state_dict(sd)
+    print(f"    {sum(v.numel() for v in sd.values()) / 1e6:.1f} M parameters")
+
+    class Fmt:
+        fs = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+        def get_ln_freqs(self, x):
+            ln = self.fs.get_unscaled(x.shape[2] + 2, device=x.device)[1:-1].log2()
+            ln = ln.view(1, 1, -1, 1).repeat(x.shape[0], 1, 1, x.shape[3])
+            return ((ln - ln.mean()) / ln.std()).to(x.dtype)
+
+    g = torch.Generator().manual_seed(32)
+    H, W = 256, 688
+    x = torch.randn(1, 2, H, W, generator=g)
+    labels_like = torch.randn(1, cfg["label_dim"], generator=g)
+    got, hooks = {}, []
+    for side in ("enc", "dec"):
+        for nm, mod in getattr(ref, side).items():
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=f"{side}.{nm}": got.__setitem__(key, o.detach().clone())))
+    with torch.no_grad():
+        emb = R_silu(ref.emb_label(R_normalize(labels_like)))
+        z = ref.encode(x, emb, Fmt()).mode()
+        rec = ref.decode(z, emb, Fmt())
+    for h in hooks:
+        h.remove()
+    mean, _ = O.vae_encode(sd, cfg, x, emb)
+    check("vae default encode", mean, z, 1e-5)
+    check("vae default decode", O.vae_decode(sd, cfg, z, emb), rec, 1e-5)
+    STRIDE = 997
+    t = {"x_check": _checksum(x), "labels_like": labels_like, "emb": emb, "latents": z, "recon_sub": _sub(rec, 7)}
+    for k, v in got.items():
+        t[f"stage_sub.{k}"] = _sub(v, STRIDE)
+    save("vae_default", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in over.items()}, seed=31, input_seed=32, H=H, W=W,
+                                 stage_stride=STRIDE, recon_stride=7, freq_range=[20.0, 16000.0], weights="oracle.random_vae_state(cfg, seed)"))
+
+
+def gen_ddec_default() -> None:
+    """DDec_MCLT_UNet_B1 with its default config (32 x (1,2,3,4), 3 layers per block, 4096 PSD bins) on a (1, 2, 256, 344) input."""
+    print("ddec default (real widths, B=1, 256 x 344)")
+    from modules.unets.unet_edm2_ddec_mclt_b1 import DDec_MCLT_UNet_B1, DDec_MCLT_UNet_B1_Config
+    from oracle import ddec_oracle as DO
+    cfg = DO.ddec_cfg()
+    unet = DDec_MCLT_UNet_B1(DDec_MCLT_UNet_B1_Config()).requires_grad_(False).train(False)
+    shapes = DO.ddec_param_shapes(cfg)
+    ref_sd = unet.state_dict()
+    assert {k: tuple(v.shape) for k, v in ref_sd.items() if "fourier" not in k} == {k: tuple(v) for k, v in shapes.items() if "fourier" not in k}, "param shapes differ"
+    sd = DO.random_ddec_state(cfg, seed=51)
+    unet.load_state_dict(sd)
+    g = torch.Generator().manual_seed(52)
+    B, H, W = 1, 256, 344
+    sigma = torch.tensor([1.3])
+    x_in = torch.randn(B, 2, H, W, generator=g) * torch.sqrt(sigma ** 2 + 1).view(-1, 1, 1, 1)
+    x_ref = torch.randn(B, 2, cfg["in_psd_freqs"], W, generator=g).abs()
+    got, hooks = {}, []
+    for side in ("enc", "dec"):
+        for nm, mod in getattr(unet, side).items():
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=f"{side}.{nm}": got.__setitem__(key, o.detach().float().clone())))
+    with torch.no_grad():
+        out = unet(x_in, sigma, None, None, x_ref=x_ref)
+    for h in hooks:
+        h.remove()
+    with torch.no_grad():
+        ours = DO.ddec_forward(sd, cfg, x_in, sigma, x_ref)
+        ours32 = DO.ddec_forward(sd, cfg, x_in, sigma, x_ref, compute_dtype=torch.float32)
+    # (at these widths torch's CPU bf16 convolutions block their reductions differently for the 5-D reference tensors and the
+    #  oracle's folded ones: bf16 rounding noise, not bit equality as in the small fixture)
+    check("ddec default forward (bf16 body as the reference)", ours, out, 2e-2)
+    print(f"    fp32 oracle vs the reference's bf16 forward: rel-L2 {rel_l2(ours32, out):.2e}")
+    STRIDE = 997
+    t = {"x_in_check": _checksum(x_in), "x_ref_check": _checksum(x_ref), "sigma": sigma, "out_sub": _sub(out, 5), "out_fp32_oracle_sub": _sub(ours32, 5)}
+    for k, v in got.items():
+        t[f"stage_sub.{k}"] = _sub(v, STRIDE)
+    save("ddec_default", t, dict(seed=51, input_seed=52, B=B, H=H, W=W, stage_stride=STRIDE, out_stride=5,
+                                  weights="oracle.ddec_oracle.random_ddec_state(default cfg, seed)"))
+
+
+def gen_dae_default() -> None:
+    """DAE_G1 with its default config (32 x (1,2,4,8) decoder, 6 encoder layers, 3 decoder layers per block) on a (1, 2, 256, 344) mel
+    spectrogram: encode, decode of the reference's own latents."""
+    print("dae_g1 default (real widths, B=1, 256 x 344)")
+    from modules.daes.dae_edm2_g1 import DAE_G1, DAE_G1_Config
+    from oracle import dae_oracle as DO
+    cfg = DO.dae_cfg()
+    dae = DAE_G1(DAE_G1_Config()).requires_grad_(False).train(False)
+    ref_shapes = {k: tuple(v.shape) for k, v in dae.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in DO.dae_param_shapes(cfg).items()}, (set(ref_shapes) ^ set(DO.dae_param_shapes(cfg)))
+    sd = DO.random_dae_state(cfg, seed=61)
+    dae.load_state_dict(sd)
+    g = torch.Generator().manual_seed(62)
+    B, H, W = 1, 256, 344
+    x = torch.randn(B, 2, H, W, generator=g).abs() * 2.0
+    emb_in = torch.randn(B, cfg["in_channels_emb"], generator=g)
+    got, hooks = {}, []
+    for side in ("enc", "dec"):
+        for nm, mod in getattr(dae, side).items():
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=f"{side}.{nm}": got.__setitem__(key, o.detach().float().clone())))
+    with torch.no_grad():
+        emb = dae.get_embeddings(emb_in)
+        lat = dae.encode(x, emb)
+        rec = dae.decode(lat, emb)
+    for h in hooks:
+        h.remove()
+    o_emb = DO.dae_embeddings(sd, emb_in)
+    check("dae default embeddings", o_emb, emb, 2e-6)
+    check("dae default encode", DO.dae_encode(sd, cfg, x, o_emb), lat, 1e-5)
+    check("dae default decode", DO.dae_decode(sd, cfg, lat, o_emb), rec, 1e-5)
+    STRIDE = 997
+    t = {"x_check": _checksum(x), "emb_in": emb_in, "emb": emb, "latents": lat, "recon_sub": _sub(rec, 5)}
+    for k, v in got.items():
+        t[f"stage_sub.{k}"] = _sub(v, STRIDE)
+    save("dae_g1_default", t, dict(seed=61, input_seed=62, B=B, H=H, W=W, stage_stride=STRIDE, recon_stride=5,
+                                    weights="oracle.dae_oracle.random_dae_state(default cfg, seed)"))
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -782,7 +924,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
