@@ -12,6 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig  # noqa: E402
 from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from default_configs import DEFAULT_UNET, DEFAULT_VAE  # noqa: E402  (the json configs, not the dataclass defaults)
 from dualdiffusion_amd.modules.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config  # noqa: E402
 from dualdiffusion_amd.pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams  # noqa: E402
 
@@ -30,9 +32,9 @@ def main():
     fgla = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     torch.manual_seed(0)
     dt = torch.bfloat16
-    unet = init(UNet(UNetConfig()).requires_grad_(False).train(False).to(device="cuda", dtype=dt))
+    unet = init(UNet(UNetConfig(**DEFAULT_UNET)).requires_grad_(False).train(False).to(device="cuda", dtype=dt))
     unet.compile()
-    vae = init(AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config()).requires_grad_(False).train(False).to(device="cuda", dtype=dt))
+    vae = init(AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**DEFAULT_VAE)).requires_grad_(False).train(False).to(device="cuda", dtype=dt))
     fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
     pipe = DualDiffusionPipeline({"unet": unet, "vae": vae, "format": fmt})
     clap = torch.randn(1, 512, device="cuda").repeat(2 * B, 1)     # one prompt embedding for the conditioned and the dropped rows
@@ -44,7 +46,7 @@ def main():
     latents = pipe.diffusion_decode(params, quiet=True, audio_embedding=clap, sample_shape=shape)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     with torch.no_grad():
-        vemb = vae.get_embeddings(torch.randn(B, 512, device="cuda"))
+        vemb = vae.get_embeddings(torch.randn(B, DEFAULT_VAE["label_dim"], device="cuda"))
         mel = vae.decode(latents.to(dt), vemb, fmt)
         torch.cuda.synchronize(); t2 = time.perf_counter()
         mel = vae.decode(latents.to(dt), vemb, fmt)

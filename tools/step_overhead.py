@@ -5,12 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as Bn  # noqa
 
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from default_configs import DEFAULT_UNET  # noqa: E402
+
+
 def main():
     from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
     from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
     class Fmt: ms_freq_scale = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
     torch.manual_seed(0)
-    unet = UNet(UNetConfig()).requires_grad_(False).train(False).to(device="cuda", dtype=torch.bfloat16)
+    unet = UNet(UNetConfig(**DEFAULT_UNET)).requires_grad_(False).train(False).to(device="cuda", dtype=torch.bfloat16)
     unet.normalize_weights()
     for n, p in unet.named_parameters():
         if p.ndim == 0: p.data.fill_(0.7)

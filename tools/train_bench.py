@@ -12,6 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale  # noqa: E402
 from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from default_configs import DEFAULT_UNET  # noqa: E402  (unet.json, not the dataclass defaults)
 from dualdiffusion_amd.training.optimizer import LRScheduleConfig, OptimizerConfig  # noqa: E402
 from dualdiffusion_amd.training.train_step import UNetTrainStep  # noqa: E402
 
@@ -24,7 +26,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     torch.manual_seed(0)
-    unet = UNet(UNetConfig()).requires_grad_(False).to(device="cuda", dtype=torch.float32).train(True)
+    unet = UNet(UNetConfig(**DEFAULT_UNET)).requires_grad_(False).to(device="cuda", dtype=torch.float32).train(True)
     unet.normalize_weights()
     for n, p in unet.named_parameters():
         if p.ndim == 0:
