@@ -234,6 +234,11 @@ PROTOTYPES = {
     "ddx_plan_op_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ddx_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "ddx_plan_destroy": (None, [C.c_void_p]),
+    "ddx_plan_include": (C.c_int, [C.c_void_p]),
+    "ddx_sampler_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "ddx_lincomb3_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int64, C.c_void_p]),
+    "ddx_step_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 
@@ -317,6 +322,11 @@ class Plan:
 
     def graph_launch(self, stream: Optional[int] = None) -> None:
         check(lib().ddx_plan_graph_launch(self._h, stream if stream is not None else current_stream()), "plan_graph_launch")
+
+    def include(self, other: "Plan") -> None:
+        """While THIS plan is being recorded: append the launches of the finished plan `other`."""
+        check(lib().ddx_plan_include(other._h), "plan_include")
+        self.keepalive.append(other)
 
     def profile(self, reps: int = 3, stream: Optional[int] = None) -> list:
         """Eager replay with a hipEvent pair around every op: [(tag, flops, bytes, mean_ms)] per op."""

@@ -489,6 +489,74 @@ extern "C" int ddx_lincomb3(const float* x, float a, const float* y, float b, co
   }, stream, "lincomb3", 0.0, 4.0 * (double)n * (2 + (y ? 1 : 0) + (z ? 1 : 0)));
 }
 
+// ---- sampler step with device-resident scalars: the whole Heun / CFG step is one recorded plan (one hipGraph), so its per-step
+// numbers (sigma rows, lerp weights, noise gain, which noise tensor) are read from device tables indexed by a device step counter.
+__global__ __launch_bounds__(256) void sampler_load_kernel(const float* __restrict__ sample, float* __restrict__ x_in, float* __restrict__ x_pre,
+                                                           float* __restrict__ sigma_out, const float* __restrict__ sig_table, const int* __restrict__ step,
+                                                           int which, int B, int nb, size_t n_per_copy) {
+  const int st = *step;
+  if (blockIdx.x == 0 && threadIdx.x < nb) sigma_out[threadIdx.x] = sig_table[((size_t)st * 2 + which) * nb + threadIdx.x];
+  const int copies = nb / B;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_per_copy; i += (size_t)gridDim.x * 256) {
+    const float v = sample[i];
+    for (int c = 0; c < copies; ++c) {
+      x_in[(size_t)c * n_per_copy + i] = v;
+      if (x_pre) x_pre[(size_t)c * n_per_copy + i] = v;
+    }
+  }
+}
+
+// out = a*x + b*y + c*z with (a, b, c) = coef[step * stride + {ia, ib, ic}] (a negative index: operand absent) and z advanced by
+// step * z_step_stride elements (the step's own noise tensor): the same expression, in the same order, as lincomb3_kernel
+__global__ __launch_bounds__(256) void lincomb3_dev_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                           float* __restrict__ out, size_t n, const float* __restrict__ coef, const int* __restrict__ step,
+                                                           int stride, int ia, int ib, int ic, size_t z_step_stride) {
+  const int st = *step;
+  const float a = coef[st * stride + ia];
+  const float b = ib >= 0 ? coef[st * stride + ib] : 0.f;
+  const float c = ic >= 0 ? coef[st * stride + ic] : 0.f;
+  const float* zz = z ? z + (size_t)st * z_step_stride : nullptr;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = a * x[i];
+    if (y && ib >= 0) v += b * y[i];
+    if (zz && ic >= 0) v += c * zz[i];
+    out[i] = v;
+  }
+}
+
+__global__ void step_advance_kernel(int* step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+
+extern "C" int ddx_sampler_load(const float* sample, float* x_in, float* x_pre, float* sigma_out, const float* sig_table, const int32_t* step,
+                                int32_t which, int32_t B, int32_t nb, int64_t n_per_copy, ddx_stream stream) {
+  if (!sample || !x_in || !sigma_out || !sig_table || !step || B <= 0 || nb < B || nb % B || nb > 256 || n_per_copy <= 0 || (which != 0 && which != 1))
+    return set_error(DDX_ERR_ARG, "sampler_load: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(sampler_load_kernel, dim3(grid_for((size_t)n_per_copy)), dim3(256), 0, s, sample, x_in, x_pre, sigma_out, sig_table, step, which, B, nb,
+                       (size_t)n_per_copy);
+    return check_launch("sampler_load");
+  }, stream, "sampler_load", 0.0, 4.0 * (double)n_per_copy * (1 + (nb / B) * (x_pre ? 2 : 1)));
+}
+
+extern "C" int ddx_lincomb3_dev(const float* x, const float* y, const float* z, float* out, int64_t n, const float* coef, const int32_t* step,
+                                int32_t stride, int32_t ia, int32_t ib, int32_t ic, int64_t z_step_stride, ddx_stream stream) {
+  if (!x || !out || !coef || !step || n <= 0 || stride <= 0 || ia < 0 || ia >= stride || ib >= stride || ic >= stride || z_step_stride < 0)
+    return set_error(DDX_ERR_ARG, "lincomb3_dev: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(lincomb3_dev_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, s, x, y, z, out, (size_t)n, coef, step, stride, ia, ib, ic, (size_t)z_step_stride);
+    return check_launch("lincomb3_dev");
+  }, stream, "lincomb3", 0.0, 4.0 * (double)n * (2 + ((y && ib >= 0) ? 1 : 0) + ((z && ic >= 0) ? 1 : 0)));
+}
+
+extern "C" int ddx_step_advance(int32_t* step, ddx_stream stream) {
+  if (!step) return set_error(DDX_ERR_ARG, "step_advance: null counter");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step);
+    return check_launch("step_advance");
+  }, stream, "op", 0.0, 8.0);
+}
+
 extern "C" int ddx_linear_small_batched(const ddx_linear_job* jobs_dev, int32_t njobs, int32_t max_O, const float* x, int32_t x_stride,
                                         int32_t M, int32_t w_dtype, ddx_stream stream) {
   if (!jobs_dev || njobs <= 0 || max_O <= 0 || !x || M <= 0) return set_error(DDX_ERR_ARG, "linear_small: bad args");

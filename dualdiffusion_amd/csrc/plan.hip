@@ -104,6 +104,25 @@ extern "C" int ddx_plan_join(void) {
 }
 
 // replay every op in order; launches of the side lane go to the plan's side stream, markers become event edges
+// Append the launches of a finished plan to the plan being recorded (a sampler step = [glue, UNet forward, glue, UNet forward, glue]
+// as ONE plan / hipGraph).  The closures are copied: `src` may be replayed or destroyed independently afterwards, the buffers its
+// launches point into must outlive both.
+extern "C" int ddx_plan_include(const ddx_plan* src) {
+  ddx_plan* p = ddx::g_recording;
+  if (!p) return ddx::set_error(DDX_ERR_ARG, "plan_include: no plan is being recorded");
+  if (!src || src->recording || src == p) return ddx::set_error(DDX_ERR_ARG, "plan_include: bad source plan");
+  for (size_t i = 0; i < src->ops.size(); ++i) {
+    if (src->kind[i] == DDX_MARK_FORK || src->kind[i] == DDX_MARK_JOIN) {
+      if (p->forked && src->kind[i] == DDX_MARK_FORK) return ddx::set_error(DDX_ERR_ARG, "plan_include: fork inside a fork");
+      p->forked = src->kind[i] == DDX_MARK_FORK;
+    }
+    p->ops.push_back(src->ops[i]);
+    p->meta.push_back(src->meta[i]);
+    p->kind.push_back(src->kind[i]);
+  }
+  return DDX_OK;
+}
+
 static int plan_replay(ddx_plan* p, hipStream_t s, bool lanes) {
   static const bool lanes_enabled = []() { const char* e = std::getenv("DDX_PLAN_LANES"); return !e || e[0] != '0'; }();
   lanes = lanes && lanes_enabled;

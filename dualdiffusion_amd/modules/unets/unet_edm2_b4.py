@@ -209,14 +209,18 @@ class UNet(DualDiffusionUNet):
                            "for inference call under torch.no_grad() or requires_grad_(False)")
         return self._forward_plan(x_in, sigma, format, embeddings, x_ref, perturbed_input)
 
+    def _engine_for(self, B: int, H: int, W: int, with_xref: bool) -> "_UNetEngine":
+        key = (B, H, W, self.dtype, self.training, with_xref)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _UNetEngine(self, B, H, W, self.training, with_xref)
+            self._engines[key] = eng
+        return eng
+
     @torch.no_grad()
     def _forward_plan(self, x_in, sigma, format, embeddings, x_ref=None, perturbed_input=None) -> torch.Tensor:
         B, _, H, W = x_in.shape
-        key = (B, H, W, self.dtype, self.training, x_ref is not None)
-        eng = self._engines.get(key)
-        if eng is None:
-            eng = _UNetEngine(self, B, H, W, self.training, x_ref is not None)
-            self._engines[key] = eng
+        eng = self._engine_for(B, H, W, x_ref is not None)
         return eng.run(x_in, sigma, format, embeddings, x_ref, perturbed_input, use_graph=self._use_graph)
 
 
@@ -360,6 +364,20 @@ class _UNetEngine:
         pb.step(lambda: ops.unet_output_combine(y, self.x_in, self.sigma, self.x_ref, self.out, cfg.sigma_data))
         pb.finalize(emb, cemb, pre_steps=front)
         self.fplan = pb.fplan
+
+    def prepare(self, format, embeddings, x_ref) -> None:
+        """Everything of a call that does not change inside a sampler loop: frequency table, prepared weights, embeddings, x_ref
+        (the sampler's step graph writes x_in / x_pre / sigma itself and replays `fplan`)."""
+        fs = format.ms_freq_scale
+        lkey = (type(fs).__name__, getattr(fs, "freq_scale", None), float(getattr(fs, "freq_min", 0.0)), float(getattr(fs, "freq_max", 0.0)),
+                int(getattr(fs, "num_filters", 0)))
+        if lkey != self._lnf_key:
+            self.lnf.copy_(self.u.get_ln_freqs_rows(format, self.B, self.H, self.W))
+            self._lnf_key = lkey
+        self.pb.refresh_weights(self.u.parameters())
+        self.emb_in.copy_(embeddings)
+        if x_ref is not None:
+            self.x_ref.copy_(x_ref)
 
     def run(self, x_in, sigma, format, embeddings, x_ref, perturbed_input, use_graph: bool) -> torch.Tensor:
         fs = format.ms_freq_scale

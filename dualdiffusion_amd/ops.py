@@ -509,6 +509,28 @@ def lincomb3(out: torch.Tensor, x: torch.Tensor, a: float, y: Optional[torch.Ten
     return out
 
 
+def sampler_load(sample: torch.Tensor, x_in: torch.Tensor, x_pre: Optional[torch.Tensor], sigma_out: torch.Tensor, sig_table: torch.Tensor,
+                 step: torch.Tensor, which: int) -> None:
+    """x_in[c] = x_pre[c] = sample for the nb / B batch copies and sigma_out = sig_table[step][which] (device step counter)."""
+    B, nb = sample.shape[0], x_in.shape[0]
+    assert sample.is_contiguous() and x_in.is_contiguous() and sig_table.shape[1:] == (2, nb) and step.dtype == torch.int32
+    check(lib().ddx_sampler_load(ptr(sample), ptr(x_in), ptr(x_pre), ptr(sigma_out), ptr(sig_table), ptr(step), which, B, nb, sample.numel(),
+                                 current_stream()), "sampler_load")
+
+
+def lincomb3_dev(out: torch.Tensor, coef: torch.Tensor, step: torch.Tensor, x: torch.Tensor, ia: int, y: Optional[torch.Tensor] = None, ib: int = -1,
+                 z: Optional[torch.Tensor] = None, ic: int = -1, z_step_stride: int = 0) -> torch.Tensor:
+    """out = a*x + b*y + c*z with (a, b, c) = coef[step, (ia, ib, ic)] read on the device; z advanced by step * z_step_stride elements."""
+    assert out.dtype == torch.float32 and coef.dtype == torch.float32 and coef.ndim == 2 and step.dtype == torch.int32
+    check(lib().ddx_lincomb3_dev(ptr(x), ptr(y), ptr(z), ptr(out), out.numel(), ptr(coef), ptr(step), coef.shape[1], ia, ib, ic, z_step_stride,
+                                 current_stream()), "lincomb3_dev")
+    return out
+
+
+def step_advance(step: torch.Tensor) -> None:
+    check(lib().ddx_step_advance(ptr(step), current_stream()), "step_advance")
+
+
 def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, Cn, H, W = x.shape
     if out is None:

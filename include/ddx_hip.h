@@ -395,6 +395,19 @@ int ddx_resample2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int3
 int ddx_lincomb3(const float* x, float a, const float* y, float b, const float* z, float c, float* out, int64_t n,
                  ddx_stream stream);
 
+/* The sampler step with device-resident scalars (the whole CFG + Heun step of dual_diffusion_pipeline.py:683-737 recorded as ONE
+ * plan / hipGraph: its per-step numbers cannot be kernel arguments).  `step` is a device int32 counter.
+ *   ddx_sampler_load: x_in[c] = x_pre[c] = sample for the nb / B copies c (CFG batch doubling; x_pre may be NULL) and
+ *                     sigma_out[0..nb) = sig_table[step][which][0..nb)   (sig_table: [steps][2][nb] fp32, which = 0 | 1, nb <= 256)
+ *   ddx_lincomb3_dev: out = a*x + b*y + c*z with (a, b, c) = coef[step * stride + {ia, ib, ic}] (ib / ic < 0: operand unused) and
+ *                     z advanced by step * z_step_stride elements; same arithmetic, in the same order, as ddx_lincomb3
+ *   ddx_step_advance: *step += 1 */
+int ddx_sampler_load(const float* sample, float* x_in, float* x_pre, float* sigma_out, const float* sig_table, const int32_t* step,
+                     int32_t which, int32_t B, int32_t nb, int64_t n_per_copy, ddx_stream stream);
+int ddx_lincomb3_dev(const float* x, const float* y, const float* z, float* out, int64_t n, const float* coef, const int32_t* step,
+                     int32_t stride, int32_t ia, int32_t ib, int32_t ic, int64_t z_step_stride, ddx_stream stream);
+int ddx_step_advance(int32_t* step, ddx_stream stream);
+
 /* Layout conversion helpers NCHW fp32 <-> NHWC dtype (module boundary). */
 int ddx_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
 int ddx_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t dtype, ddx_stream stream);
@@ -620,6 +633,8 @@ int ddx_plan_graph_launch(ddx_plan* p, ddx_stream stream);
 /* per-op metadata (kernel family tag, algorithmic flops and bytes) and a hipEvent-timed eager replay */
 int ddx_plan_op_info(const ddx_plan* p, int i, const char** tag, double* flops, double* bytes);
 int ddx_plan_profile(ddx_plan* p, ddx_stream stream, int reps, float* ms_out);
+/* While a plan is being recorded: append the launches of the finished plan `src` (e.g. a module's forward inside a sampler step). */
+int ddx_plan_include(const ddx_plan* src);
 void ddx_plan_destroy(ddx_plan* p);
 
 #ifdef __cplusplus

@@ -35,6 +35,42 @@ def test_diffusion_decode_matches_reference():
     a = pipe.diffusion_decode(params, audio_embedding=t["clap"], sample_shape=tuple(m["shape"]))
     b = pipe.diffusion_decode(params, audio_embedding=t["clap"], sample_shape=tuple(m["shape"]))
     assert torch.equal(a, b) and torch.isfinite(a).all()
+    # the one-graph-per-step loop (default) and the eager step loop are the same arithmetic: bit-identical, with and without
+    # ancestral noise, Heun on and off
+    for kw in (dict(use_heun=True, input_perturbation=1.0), dict(use_heun=False, input_perturbation=0.0)):
+        params = SampleParams(seed=7, num_steps=3, batch_size=m["B"], sigma_max=20.0, sigma_min=0.1, sigma_data=1.0, cfg_scale=1.7, **kw)
+        assert pipe.step_graph
+        g_out = pipe.diffusion_decode(params, audio_embedding=t["clap"], sample_shape=tuple(m["shape"]))
+        pipe.step_graph = False
+        try:
+            e_out = pipe.diffusion_decode(params, audio_embedding=t["clap"], sample_shape=tuple(m["shape"]))
+        finally:
+            pipe.step_graph = True
+        assert torch.equal(g_out, e_out), kw
+
+
+def test_sampler_device_scalar_ops():
+    """ddx_sampler_load / ddx_lincomb3_dev / ddx_step_advance against their host-scalar twins."""
+    from dualdiffusion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, nb, shp = 2, 4, (2, 3, 4, 6)
+    sample = torch.randn(shp, generator=g).cuda()
+    sig_table = torch.rand(5, 2, nb, generator=g).cuda()
+    coef = torch.randn(5, 5, generator=g).cuda()
+    noise = torch.randn((5,) + shp, generator=g).cuda()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    x_in, x_pre, sig = torch.zeros((nb,) + shp[1:], device="cuda"), torch.zeros((nb,) + shp[1:], device="cuda"), torch.zeros(nb, device="cuda")
+    for st in range(3):
+        ops.sampler_load(sample, x_in, x_pre, sig, sig_table, step, 1)
+        assert torch.equal(x_in[:B], sample) and torch.equal(x_in[B:], sample) and torch.equal(x_pre, x_in) and torch.equal(sig, sig_table[st, 1])
+        a, b = torch.randn(shp, generator=g).cuda(), torch.randn(shp, generator=g).cuda()
+        want = ops.lincomb3(torch.empty_like(a), a, float(coef[st, 2]), b, float(coef[st, 3]), noise[st], float(coef[st, 4]))
+        got = ops.lincomb3_dev(torch.empty_like(a), coef, step, a, 2, b, 3, noise, 4, z_step_stride=a.numel())
+        assert torch.equal(got, want)
+        want2 = ops.lincomb3(torch.empty_like(a), a, float(coef[st, 0]), b, float(coef[st, 1]))
+        assert torch.equal(ops.lincomb3_dev(torch.empty_like(a), coef, step, a, 0, b, 1), want2)
+        ops.step_advance(step)
+    assert int(step.item()) == 3
 
 
 def test_lincomb3():
