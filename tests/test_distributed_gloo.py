@@ -62,6 +62,30 @@ def _worker(rank: int, ws: int, port: int, out_dir: str):
         e2.start_early()
         e2.finish()
         assert torch.equal(f2, torch.full((10,), 3.0)), early
+    # the explicit reduce-scatter + all-gather pair gives what the all-reduce gives, for pieces that do and do not divide
+    # by the world size, with and without an early part and an accumulation bucket; the bf16 bucket option sums in bf16
+    g = torch.Generator().manual_seed(7 + rank)
+    for n, early in ((11, 5), (16, 8), (7, 0), (9, 9)):
+        base = torch.randn(n, generator=g)
+        want = base.clone()
+        dist.all_reduce(want)
+        for kw in (dict(mode="rs_ag"), dict(mode="all_reduce"), dict(mode="rs_ag", comm_dtype=torch.bfloat16)):
+            f3 = torch.zeros(n)
+            f3[:early] = base[:early]
+            e3 = GradientExchange(f3, early, **kw)
+            e3.start_early()
+            f3[early:] = base[early:]
+            e3.finish()
+            if "comm_dtype" in kw:
+                assert torch.allclose(f3, want, rtol=2e-2, atol=2e-2), (n, early, kw)
+            else:
+                assert torch.allclose(f3, want, rtol=0, atol=1e-6), (n, early, kw, f3, want)
+        acc = torch.ones(n)
+        f4 = base.clone()
+        e4 = GradientExchange(f4, early, accum=acc, mode="rs_ag")
+        e4.start_early()
+        e4.finish()
+        assert torch.allclose(acc, want + 2.0, atol=1e-6)          # (1 + g_rank0) + (1 + g_rank1)
     # every rank derives the same learning rate from the global step (host schedule, reference trainer.py:653-663)
     c = LRScheduleConfig()
     assert lr_multiplier(c, 2500) == 0.5 and lr_multiplier(c, 70000) == 1.0 and abs(lr_multiplier(c, 280000) - 0.5) < 1e-12

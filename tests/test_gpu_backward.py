@@ -418,10 +418,12 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
     s.close()
     res = {}
     try:
-        for bucketed in (False, True, "graph"):
+        for bucketed in (False, True, "graph", "rs_ag"):
             if bucketed is True:
                 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
                 monkeypatch.setenv("DDX_DDP_BUCKETS", "1")
+            if bucketed == "rs_ag":      # the explicit reduce_scatter_tensor + all_gather_into_tensor pair over RCCL (eager loop)
+                monkeypatch.setenv("DDX_GRAD_EXCHANGE", "rs_ag")
             unet = UNet(UNetConfig(**over)).requires_grad_(False)
             unet.load_state_dict(sd, strict=True)
             unet = unet.to(device="cuda", dtype=torch.float32).train(True)
@@ -439,14 +441,16 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
                 outs.append((o["loss"].clone().cpu(), o["grad_norm"]))
             res[bucketed] = (outs, unet.dec["block0_layer0"].conv_res0.weight.data.clone().cpu(),
                              unet.enc["block0_layer0"].conv_res0.weight.data.clone().cpu())
+            if bucketed == "graph":
+                res["graph_tail"] = ts._graph_tail is not None
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
     # "graph": the train batch captured as two hipGraphs cut at the bucket hook, the early collective between the two replays
-    assert ts._graph_tail is not None, "graph mode with an exchange must capture the batch in two halves"
-    for variant in (True, "graph"):
+    assert res["graph_tail"], "graph mode with an exchange must capture the batch in two halves"
+    for variant in (True, "graph", "rs_ag"):
         for (l0, n0), (l1, n1) in zip(res[False][0], res[variant][0]):
             assert rel_l2(l1, l0) < 5e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)   # (two runs differ by bf16 rounding flips: float atomics)
         e_dec, e_enc = rel_l2(res[variant][1], res[False][1]), rel_l2(res[variant][2], res[False][2])
-        print(f"bucketed exchange (world 1, rccl, {'two hipGraphs' if variant == 'graph' else 'eager'}) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
+        print(f"bucketed exchange (world 1, rccl, {'two hipGraphs' if variant == 'graph' else ('reduce-scatter + all-gather' if variant == 'rs_ag' else 'eager')}) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
         assert e_dec < 2e-3 and e_enc < 2e-3
