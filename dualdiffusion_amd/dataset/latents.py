@@ -41,7 +41,9 @@ def _normalize(x: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
 
 
 def _mp_sum(a: torch.Tensor, b: torch.Tensor, t: float) -> torch.Tensor:
-    return torch.lerp(a.float(), b.float(), t) / ((1 - t) ** 2 + t ** 2) ** 0.5
+    """mp_tools.mp_sum with a python-float t (mp_tools.py:274-279): in the operands' dtype -- the stored CLAP rows are bfloat16 and the
+    reference's loader mixes and averages them in bfloat16 (training/dataset.py:228-236)."""
+    return a.lerp(b, t) / ((1 - t) ** 2 + t ** 2) ** 0.5
 
 
 class LatentPreEncoder:
@@ -73,7 +75,9 @@ class LatentPreEncoder:
                 crops.append(torch.flip(x, dims=(1,)))
         crops = torch.cat(crops, dim=0).contiguous()
         bsz = cfg.latents_batch_size
-        mels = [fmt.raw_to_mel_spec(crops[b * bsz:(b + 1) * bsz]) for b in range(self.num_batches_per_sample)]
+        # the reference hands the DAE a bfloat16 mel spectrogram (encode.py:329 `.type(torch.bfloat16)`): round here too, so that
+        # latents encoded by an fp32 DAE are comparable with reference-encoded datasets
+        mels = [fmt.raw_to_mel_spec(crops[b * bsz:(b + 1) * bsz]).to(torch.bfloat16).float() for b in range(self.num_batches_per_sample)]
         mel = torch.cat(mels, dim=0)
         emb = _normalize(clap_audio_embeddings.float().mean(dim=0, keepdim=True)).to(dev)
         dae_emb = dae.get_embeddings(emb)
@@ -130,7 +134,7 @@ class LatentsLoader:
             start = float(np.clip(start - 0.5, 0, emb_len - 1))
             end = float(np.clip(end - 0.5, start, emb_len - 1))
             s_int, s_frac, e_int, e_frac = int(start), start % 1, int(end), end % 1
-            selected = emb_sl[s_int:e_int + 1].float()
+            selected = emb_sl[s_int:e_int + 1]            # stored dtype (bfloat16), as the reference
             if s_frac > 0:
                 selected[0] = _normalize(_mp_sum(emb_sl[s_int], emb_sl[s_int + 1], s_frac).unsqueeze(0))[0]
             if e_frac > 0:

@@ -108,9 +108,18 @@ class DualDiffusionPipeline(torch.nn.Module):
         return self
 
     def compile(self, compile_options: Optional[dict] = None) -> None:
-        for module in self.children():
-            if hasattr(module, "compile"):
-                module.compile(**(compile_options or {}))
+        """reference :178-187: a dict of per-module dicts {module_name: options} compiles only the listed modules, anything else is
+        one option set for every module."""
+        opts = compile_options or {}
+        per_module = bool(opts) and all(isinstance(v, dict) for v in opts.values()) and "options" not in opts
+        for name, module in self.named_children():
+            if not hasattr(module, "compile"):
+                continue
+            if per_module:
+                if name in opts:
+                    module.compile(**opts[name])
+            else:
+                module.compile(**opts)
 
     # ------------------------------------------------------------------ model directory (reference :178-300)
     @staticmethod

@@ -111,6 +111,14 @@ class FusedAdamW:
             raise L.DDXError(f"FusedAdamW: at most {L.MAX_EMAS} EMAs per launch")
         if self.emas and ema is not None:
             raise L.DDXError("FusedAdamW: give either `ema` (one fixed-beta EMA) or `emas`")
+        for j, e in enumerate(self.emas):      # the kernel gets raw pointers: every EMA must shadow every parameter exactly
+            missing = [k for k in params if k not in e.tensors]
+            if missing:
+                raise L.DDXError(f"FusedAdamW: EMA {j} has no tensor for {missing[:3]} (a missing entry would silently get no update)")
+            for k, p_ in params.items():
+                t = e.tensors[k]
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != p_.shape or t.device != p_.device:
+                    raise L.DDXError(f"FusedAdamW: EMA {j} tensor of {k} must be contiguous float32 with the parameter's shape on its device")
         self.fused = bool(self.emas) or wn_rows is not None
         self.m = {k: torch.zeros_like(p) for k, p in params.items()}
         self.v = {k: torch.zeros_like(p) for k, p in params.items()}

@@ -571,8 +571,10 @@ int ddx_mss_loss_scale(const ddx_mss_desc* d, ddx_stream stream);
  * multi-tensor kernels over a DEVICE table of jobs, one job per parameter tensor (fp32 master weights / moments):
  *   ddx_multi_grad_norm: workspace3[0] = sum g^2, [1] = clip coefficient min(1, max_norm / (norm + 1e-6)), [2] = norm,
  *                        norm taken of grad_scale * g  (grad_scale = loss_scale / world_size after a SUM all-reduce)
- *   ddx_multi_adamw    : g' = g * grad_scale * (clip_coef ? *clip_coef : 1); decoupled weight decay; bias-corrected AdamW
+ *   ddx_multi_adamw    : g' = g * grad_scale * (clip_coef ? clip_coef[0] : 1); decoupled weight decay; bias-corrected AdamW
  *                        (step = 1-based step count); ema (if non-NULL) <- lerp(ema, p, 1 - ema_beta).
+ *                        clip_coef, when given, must point at TWO floats {coefficient, gradient norm} -- workspace3 + 1 of
+ *                        ddx_multi_grad_norm: a non-finite norm in clip_coef[1] skips the whole step on the device.
  * max_n = largest job size (grid sizing).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {

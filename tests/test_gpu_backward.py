@@ -454,3 +454,37 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
         e_dec, e_enc = rel_l2(res[variant][1], res[False][1]), rel_l2(res[variant][2], res[False][2])
         print(f"bucketed exchange (world 1, rccl, {'two hipGraphs' if variant == 'graph' else ('reduce-scatter + all-gather' if variant == 'rs_ag' else 'eager')}) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
         assert e_dec < 2e-3 and e_enc < 2e-3
+
+
+def test_run_batch_graph_with_accumulation_reports_every_micro_step_loss():
+    """UNetTrainStep.run_batch with use_graph=True and two accumulation micro-steps: the per-micro-step losses are those of the eager
+    loop (the captured static loss buffer is overwritten by every replay: each micro-step's value is copied out), same gradient norm."""
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    from dualdiffusion_amd.training.optimizer import LRScheduleConfig, OptimizerConfig
+    from dualdiffusion_amd.training.sigma_sampler import SigmaSampler, SigmaSamplerConfig
+    from dualdiffusion_amd.training.train_step import UNetTrainStep
+    over = dict(model_channels=256, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=64, num_layers_per_block=1, in_channels_emb=64,
+                logvar_channels=32)
+    cfg = O.unet_cfg(**over)
+    sd = O.random_unet_state(cfg, seed=4, gain_value=0.3)
+    g = torch.Generator().manual_seed(8)
+    A, Bd, H, W = 2, 2, 16, 32
+    samples, clap = torch.randn(A * Bd, 4, H, W, generator=g), torch.randn(A * Bd, 64, generator=g)
+    jitter = torch.tensor([0.3])
+    res = {}
+    for use_graph in (False, True):
+        unet = UNet(UNetConfig(**over)).requires_grad_(False)
+        unet.load_state_dict(sd, strict=True)
+        unet = unet.to(device="cuda", dtype=torch.float32).train(True)
+        ts = UNetTrainStep(unet, _Fmt(), OptimizerConfig(), LRScheduleConfig(learning_rate=1e-4, lr_warmup_steps=1, lr_reference_steps=1000),
+                           use_graph=use_graph, gradient_accumulation_steps=A, sigma_sampler=SigmaSampler(SigmaSamplerConfig()),
+                           conditioning_dropout=0.0)
+        ts.global_step = 1
+        gen = torch.Generator(device="cuda").manual_seed(77)
+        out = ts.run_batch(samples, clap, generator=gen, sigma_jitter=jitter)
+        res[use_graph] = (out["loss"].detach().float().cpu().clone(), float(out["grad_norm"]))
+    l_e, l_g = res[False][0], res[True][0]
+    assert l_e.numel() == A * Bd and l_g.shape == l_e.shape
+    assert not torch.allclose(l_e[:Bd], l_e[Bd:]), "the two micro-steps must have different losses for this test to mean anything"
+    assert rel_l2(l_g, l_e) < 5e-4, (l_g, l_e)
+    assert abs(res[True][1] - res[False][1]) <= 2e-3 * abs(res[False][1])

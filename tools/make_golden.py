@@ -914,6 +914,35 @@ def gen_dae_default() -> None:
                                     weights="oracle.dae_oracle.random_dae_state(default cfg, seed)"))
 
 
+def gen_loader() -> None:
+    """The reference's own DatasetTransform (training/dataset.py:157-260: DualDiffusionDataset.__call__) on a small pre-encoded track
+    file: random variation / time crop of the latents and the crop's CLAP audio embedding (bfloat16 mp_sum / normalize / sum, as stored)."""
+    print("latents loader (reference DatasetTransform)")
+    import tempfile
+    import numpy as np
+    from safetensors.torch import save_file as st_save
+    import training.dataset as RD
+    from modules.embeddings.clap import CLAP_Config
+    from modules.formats.ms_mdct_dual import MS_MDCT_DualFormatConfig
+    g = torch.Generator().manual_seed(70)
+    lat = torch.randn(3, 8, 16, 800, generator=g).to(torch.bfloat16)
+    emb = R_normalize(torch.randn(7, 512, generator=g)).to(torch.bfloat16)
+    ds = RD.DualDiffusionDataset.__new__(RD.DualDiffusionDataset)       # (the constructor opens a dataset directory: not needed for __call__)
+    torch.nn.Module.__init__(ds)
+    ds.config = RD.DatasetConfig(data_dir="", raw_crop_width=1408768, latents_crop_width=688, load_datatypes=("latents", "audio_embeddings"))
+    ds.format_config = MS_MDCT_DualFormatConfig()
+    ds.clap_config = CLAP_Config()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "track.safetensors")
+        st_save({"latents": lat, "clap_audio_embeddings": emb}, path)
+        np.random.seed(5)
+        out = ds({"file_name": ["a", "b", "c", "d"], "latents_file_name": [path] * 4})
+    save("latents_loader", {"latents": lat, "clap_audio_embeddings": emb, "out_latents": torch.stack(out["latents"]),
+                            "out_audio_embeddings": torch.stack(out["audio_embeddings"])},
+         dict(numpy_seed=5, n=4, raw_crop_width=1408768, latents_crop_width=688, sample_rate=int(ds.format_config.sample_rate),
+              audio_embedding_duration=float(ds.clap_config.audio_embedding_duration)))
+
+
 def R_silu(x):
     from modules.mp_tools import mp_silu
     return mp_silu(x)
@@ -924,7 +953,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default, "loader": gen_loader}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
