@@ -1,0 +1,76 @@
+"""torch.library registration of the module-level entry points (the reference compiles its modules with torch.compile,
+src/modules/module.py:145-149, and wraps callers such as the sampling loop).
+
+The HIP modules are launch plans over ctypes calls that Dynamo cannot see into: traced naively they graph-break at the first
+ctypes call.  Each module forward is therefore ONE custom op with a fake (meta) implementation:
+
+    dualdiffusion_amd::unet_forward(x_in, sigma, embeddings, x_ref?, perturbed_input?, module, format) -> float32 [B, C_out, H, W]
+    dualdiffusion_amd::vae_encode(x, class_embeddings, module, format) -> latents mean
+    dualdiffusion_amd::vae_decode(z, class_embeddings, module, format) -> sample
+
+`module` / `format` are integer handles into a registry (custom ops take tensors and scalars only).  `UNet.forward`,
+`AutoencoderKL_EDM2.encode / decode` route through these ops while `torch.compiler.is_compiling()`, so a compiled caller holds the
+whole module call as one opaque node: no graph break, shapes and dtypes known to the tracer.  Inference only (the autograd bridge
+of dualdiffusion_amd.autograd is a torch.autograd.Function, which Dynamo already traces as a unit).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+# handle -> object.  A plain dict with id() keys: Dynamo traces `handle_of` itself (id() and a global dict store are supported), so the
+# registration happens while the caller is being compiled.  Entries are strong references: a module that was part of a compiled
+# graph stays alive as long as the process (the compiled graph holds its handle as a constant).
+_OBJECTS: dict = {}
+
+
+def handle_of(obj) -> int:
+    """Integer handle of a module / format object."""
+    h = id(obj)
+    _OBJECTS[h] = obj
+    return h
+
+
+def _get(h: int):
+    obj = _OBJECTS.get(h, None)
+    if obj is None:
+        # while Dynamo traces, the dict store of `handle_of` is a deferred side effect: the fake implementations see the handle before
+        # the registry does.  The object is alive (the traced caller holds it), so its id() can be turned back into a reference.
+        import ctypes
+        obj = ctypes.cast(h, ctypes.py_object).value
+    return obj
+
+
+@torch.library.custom_op("dualdiffusion_amd::unet_forward", mutates_args=())
+def unet_forward(x_in: torch.Tensor, sigma: torch.Tensor, embeddings: torch.Tensor, x_ref: Optional[torch.Tensor],
+                 perturbed_input: Optional[torch.Tensor], module: int, format: int) -> torch.Tensor:
+    return _get(module)._forward_plan(x_in, sigma, _get(format), embeddings, x_ref, perturbed_input)
+
+
+@unet_forward.register_fake
+def _(x_in, sigma, embeddings, x_ref, perturbed_input, module, format):
+    cfg = _get(module).config
+    return x_in.new_empty((x_in.shape[0], cfg.out_channels, x_in.shape[2], x_in.shape[3]), dtype=torch.float32)
+
+
+@torch.library.custom_op("dualdiffusion_amd::vae_encode", mutates_args=())
+def vae_encode(x: torch.Tensor, class_embeddings: torch.Tensor, module: int, format: int) -> torch.Tensor:
+    return _get(module)._run_chunked("enc", x, class_embeddings, _get(format))
+
+
+@vae_encode.register_fake
+def _(x, class_embeddings, module, format):
+    vae = _get(module)
+    return x.new_empty(tuple(vae.get_latent_shape(x.shape)), dtype=torch.float32)
+
+
+@torch.library.custom_op("dualdiffusion_amd::vae_decode", mutates_args=())
+def vae_decode(z: torch.Tensor, class_embeddings: torch.Tensor, module: int, format: int) -> torch.Tensor:
+    return _get(module)._run_chunked("dec", z, class_embeddings, _get(format))
+
+
+@vae_decode.register_fake
+def _(z, class_embeddings, module, format):
+    vae = _get(module)
+    return z.new_empty(tuple(vae.get_sample_shape(z.shape)), dtype=torch.float32)

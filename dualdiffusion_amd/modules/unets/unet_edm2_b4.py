@@ -200,6 +200,10 @@ class UNet(DualDiffusionUNet):
     def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor,
                 x_ref: Optional[torch.Tensor] = None, perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
         """reference unet_edm2_b4.py:250-296.  Returns float32 NCHW like the reference."""
+        if torch.compiler.is_compiling() and not self.training:
+            # under torch.compile the whole forward is one custom op with a fake implementation (no graph break in a compiled caller)
+            from ... import compile_ops
+            return compile_ops.unet_forward(x_in, sigma, embeddings, x_ref, perturbed_input, compile_ops.handle_of(self), compile_ops.handle_of(format))
         self._require_device()
         if _autograd.wants_grad(self):
             # training forward under autograd (reference trainer: unet(...) then accelerator.backward(loss), trainer.py:1016)

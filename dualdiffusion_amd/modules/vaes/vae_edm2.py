@@ -181,12 +181,19 @@ class AutoencoderKL_EDM2(DualDiffusionVAE):
 
     def encode(self, x: torch.Tensor, class_embeddings: torch.Tensor, format) -> IsotropicGaussianDistribution:
         """reference vae_edm2.py:259-269."""
-        mean = self._run_chunked("enc", x, class_embeddings, format)
+        if torch.compiler.is_compiling():
+            from ... import compile_ops
+            mean = compile_ops.vae_encode(x, class_embeddings, compile_ops.handle_of(self), compile_ops.handle_of(format))
+        else:
+            mean = self._run_chunked("enc", x, class_embeddings, format)
         logvar = torch.tensor(math.log(1 / (self.config.target_snr ** 2 + 1)), device=mean.device, dtype=mean.dtype)
         return IsotropicGaussianDistribution(mean, logvar)
 
     def decode(self, x: torch.Tensor, class_embeddings: torch.Tensor, format) -> torch.Tensor:
         """reference vae_edm2.py:271-279."""
+        if torch.compiler.is_compiling():
+            from ... import compile_ops
+            return compile_ops.vae_decode(x, class_embeddings, compile_ops.handle_of(self), compile_ops.handle_of(format))
         return self._run_chunked("dec", x, class_embeddings, format)
 
     def forward(self, x, class_embeddings, format):
