@@ -83,12 +83,9 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
   static constexpr int NST = 2;  // (a 3-stage ring with counted vmcnt was measured on the 1x1 variant: no gain)
   static constexpr int AI = (APIECES + NW - 1) / NW, BI = (BPIECES + NW - 1) / NW;
   static constexpr int EPI_WAVE = 32 * 36 * 4;  // one 32 pixel x 32 channel fp32 patch, rows padded to 36 floats
-  // 8-fragment waves in 4-wave workgroups: two workgroups per CU only fit when the epilogue patches reuse stage 1 (idle between
-  // the last matrix phase of a unit and the second stage of the next one) -- at the price of one barrier before the epilogue
-  static constexpr bool EPI_OVERLAY = NF * MF > 4 && NW == 4;
   // output channel scales of the unit's BN channels, staged by DMA with the unit's first stage (two 1-KiB DMA targets, units
   // alternate): a global load inside the epilogue would wait behind the next unit's first stage, which is in flight there
-  static constexpr int CS_OFF = NST * STAGE + (EPI_OVERLAY ? 0 : NW * EPI_WAVE);
+  static constexpr int CS_OFF = NST * STAGE + NW * EPI_WAVE;
   static constexpr int SMEM = CS_OFF + 2048;
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
   static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
@@ -132,14 +129,14 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   // of a plane starts at row 308 and rewrites 12 rows of the 10th with the same bytes instead of running into the next plane)
   constexpr int RROWS = 340, RA = RROWS * RB;
   constexpr int R_WOFF = 2 * NK * RA;                                            // weight stages behind the two tile buffers
-  constexpr int R_EOFF = R_WOFF + NK * GEO::B_BYTES;                             // epilogue patches (REG = 0)
-  constexpr int R_FLOFF = R_EOFF + (REG ? 0 : NW * GEO::EPI_WAVE);               // hand-over counters (PC): full[2], empty[2]
+  constexpr int R_FLOFF = R_WOFF + NK * GEO::B_BYTES;                            // hand-over counters: full[2], empty[2]
   constexpr int R_CSOFF = R_FLOFF + 64;                                          // channel scales of all images, loaded once
   static_assert(!PC || RES || PCS, "producer waves: resident / streaming producer-consumer modes only");
+  static_assert(!(RES || PCS) || (PC >= 1 && REG == 1), "resident / streaming producer-consumer modes ship with producer waves and the register epilogue only "
+                "(their barrier / patch-epilogue variants measured 0 ... +18 % against the 4-wave kernels and were removed)");
   static_assert(!PCS || (KS == 3 && SK == 16 && WN == 1 && WM == 8 && MF == 2 && !EB && !WS && !RES && PC == 2), "streaming producer / consumer mode: 3x3, eight consumer waves of two pixel fragments, two producers");
   constexpr int P_SLOT = GEO::A_BYTES + GEO::B_BYTES;                            // one stage slot of the ring
-  constexpr int P_EOFF = RING * P_SLOT;                                          // epilogue patches (REG = 0)
-  constexpr int P_FLOFF = P_EOFF + (REG ? 0 : NW * GEO::EPI_WAVE);               // hand-over counters: full[RING], empty[RING]
+  constexpr int P_FLOFF = RING * P_SLOT;                                         // hand-over counters: full[RING], empty[RING]
   constexpr int P_CSOFF = P_FLOFF + 64;                                          // output channel scales of four units in a row (1 KiB each)
   static_assert(!RES || (KS == 3 && SK == 16 && WN == 1 && WM == 8 && MF == 1 && !EB && !WS), "resident mode: 3x3, eight waves of one tile row");
   static_assert(!REG || RES || PCS, "register epilogue: resident / streaming producer-consumer modes only");
@@ -209,11 +206,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 
   // ---- DMA source bookkeeping (per lane): this wave moves pieces wave, wave+4, ...
   const int lrow = lane / LPR, lslot = lane % LPR;
-  // tile-independent halo coordinates of this lane's rows: a table for the 4-fragment variants; recomputed per unit (from a
-  // laundered lane row, so that the compiler does not turn it back into a table) where the registers go to accumulators
-  constexpr bool DMA_TABLE = MF <= 2;
+  // tile-independent halo coordinates of this lane's rows
+  static_assert(MF <= 2, "at most two pixel fragments per wave");
   auto a_row = [&](int i, int lr, int& hh_out, int& ww_out, int& slot_out) {
-    const int r = (RES ? min((wave + NW * i) * RPW, RROWS - RPW) : (wave + NW * i) * RPW) + lr;
+    const int r = (wave + NW * i) * RPW + lr;
     const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
     hh_out = r < R ? hh - PAD : -(1 << 20);
     ww_out = r - hh * TWP - PAD;
@@ -225,14 +221,12 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     n_out = r - tap_out * BN;
     slot_out = (lslot ^ GEO::swz(r)) * 8;
   };
-  int ahh[DMA_TABLE ? AI : 1], aww[DMA_TABLE ? AI : 1], aslot[DMA_TABLE ? AI : 1];
-  int btap[DMA_TABLE ? BI : 1], bn[DMA_TABLE ? BI : 1], bslot[DMA_TABLE ? BI : 1];
-  if constexpr (DMA_TABLE) {
+  int ahh[AI], aww[AI], aslot[AI];
+  int btap[BI], bn[BI], bslot[BI];
 #pragma unroll
-    for (int i = 0; i < AI; ++i) a_row(i, lrow, ahh[i], aww[i], aslot[i]);
+  for (int i = 0; i < AI; ++i) a_row(i, lrow, ahh[i], aww[i], aslot[i]);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) b_row(i, lrow, btap[i], bn[i], bslot[i]);
-  }
+  for (int i = 0; i < BI; ++i) b_row(i, lrow, btap[i], bn[i], bslot[i]);
   const rsrc_t rs0 = make_rsrc(p.src0, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
   const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
   const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.G * p.nchunk * TAPS * p.NgP * p.CK * 2);
@@ -248,19 +242,13 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   int iu = blockIdx.x, iq = 0, isrc = -1, iunit = 0;
   Unit it{};
   int apix[AI], avoff[AI], bvoff[BI];
-  [[maybe_unused]] int aslot_u[DMA_TABLE ? 1 : AI];
   auto issue_setup = [&](int u) {
     it = decode(u);
     isrc = -1;
-    int lr = lrow;
-    if constexpr (!DMA_TABLE) asm volatile("" : "+v"(lr));
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int hh, ww, sl;
-      if constexpr (DMA_TABLE) { hh = ahh[i]; ww = aww[i]; sl = aslot[i]; }
-      else { a_row(i, lr, hh, ww, sl); aslot_u[i] = sl; }
-      const int ih = it.h0 + hh;
-      int iw = it.w0 + ww;
+      const int ih = it.h0 + ahh[i];
+      int iw = it.w0 + aww[i];
       if (p.reflect_w) iw = iw < 0 ? -iw : (iw >= p.W && iw < p.W + PAD ? 2 * (p.W - 1) - iw : iw);  // only the true border mirrors
       const bool ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
       const int pix = p.resample == DDX_RESAMPLE_UP ? (it.b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (it.b * p.sH + ih) * p.sW + iw;
@@ -268,16 +256,13 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      int tp, nn, sl;
-      if constexpr (DMA_TABLE) { tp = btap[i]; nn = bn[i]; sl = bslot[i]; }
-      else b_row(i, lr, tp, nn, sl);
-      const int n = min(it.n0 + nn, p.NgP - 1);  // rows past NgP only feed outputs that are never stored
-      bvoff[i] = (((tp * p.NgP + n) << ck_shift) + sl) * 2;
+      const int n = min(it.n0 + bn[i], p.NgP - 1);  // rows past NgP only feed outputs that are never stored
+      bvoff[i] = (((btap[i] * p.NgP + n) << ck_shift) + bslot[i]) * 2;
     }
   };
   auto issue_next = [&](auto stage) {  // stage: integral_constant (2-stage pipeline) or runtime int
     if (!live(iu)) return;
-    char* sbase = RES ? smem + ((int)stage * NK + iq) * RA : smem + (int)stage * (WS ? GEO::A_BYTES : GEO::STAGE);   // (resident: stage = tile buffer, iq = plane)
+    char* sbase = smem + (int)stage * (WS ? GEO::A_BYTES : GEO::STAGE);
     int cabs = it.g * p.Cg + iq * SK;  // first channel of this stage in the (virtually concatenated) input
     const int half = p.C0 + p.C1;
     const int swapped = (p.paired && cabs >= half) ? 1 : 0;   // [src0 | src1 | src0' | src1']: second half from image b ^ 1
@@ -292,10 +277,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
         const int hw = p.sH * p.sW;
         const int ibase = (it.b * hw + dpix) * cs2 - it.b * hw * 32;   // image base of the (swapped) image minus the image part of apix
 #pragma unroll
-        for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * 32 + ibase + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+        for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? apix[i] * 32 + ibase + aslot[i] * 2 : kOobOffset;
       } else {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + (DMA_TABLE ? aslot[i] : aslot_u[i]) * 2 : kOobOffset;
+        for (int i = 0; i < AI; ++i) avoff[i] = apix[i] >= 0 ? (apix[i] + dpix) * cs2 + aslot[i] * 2 : kOobOffset;
       }
     }
     const int cin_src = src_id ? cabs - p.C0 : cabs;
@@ -304,9 +289,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int piece = wave + NW * i;
-      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + (RES ? min(piece * RPW, RROWS - RPW) * RB : piece * 1024));
+      if (piece < GEO::APIECES) dma16(rsa, avoff[i], soff_a, sbase + piece * 1024);
     }
-    if (!RES && cs_lds && iq == 0 && wave == 0)   // (rides with the unit's first stage: landed at that stage's barrier)
+    if (cs_lds && iq == 0 && wave == 0)   // (rides with the unit's first stage: landed at that stage's barrier)
       dma16(rscs, lane < BN / 4 ? lane * 16 : kOobOffset, ((it.b * p.Cout + it.g * p.Ng + it.n0) * 4), smem + cs_base + (iunit & 1) * 1024);
     if constexpr (!WSMAP) {
       const int k0 = iq * SK;
@@ -326,34 +311,19 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   };
 
   // ---- fragment read addresses (bytes inside a stage); the tile geometry is the same for every unit
-  // (MF > 2: only the halo row of tap 0 is kept per fragment and the tap offsets are added at the read -- 5 VALU per read
-  // against 4 * 9 address registers the 8-fragment variant does not have)
-  constexpr bool AOFF_TABLE = MF <= 2;
-  int aoff[AOFF_TABLE ? MF : 1][AOFF_TABLE ? TAPS : 1];
-  int abase[MF];
+  int aoff[MF][TAPS];
 #pragma unroll
   for (int j = 0; j < MF; ++j) {
     const int ml = (wm * MF + j) * 32 + l31;
     const int th = (int)(((float)ml + 0.5f) * inv_TW);
     const int tw = ml - th * TW;
-    abase[j] = th * TWP + tw;
-    if constexpr (AOFF_TABLE) {
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int r = abase[j] + (t / KS) * TWP + (t % KS);
-        aoff[j][t] = r * RB + ((khalf ^ GEO::swz(r)) << 4);  // k-step ks adds (2*ks) to the slot: XOR commutes below
-      }
+    for (int t = 0; t < TAPS; ++t) {
+      const int r = th * TWP + tw + (t / KS) * TWP + (t % KS);
+      aoff[j][t] = r * RB + ((khalf ^ GEO::swz(r)) << 4);  // k-step ks adds (2*ks) to the slot: XOR commutes below
     }
   }
-  auto a_addr = [&](int j, int tap) {
-    if constexpr (AOFF_TABLE) return aoff[j][tap];
-    else {
-      int b = abase[j];
-      asm volatile("" : "+v"(b));  // (loop-invariant otherwise: the compiler would hoist all 36 addresses out of the unit loop and spill them)
-      const int r = b + (tap / KS) * TWP + (tap % KS);
-      return r * RB + ((khalf ^ GEO::swz(r)) << 4);
-    }
-  };
+  auto a_addr = [&](int j, int tap) { return aoff[j][tap]; };
   // weight rows tap*BN + i*32 + l31: the swizzle only depends on l31
   const int bsw = GEO::swz(l31);
   const int boff_r = l31 * RB;
@@ -398,8 +368,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     compute_at(smem + (int)stage * GEO::STAGE, smem + (int)stage * GEO::STAGE + GEO::A_BYTES);
   };
 
-  static_assert(!GEO::EPI_OVERLAY || NW * GEO::EPI_WAVE <= GEO::STAGE, "epilogue patches overlay stage 1");
-  float* sE = reinterpret_cast<float*>(smem + (PCS ? P_EOFF : RES ? R_EOFF : (WS ? ws_eoff : (GEO::EPI_OVERLAY ? GEO::STAGE : NST * GEO::STAGE))) + wave * GEO::EPI_WAVE);
+  float* sE = reinterpret_cast<float*>(smem + (WS ? ws_eoff : NST * GEO::STAGE) + wave * GEO::EPI_WAVE);   // (epilogue patches of the 4-wave variants)
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
@@ -520,13 +489,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
         }
       }
     }
-    if constexpr (RES) {
-      if constexpr (!PC) {
-        for (int q = 0; q < NK; ++q) issue_next(0);
-      }
-    } else {
-      issue_next(S0{});
-    }
+    if constexpr (!RES) issue_next(S0{});
   }
   if constexpr (PC && RES) {
     wait_vmcnt<0>();
@@ -674,41 +637,16 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
       }
     } else if constexpr (RES) {
       DDX_TR(5);
-      if constexpr (PC) {
-        const unsigned need = (unsigned)((cunit >> 1) + 1);   // tiles landed in this buffer so far, this unit's included
-        while (flags[cunit & 1] < need) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        DDX_TR(0);
-      } else {
-        wait_vmcnt<0>();
-        DDX_TR(0);
-        __builtin_amdgcn_s_barrier();  // this unit's tile (the first time: weights, scales) landed for every wave; everyone is done reading the other tile buffer
-        DDX_TR(1);
-      }
+      const unsigned need = (unsigned)((cunit >> 1) + 1);   // tiles landed in this buffer so far, this unit's included
+      while (flags[cunit & 1] < need) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      DDX_TR(0);
       const int bufoff = (cunit & 1) * (NK * RA);
-      if constexpr (!PC) {
-        for (int q = 0; q < NK; ++q) issue_next((cunit + 1) & 1);   // the next unit's whole tile
-      }
-      DDX_TR(2);
 #pragma unroll
-      for (int q = 0; q < NK; ++q) {
-        if (!REG && q + 1 == NK && p.epilogue == DDX_EPI_MPSUM) {  // residual rows ride along with the last plane
-#pragma unroll
-          for (int i = 0; i < NF; ++i)
-#pragma unroll
-            for (int j = 0; j < MF; ++j)
-#pragma unroll
-              for (int tt = 0; tt < 2; ++tt) {
-                const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + item_c8(tt) < p.Ng;
-                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
-              }
-        }
-        compute_at(smem + bufoff + q * RA, smem + R_WOFF + q * GEO::B_BYTES);
-      }
-      if constexpr (PC) {   // this wave is done reading the tile buffer (its fragment reads were consumed by the MFMAs above)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flags + 2 + (cunit & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+      for (int q = 0; q < NK; ++q) compute_at(smem + bufoff + q * RA, smem + R_WOFF + q * GEO::B_BYTES);
+      // this wave is done reading the tile buffer (its fragment reads were consumed by the MFMAs above)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flags + 2 + (cunit & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       DDX_TR(3);
     } else {
       // stages come in pairs (nk is even): even stages live in LDS stage 0, odd ones in stage 1
@@ -748,7 +686,6 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
     if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
-    if constexpr (GEO::EPI_OVERLAY) __builtin_amdgcn_s_barrier();  // every wave is done reading stage 1: the patches live there
     if constexpr (!EB && WN == 1 && NF <= 2 && MF <= 2) {
       if (p.epilogue == DDX_EPI_PIXELNORM) {
         // normalize(y, dim = channels) on the accumulators: a lane holds 16 of the 32 channels of pixel (lane & 31) per fragment,
@@ -1050,7 +987,7 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   static_assert(GEO::SMEM <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
   if (WS && (p.Cg / SK > WS_NK_MAX)) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma: weights do not fit LDS");
   static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, ((MF > 2 && NF * MF > 4) ? 0 : 1), EB, WM, MF, WS>;  // (no fragment prefetch only where 128 accumulators leave no registers)
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, 1, EB, WM, MF, WS>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WS ? 80 * 1024 : SMEM_BYTES) != hipSuccess)
@@ -1083,12 +1020,13 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
 }
 
 // Resident mode (NK > 0 in conv_dma_kernel): one workgroup of eight waves per CU, grid 256.
-template <int NF, int NK, int REG, int PC>
-int launch_dma_res_t(const ConvParams& p, hipStream_t s) {
+template <int NF, int NK>
+int launch_dma_res(const ConvParams& p, hipStream_t s) {
+  constexpr int REG = 1, PC = 1;   // register epilogue, one producer wave
   using GEO = DmaGeom<3, 16, NF, 1, 8, 1>;
   constexpr int RA = 340 * GEO::RB;
   const int cs_pieces = p.out_cs ? (p.B * (GEO::BN / 4) + 63) / 64 : 0;
-  const int SMEM_BYTES = 2 * NK * RA + NK * GEO::B_BYTES + (REG ? 0 : GEO::NW * GEO::EPI_WAVE) + 64 + cs_pieces * 1024;
+  const int SMEM_BYTES = 2 * NK * RA + NK * GEO::B_BYTES + 64 + cs_pieces * 1024;
   if (SMEM_BYTES > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma (resident): LDS budget");
   auto kern = conv_dma_kernel<3, 16, NF, 1, 1, 0, 8, 1, 0, NK, REG, PC>;
   static bool attr_done = false;
@@ -1103,18 +1041,13 @@ int launch_dma_res_t(const ConvParams& p, hipStream_t s) {
   dma_trace_report(total);
   return check_launch("conv_dma_res");
 }
-template <int NF, int NK, int REG>
-int launch_dma_res(const ConvParams& p, hipStream_t s) {
-  static const int pc_knob = std::getenv("DDX_DMA_PC") ? atoi(std::getenv("DDX_DMA_PC")) : 1;   // 0: all eight waves issue the tile DMA, one barrier per unit
-  return pc_knob ? launch_dma_res_t<NF, NK, REG, 1>(p, s) : launch_dma_res_t<NF, NK, REG, 0>(p, s);
-}
 
 // Streaming producer / consumer mode (RING > 0 in conv_dma_kernel): 512-pixel units, eight consumer + two producer waves, grid <= 256.
-template <int NF, int REG>
+template <int NF>
 int launch_dma_pcs(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<3, 16, NF, 1, 8, 2>;
-  constexpr int RING = 3;
-  constexpr int SMEM_BYTES = RING * (GEO::A_BYTES + GEO::B_BYTES) + (REG ? 0 : GEO::NW * GEO::EPI_WAVE) + 64 + 4096;
+  constexpr int RING = 3, REG = 1;
+  constexpr int SMEM_BYTES = RING * (GEO::A_BYTES + GEO::B_BYTES) + 64 + 4096;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
   auto kern = conv_dma_kernel<3, 16, NF, 1, 1, 0, 8, 2, 0, 0, REG, 2, RING>;
   static bool attr_done = false;
@@ -1131,26 +1064,22 @@ int launch_dma_pcs(const ConvParams& p, hipStream_t s) {
   return check_launch("conv_dma_pcs");
 }
 
-// which resident variant serves the layer: 0 none, else 1 + (NF - 1) + 2 * (NK == 4) + 4 * REG
+// which resident variant serves the layer: 0 none, else 1 + (NF - 1) + 2 * (NK == 4).  Layers whose epilogue is the register
+// epilogue (plain / clipped / activated store into a channel-blocked output: the conv_res0 type) -- measured -10 ... -25 % there
+// (tools/conv_bench.py --cases dma3 --epi real --path dma16); the residual + twin layers stay on the 4-wave kernels (the resident
+// mode with their LDS-patch epilogue measured 0 ... +7 %: built, measured, removed).  DDX_DMA_RES=0 switches the mode off.
 int dma_res_variant(const ConvParams& p, int TH, int TW) {
-  static const int knob = std::getenv("DDX_DMA_RES") ? atoi(std::getenv("DDX_DMA_RES")) : 1;   // 0: off; 2: patch epilogue wherever it fits (A/B of the register epilogue); 3: both epilogues
-  if (!knob || p.epilogue == DDX_EPI_SILU_BWD || TH != 8 || TW != 32) return 0;
+  static const int knob = std::getenv("DDX_DMA_RES") ? atoi(std::getenv("DDX_DMA_RES")) : 1;
+  if (!knob || p.epilogue != DDX_EPI_STORE || p.out2 || !(p.layout & 4) || p.Ng % 16 || p.Cout % 16 || TH != 8 || TW != 32) return 0;
   const int nk = p.Cg / 16;
   if (p.Cg % 16 || (nk != 2 && nk != 4)) return 0;
   const int bn = p.Ng <= 32 ? 32 : 64, nf = bn / 32;
   const int gn = p.G * ceil_div(p.Ng, bn);
   const long tiles = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW);
   if (256 % (8 * gn) != 0 || tiles * gn < 512) return 0;
-  const bool reg_ok = p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 16 == 0 && p.Cout % 16 == 0;
   const int cs_bytes = p.out_cs ? ((p.B * (bn / 4) + 63) / 64) * 1024 : 0;
-  const int base = 2 * nk * 340 * 32 + nk * 9 * bn * 32 + 64 + cs_bytes;
-  const bool patch_fits = base + 8 * DmaGeom<3, 16, 1, 1, 8, 1>::EPI_WAVE <= 160 * 1024;
-  const bool reg = reg_ok && (knob != 2 || !patch_fits);
-  // measured (same command): -10 ... -25 % on the conv_res0-type layers (register epilogue), 0 ... +7 % on the residual + twin layers
-  // (patch epilogue) -> automatic choice only for the former; DDX_DMA_RES=2 / 3 take the patch epilogue wherever it fits
-  if (!reg && (knob == 1 || !patch_fits)) return 0;
-  if (reg && base > 160 * 1024) return 0;
-  return 1 + (nf - 1) + 2 * (nk == 4 ? 1 : 0) + 4 * (reg ? 1 : 0);
+  if (2 * nk * 340 * 32 + nk * 9 * bn * 32 + 64 + cs_bytes > 160 * 1024) return 0;
+  return 1 + (nf - 1) + 2 * (nk == 4 ? 1 : 0);
 }
 
 // 1x1 layers with >= 192 output channels per group run as 256 x 256 GEMM tiles (8 waves) when that still leaves
@@ -1238,63 +1167,34 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     return narrow ? launch_dma_t<1, 32, 1, 1, 1>(p, s) : launch_dma_t<1, 32, 2, 1, 1>(p, s);
   }
   if (ksize == 3) {
-    // 512-pixel units (4 waves x 4 pixel fragments): twice the matrix work per DMA round trip of a K-stage and the weight
-    // slices staged once per 512 pixels.  With 32-channel tiles (4 fragments per wave, no register pressure) this is the
-    // candidate for layers with few K-stages per unit -- measured 10-40 % slower than the 256-pixel units for both channel
-    // widths, kept behind the knob.
-    static const int big_knob = std::getenv("DDX_DMA_BIG") ? atoi(std::getenv("DDX_DMA_BIG")) : 0;  // experiment knob: 2 = wherever it fits
-    using BIG = DmaGeom<3, 16, 2, 1, 4, 4>;
-    int bth = 0, btw = 0; double butil = 0;
-    if (big_knob && !p.layout && dma_tile(p, 3, &bth, &btw, &butil, BIG::BM, BIG::AROWS)) {
-      const int bn = p.Ng <= 32 ? 32 : 64;
-      const long units = (long)p.B * ceil_div(p.H, bth) * ceil_div(p.W, btw) * p.G * ceil_div(p.Ng, bn);
-      if (big_knob == 2 && units > 0) {   // (no automatic rule: both channel widths measured slower than the 256-pixel units)
-        p.TH = bth; p.TW = btw;
-        p.tiles_h = ceil_div(p.H, bth); p.tiles_w = ceil_div(p.W, btw);
-        p.arows_alloc = (bth + 2) * (btw + 2);
-        p.inv_TWP = 1.0f / (float)(btw + 2);
-        return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 4>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 4>(p, s);
-      }
-    }
-  }
-  // streaming producer / consumer mode: 512-pixel units wherever they fill the chip (DDX_DMA_PCS: 0 off, 1 = layers the resident
-  // mode does not take, 2 = before the resident mode)
-  static const int pcs_knob = std::getenv("DDX_DMA_PCS") ? atoi(std::getenv("DDX_DMA_PCS")) : 1;
-  auto try_pcs = [&](int* rc) -> bool {
-    using GEO = DmaGeom<3, 16, 2, 1, 8, 2>;
-    int th = 0, tw = 0; double ut = 0;
-    if (ksize != 3 || !pcs_knob || p.epilogue == DDX_EPI_SILU_BWD || p.Cg % 16 || !dma_tile(p, 3, &th, &tw, &ut, GEO::BM, GEO::AROWS) || ut < 0.6) return false;
-    const int bn = p.Ng <= 32 ? 32 : 64;
-    const long units = (long)p.B * ceil_div(p.H, th) * ceil_div(p.W, tw) * p.G * ceil_div(p.Ng, bn);
-    if (units < 384) return false;
-    ConvParams q = p;
-    q.TH = th; q.TW = tw;
-    q.tiles_h = ceil_div(p.H, th); q.tiles_w = ceil_div(p.W, tw);
-    q.arows_alloc = (th + 2) * (tw + 2);
-    q.inv_TWP = 1.0f / (float)(tw + 2);
-    const bool reg = p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0;
-    // measured (tools/conv_bench.py --cases dma3 --epi real --path dma16, B = 4): -5 ... -11 % on the conv_res0-type layers of
-    // levels 0 / 1 (register epilogue), +6 ... +18 % on the residual + twin layers (patch epilogue at 168 registers), slower at level 2
-    // (384 units for 256 workgroups) -> automatic choice only for the former; DDX_DMA_PCS=2 takes it wherever it runs
-    if (pcs_knob == 1 && (!reg || units < 640)) return false;
-    *rc = bn == 32 ? (reg ? launch_dma_pcs<1, 1>(q, s) : launch_dma_pcs<1, 0>(q, s)) : (reg ? launch_dma_pcs<2, 1>(q, s) : launch_dma_pcs<2, 0>(q, s));
-    return true;
-  };
-  int rc_pcs = 0;
-  if (pcs_knob == 2 && try_pcs(&rc_pcs)) return rc_pcs;
-  if (ksize == 3) {
     switch (dma_res_variant(p, TH, TW)) {
-      case 1: return launch_dma_res<1, 2, 0>(p, s);
-      case 2: return launch_dma_res<2, 2, 0>(p, s);
-      case 3: return launch_dma_res<1, 4, 0>(p, s);
-      case 5: return launch_dma_res<1, 2, 1>(p, s);
-      case 6: return launch_dma_res<2, 2, 1>(p, s);
-      case 7: return launch_dma_res<1, 4, 1>(p, s);
-      case 8: return launch_dma_res<2, 4, 1>(p, s);
+      case 1: return launch_dma_res<1, 2>(p, s);
+      case 2: return launch_dma_res<2, 2>(p, s);
+      case 3: return launch_dma_res<1, 4>(p, s);
+      case 4: return launch_dma_res<2, 4>(p, s);
       default: break;
     }
   }
-  if (pcs_knob == 1 && try_pcs(&rc_pcs)) return rc_pcs;
+  // streaming producer / consumer mode (512-pixel units) for the conv_res0-type layers with more than 64 channels per group and
+  // >= 640 units: measured -5 ... -11 % on those (same command); +6 ... +18 % with the LDS-patch epilogue of the residual + twin
+  // layers and slower at level 2 (384 units for 256 workgroups): not built for them.  DDX_DMA_PCS=0 switches the mode off.
+  static const int pcs_knob = std::getenv("DDX_DMA_PCS") ? atoi(std::getenv("DDX_DMA_PCS")) : 1;
+  if (ksize == 3 && pcs_knob && p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0 && p.Cg % 16 == 0) {
+    using GEO = DmaGeom<3, 16, 2, 1, 8, 2>;
+    int th = 0, tw = 0; double ut = 0;
+    if (dma_tile(p, 3, &th, &tw, &ut, GEO::BM, GEO::AROWS) && ut >= 0.6) {
+      const int bn = p.Ng <= 32 ? 32 : 64;
+      const long units = (long)p.B * ceil_div(p.H, th) * ceil_div(p.W, tw) * p.G * ceil_div(p.Ng, bn);
+      if (units >= 640) {
+        ConvParams q = p;
+        q.TH = th; q.TW = tw;
+        q.tiles_h = ceil_div(p.H, th); q.tiles_w = ceil_div(p.W, tw);
+        q.arows_alloc = (th + 2) * (tw + 2);
+        q.inv_TWP = 1.0f / (float)(tw + 2);
+        return bn == 32 ? launch_dma_pcs<1>(q, s) : launch_dma_pcs<2>(q, s);
+      }
+    }
+  }
   // stationary weights where all K-stages of a channel tile fit beside two activation stages (Cg <= 32 with 64-channel tiles,
   // Cg <= 64 with 32-channel tiles): -7 ... -15 % on those layers.  DDX_DMA_WS=0 off, 2 = also 32-channel tiles for
   // Ng = 64 layers with Cg = 64 (experiment)

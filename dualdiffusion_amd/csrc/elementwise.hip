@@ -243,6 +243,9 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const ddx_linear_job*
   // 16 lanes per output row (16 rows per workgroup), 16-byte weight loads when K allows
   constexpr int EV = 16 / (int)sizeof(TW_);
   const ddx_linear_job jb = jobs[blockIdx.y];
+  // the grid is sized for the widest job of the batch: workgroups past this job's rows leave at once (they used to stream row 0
+  // through the whole K loop -- most of the batched emb_linear launch's 56 us)
+  if (blockIdx.x * 16 >= jb.O) return;
   const int sub = threadIdx.x & 15;
   const int o = blockIdx.x * 16 + (threadIdx.x >> 4);
   const bool active = o < jb.O;
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const ddx_linear_job*
     for (int m = 0; m < MB; ++m) acc[m] = 0.f;
     float ss = 0.f;
     if (vec) {
+#pragma unroll 3
       for (int k = sub * EV; k < jb.K; k += 16 * EV) {
         Vec16<TW_> wv;
         wv.v = *reinterpret_cast<const decltype(wv.v)*>(wr + k);

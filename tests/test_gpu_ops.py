@@ -754,11 +754,11 @@ print("WORST", worst)
 """
 
 
-@pytest.mark.parametrize("knob", ["DDX_DMA_BIG=2", "DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_RES=2", "DDX_DMA_RES=3", "DDX_DMA_PC=0", "DDX_DMA_PCS=0", "DDX_DMA_PCS=2"])
+@pytest.mark.parametrize("knob", ["DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_PCS=0", "DDX_DMA_WS=0"])
 def test_conv_dma_experiment_knobs_stay_correct(knob):
-    """The LDS-DMA variants behind environment knobs (512-pixel units, XCD unit order, resident mode off / with the patch epilogue;
-    read once per process, so each runs in its own interpreter) against the register-staged kernel on grouped / two-source /
-    residual layers."""
+    """The LDS-DMA kernel with its mode switches flipped (XCD unit order everywhere, resident / streaming producer-consumer /
+    stationary-weights modes off; read once per process, so each runs in its own interpreter) against the register-staged kernel on
+    grouped / two-source / residual layers."""
     import os
     import subprocess
     import sys
