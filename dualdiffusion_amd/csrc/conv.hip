@@ -147,6 +147,8 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   if ((d.prologue & DDX_PRO_SCALE) && !d.chan_scale) return set_error(DDX_ERR_ARG, "conv: chan_scale missing");
   if (d.epilogue == DDX_EPI_MPSUM && !d.residual) return set_error(DDX_ERR_ARG, "conv: residual missing");
   if (d.resample == DDX_RESAMPLE_UP && ((d.H | d.W) & 1)) return set_error(DDX_ERR_ARG, "conv: upsampled size must be even");
+  if (d.residual_up && (d.epilogue != DDX_EPI_MPSUM || ((d.H | d.W) & 1) || (d.residual_up & ~1)))
+    return set_error(DDX_ERR_ARG, "conv: residual_up needs the mp_sum epilogue and an even output size");
   if (d.dtype != DDX_F32 && d.dtype != DDX_BF16) return set_error(DDX_ERR_ARG, "conv: dtype");
 
   ConvParams p{};
@@ -162,6 +164,7 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.scale0 = d.scale0; p.scale1 = d.scale1;
   const float t = d.res_t, nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
   p.res_a = (1.f - t) / nrm; p.res_b = t / nrm;
+  p.res_up = d.residual_up;
   p.clip = d.clip;
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   p.src0_alt = d.src0_alt; p.out2_cs = d.out2_chan_scale; p.out2_linear = d.out2_linear;
@@ -225,7 +228,7 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
     if (query) return 4;
     if (d.layout) return set_error(DDX_ERR_UNSUPPORTED, "conv: channel-blocked tensors need the LDS-DMA kernel");
     const double flops_sm = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
-    const double bytes_sm = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) + (double)p.Cout * p.Cg * ks * ks);
+    const double bytes_sm = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? (d.residual_up ? 1.25 : 2.0) : 1.0) + (double)p.Cout * p.Cg * ks * ks);
     return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_sm(p, ks, s); }, stream, ks == 3 ? "conv3x3_sm" : "conv1x1_sm", flops_sm, bytes_sm);
   }
   if (d.force_direct == 4) return set_error(DDX_ERR_UNSUPPORTED, "conv: the small-M kernel needs weights prepared with CK = 16");
@@ -240,7 +243,7 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
   if (d.layout && (!dma || p.epilogue == DDX_EPI_PIXELNORM)) return set_error(DDX_ERR_UNSUPPORTED, "conv: channel-blocked tensors need the LDS-DMA kernel (ddx_mpconv2d_path)");
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double es = (double)dtype_size(dt);
-  const double bytes = es * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? 2.0 : 1.0) +
+  const double bytes = es * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.residual ? (d.residual_up ? 1.25 : 2.0) : 1.0) +
                              (double)p.Cout * p.Cg * ks * ks);
   return dispatch([p, ks, dt, mfma, dma](hipStream_t s) -> int {
     if (dma) return launch_conv_dma(p, ks, s);
@@ -251,7 +254,7 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
 // ---- data-gradient conv fused with the backward of the producer-side activation (LDS-DMA kernel only)
 static int dgrad_act_fill(const ddx_dgrad_act_desc& d, ConvParams* pp) {
   ddx_conv_desc c = d.conv;
-  c.epilogue = DDX_EPI_STORE; c.residual = nullptr; c.out2 = nullptr; c.out_act = 0; c.out_scale = nullptr;
+  c.epilogue = DDX_EPI_STORE; c.residual = nullptr; c.residual_up = 0; c.out2 = nullptr; c.out_act = 0; c.out_scale = nullptr;
   ConvParams p{};
   if (int rc = conv_fill(c, &p)) return rc;
   if (!d.y0 || (d.split > 0 && (!d.y1 || !d.out1)) || d.split < 0 || d.split >= d.conv.Cout) return set_error(DDX_ERR_ARG, "dgrad_act: bad parts");

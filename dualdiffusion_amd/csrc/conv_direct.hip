@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p, in
         acc += x * to_f32<T>(wp[wp_index(g, n, tap, c, p.nchunk, taps, p.NgP, p.CK)]);
       }
     }
-    if (p.epilogue == DDX_EPI_MPSUM) acc = to_f32<T>(reinterpret_cast<const T*>(p.res)[idx]) * p.res_a + acc * p.res_b;
+    if (p.epilogue == DDX_EPI_MPSUM) {
+      const size_t ridx = p.res_up ? (((size_t)bo * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Cout + o : idx;
+      acc = to_f32<T>(reinterpret_cast<const T*>(p.res)[ridx]) * p.res_a + acc * p.res_b;
+    }
     if (p.clip > 0.f) acc = fminf(fmaxf(acc, -p.clip), p.clip);
     if (p.out2) {  // twin: with a channel scale and a raw main output the scale belongs to the twin (training forward)
       const float tc = (p.out_cs && !p.out_act) ? p.out_cs[(size_t)bo * p.Cout + o] : 1.0f;

@@ -596,6 +596,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     auto item_c8 = [&](int tt) { return map16 ? (2 * tt + (lane & 1)) * 8 : (lane & 3) * 8; };
     long eoff[MF][2];
     [[maybe_unused]] int epx[C16_OUT ? MF : 1][2];   // pixel index of the item (channel-blocked stores)
+    [[maybe_unused]] int rpx[EB ? 1 : MF][2];        // res_up: the item's pixel in the half-size residual
     auto epilogue_offsets = [&]() {
 #pragma unroll
       for (int j = 0; j < MF; ++j)
@@ -610,7 +611,14 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
           eoff[j][tt] = ok ? (long)((size_t)pix * ld_u + (size_t)t.g * p.Ng + t.n0 - cofs + wn * (NF * 32) + item_c8(tt)) : -1;
           if constexpr (EB) epix[j][tt] = ok ? pix : -1;
           if constexpr (C16_OUT) epx[j][tt] = pix;
+          if constexpr (!EB) rpx[j][tt] = (t.b * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1);
         }
+    };
+    // element offset of the item's residual vector for channel column i (res_up: gathered from the half-size tensor)
+    auto res_off = [&](int i, int j, int tt) {
+      if constexpr (!EB)
+        if (p.res_up) return (long)rpx[j][tt] * p.Cout + (long)(t.g * p.Ng + t.n0 + wn * (NF * 32) + item_c8(tt) + i * 32);
+      return eoff[j][tt] + i * 32;
     };
     // element offset of channel c of the item's pixel in a channel-blocked [B][Cout/16][H][W][16] tensor
     [[maybe_unused]] const long c16_img = (long)t.b * (p.Cout / 16 - 1) * p.H * p.W * 16;
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 #pragma unroll
               for (int tt = 0; tt < 2; ++tt) {
                 const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + item_c8(tt) < p.Ng;
-                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? eoff[j][tt] + i * 32 : 0));
+                rres[i][j][tt] = *reinterpret_cast<const u32x4*>(res_u + (ok ? res_off(i, j, tt) : 0));
               }
         }
         if constexpr (WS) compute_at(smem + GEO::A_BYTES, smem + ws_boff + (q + 1) * GEO::B_BYTES);
@@ -779,7 +787,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt) {
             const bool ok = eoff[j][tt] >= 0 && t.n0 + (wn * NF + i) * 32 + item_c8(tt) < p.Ng;
-            rres[rslot(i)][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? eoff[j][tt] + i * 32 : 0));
+            rres[rslot(i)][j][tt] = *reinterpret_cast<const u32x4*>(res + (ok ? res_off(i, j, tt) : 0));
           }
       }
 #pragma unroll

@@ -391,10 +391,10 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     const int n = n0 + c4 * 4;
     const bool ok = idx < BM * G4 && ml < MT && h < p.H && w < p.W && n < p.Ng;
     eoff[it] = ok ? (long)((((size_t)b * p.H + h) * p.W + w) * p.Cout + (size_t)g * p.Ng + n) : -1;
-  }
-  if (p.epilogue == DDX_EPI_MPSUM) {
-#pragma unroll
-    for (int it = 0; it < EI; ++it) rres[it] = *reinterpret_cast<const V4*>(res + (eoff[it] < 0 ? 0 : eoff[it]));
+    if (p.epilogue == DDX_EPI_MPSUM) {  // (residual loads issued here: with res_up the address is the half-size pixel's)
+      const long roff = p.res_up ? (long)((((size_t)b * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Cout + (size_t)g * p.Ng + n) : eoff[it];
+      rres[it] = *reinterpret_cast<const V4*>(res + (ok ? roff : 0));
+    }
   }
 #pragma unroll
   for (int it = 0; it < EI; ++it) {

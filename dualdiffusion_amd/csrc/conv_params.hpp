@@ -20,6 +20,7 @@ struct ConvParams {
   int pro_rows;       // > 0: the prologue only applies to output channels below it (merged attn_qk | attn_v conv: qk reads x * c_qk, v reads x)
   float scale0, scale1;
   float res_a, res_b;  // out = res * res_a + acc * res_b
+  int res_up;          // the residual is [B][H/2][W/2][Cout], read nearest-upsampled (ddx_conv_desc::residual_up)
   float clip;
   const float* out_cs;  // producer-side activation scale [B][Cout] (or null)
   void* out2;           // activated twin of the output (or null)

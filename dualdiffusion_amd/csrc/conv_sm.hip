@@ -59,6 +59,7 @@ __device__ __forceinline__ void sm_epilogue(const ConvParams& p, const SmArgs& a
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
   long eoff[EI];
+  [[maybe_unused]] long roff[EI];
   int ebc[EI];
   bf16x4 rres[EI];
   f32x4 ecs[EI], ecs2[EI];
@@ -70,11 +71,15 @@ __device__ __forceinline__ void sm_epilogue(const ConvParams& p, const SmArgs& a
     const int pix = (idx < BM * G4 && n < p.Ng) ? pix_of(ml) : -1;
     eoff[it] = pix >= 0 ? (long)pix * p.Cout + (size_t)g * p.Ng + n : -1;
     const int b = fdiv(max(pix, 0), a.inv_HW);
+    if (p.res_up) {   // residual at half size: pixel (b, h, w) reads (b, h / 2, w / 2)
+      const int hw = max(pix, 0) - b * p.H * p.W, h = fdiv(hw, a.inv_W), w = hw - h * p.W;
+      roff[it] = pix >= 0 ? (long)((b * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Cout + (size_t)g * p.Ng + n : 0;
+    }
     ebc[it] = b * p.Cout + min(g * p.Ng + n, p.Cout - 4);
   }
   if (p.epilogue == DDX_EPI_MPSUM) {
 #pragma unroll
-    for (int it = 0; it < EI; ++it) rres[it] = *reinterpret_cast<const bf16x4*>(res + (eoff[it] < 0 ? 0 : eoff[it]));
+    for (int it = 0; it < EI; ++it) rres[it] = *reinterpret_cast<const bf16x4*>(res + (p.res_up ? roff[it] : (eoff[it] < 0 ? 0 : eoff[it])));
   }
   if (p.out_cs) {
 #pragma unroll

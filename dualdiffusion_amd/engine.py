@@ -49,6 +49,10 @@ AUTOTUNE = os.environ.get("DDX_AUTOTUNE", "0") != "0"
 C16 = os.environ.get("DDX_C16", "1") != "0"
 SM_MAX_PIXELS = int(os.environ.get("DDX_SM_MAX_PIXELS", "512"))
 SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
+# The residual branch of an up block is conv_skip(upsample(x)): a 1x1 conv commutes with the nearest resample exactly, so the
+# skip conv runs at the SOURCE size (a quarter of the matrix work and output bytes) and conv_res1 gathers the half-size
+# residual in its epilogue (ddx_conv_desc::residual_up).  Inference plans; DDX_RES_UP=0 restores the full-size skip conv.
+RES_UP = os.environ.get("DDX_RES_UP", "1") != "0"
 
 
 class PlanBuilder:
@@ -209,7 +213,18 @@ class PlanBuilder:
             else:   # no twins available: fused prologue on the raw inputs
                 S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU,
                                      out_act=True, out_scale=c_emb, out=y0))
-            if blk.conv_skip is not None:
+            res_up = False
+            if RES_UP and not self.training and rs == RESAMPLE_UP and src1 is None:
+                # up block: residual at the source size, gathered by conv_res1 (see RES_UP above)
+                res_up = True
+                if blk.conv_skip is not None:
+                    sh, sw = src0.shape[1], src0.shape[2]
+                    pw_skip = self.prep(blk.conv_skip, npix=self.B * sh * sw)
+                    sk = self.act(sh, sw, cout)
+                    self.steps.insert(len(self.steps) - 1, lambda: ops.conv2d(src0, pw_skip, out=sk))
+                else:
+                    sk = src0
+            elif blk.conv_skip is not None:
                 # the skip conv only depends on the block input: it runs on the plan's side lane, next to conv_res0
                 pw_skip = self.prep(blk.conv_skip, npix=npix, in_split=src0.shape[3] if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
                 sk = self.act(h, w, cout)
@@ -227,7 +242,7 @@ class PlanBuilder:
             else:
                 assert src1 is None, "a concatenated input always changes the channel count, i.e. has a skip conv"
                 sk = src0
-            kw1 = dict(residual=sk, res_t=res_balance, clip=last_clip, out=xo, **tw_res1)
+            kw1 = dict(residual=sk, res_t=res_balance, clip=last_clip, out=xo, residual_up=res_up, **tw_res1)
             self._block_layouts(act0, act1, act0 if kw0 is not None else None, pw_res0, kw0, y0, pw_res1, kw1, twin if not attn else None)
             S(lambda: ops.conv2d(y0, pw_res1, **kw1))
         if not attn:

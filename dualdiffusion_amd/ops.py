@@ -174,7 +174,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            clip: float = 0.0, out: Optional[torch.Tensor] = None, force_direct: bool = False, out_act: bool = False,
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
            path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False, pixelnorm_eps: float = 0.0,
-           out2_chan_scale: Optional[torch.Tensor] = None, src0_alt: Optional[torch.Tensor] = None, query: bool = False):
+           out2_chan_scale: Optional[torch.Tensor] = None, src0_alt: Optional[torch.Tensor] = None, query: bool = False,
+           residual_up: bool = False):
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | "sm" (small-M weight-streaming kernel; weights prepared with CK = 16, which also selects it automatically)
@@ -186,6 +187,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     pixelnorm_eps > 0: the stored output is normalize(y, dim=channels) (DDX_EPI_PIXELNORM; LDS-DMA kernel, one group, Cout <= 64).
     Small-M kernel only: out2_chan_scale [B, Cout] makes out2 the LINEAR twin y_final * out2_chan_scale (operand of attn_qk);
     src0_alt (with prologue_rows > 0): output channels below prologue_rows read src0_alt instead of src0.
+    residual_up: `residual` is [B, H/2, W/2, Cout] and enters mp_sum nearest-upsampled (skip conv of an up block run at the source size).
     Tensors marked with `mark_c16` are channel-blocked [B, C/16, H, W, 16] (same shape attribute, same bytes; 3x3 LDS-DMA kernel only).
     query=True: no launch, returns the kernel code the library would choose (2 register-staged, 3 LDS-DMA, 4 small-M, 1 scalar)."""
     B, sH, sW, C0 = src0.shape
@@ -202,7 +204,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    force_direct=1 if force_direct else (path if isinstance(path, int) else _PATH_CODE[path]),
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=(L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO) | (L.PAD_SWAP_SRC1 if swap_src1 else 0) | (L.PAD_SWAP_PAIRED if swap_paired else 0),
-                   prologue_rows=prologue_rows, out2_linear=int(out2_chan_scale is not None), out2_chan_scale=ptr(out2_chan_scale), src0_alt=ptr(src0_alt))
+                   prologue_rows=prologue_rows, out2_linear=int(out2_chan_scale is not None), out2_chan_scale=ptr(out2_chan_scale), src0_alt=ptr(src0_alt),
+                   residual_up=int(residual_up))
     if query:
         return int(lib().ddx_mpconv2d_path(C.byref(d)))
     d.layout = ((L.LAYOUT_SRC0_C16 if is_c16(src0) else 0) | (L.LAYOUT_SRC1_C16 if is_c16(src1) else 0) |

@@ -159,6 +159,11 @@ typedef struct {
   int32_t layout;
   const float* out2_chan_scale;   /* [B][Cout] fp32 or NULL */
   const void* src0_alt;           /* NHWC like src0, or NULL */
+  /* 1: `residual` is [B][H/2][W/2][Cout] and enters mp_sum nearest-neighbour 2x upsampled (pixel (h, w) reads (h/2, w/2); H, W even).
+   * The residual branch of an up block is conv_skip(resample(x)) (unet_edm2_b4.py:110-117); a 1x1 conv commutes with the nearest
+   * resample exactly (every output pixel is the same dot product), so the host runs the skip conv at the SOURCE size -- a quarter
+   * of the matrix work and of the output bytes -- and the consumer gathers: the upsampled tensor never exists. */
+  int32_t residual_up;
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);

@@ -946,3 +946,38 @@ def test_conv_sm(name):
     # what the small-M kernels do not serve is refused, not mis-computed
     with pytest.raises(Exception):
         ops.conv2d(to_nhwc(a, dtype), pw, prologue=L.PRO_SILU, **common)
+
+
+@pytest.mark.parametrize("path,dtype,shape", [
+    ("direct", torch.float32, (2, 6, 10, 64, 32, 2, 3)),
+    ("mfma", torch.float32, (2, 6, 10, 64, 32, 2, 3)),
+    ("mfma", torch.bfloat16, (2, 8, 44, 128, 64, 2, 3)),
+    ("dma", torch.bfloat16, (2, 16, 96, 128, 64, 2, 3)),      # 4-wave LDS-DMA kernel: residual rows ride along with the last matrix phase
+    ("dma", torch.bfloat16, (2, 64, 256, 256, 256, 1, 1)),    # 256-channel 1x1 tiles: residual loaded per channel column
+    ("sm", torch.bfloat16, (2, 4, 86, 256, 128, 2, 3)),
+    ("sm", torch.bfloat16, (2, 2, 42, 256, 128, 1, 1)),
+])
+def test_conv_residual_up(path, dtype, shape):
+    """residual_up: the residual is [B, H/2, W/2, Cout] and enters mp_sum nearest-upsampled (skip branch of an up block run at the
+    source size, unet_edm2_b4.py:110-117) -- on every conv kernel, against mp_sum(upsample(residual), conv) of the oracle."""
+    ops = _ops()
+    B, H, W, Cin, Cout, groups, ks = shape
+    g = torch.Generator().manual_seed(77 + Cin)
+    x = _round(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin // groups, ks, ks, generator=g)
+    res = _round(torch.randn(B, Cout, H // 2, W // 2, generator=g), dtype)
+    wp_ref = O.prepared_weight(w)
+    if dtype == torch.bfloat16:
+        wp_ref = _round(wp_ref, dtype)
+    y = torch.nn.functional.conv2d(x, wp_ref, padding=ks // 2, groups=groups)
+    ref = O.sum_mp(O.resample2x(res, "up"), y, 0.3).clamp(-2.0, 2.0)
+    pw = ops.wprep(w.cuda(), groups, dtype, CK=16 if path == "sm" else None)
+    out = ops.conv2d(to_nhwc(x, dtype), pw, residual=to_nhwc(res, dtype), res_t=0.3, clip=2.0, residual_up=True, path=path)
+    torch.cuda.synchronize()
+    e = rel_l2(to_nchw(out), ref)
+    assert e < TOL[dtype], (path, e)
+    # same numbers as with the materialised upsampled residual, bit for bit (the gather only changes addresses)
+    out_full = ops.conv2d(to_nhwc(x, dtype), pw, residual=to_nhwc(O.resample2x(res, "up"), dtype), res_t=0.3, clip=2.0, path=path)
+    assert torch.equal(out, out_full)
+    with pytest.raises(Exception):
+        ops.conv2d(to_nhwc(x, dtype), pw, residual_up=True, path=path)     # no residual: argument error

@@ -221,3 +221,21 @@ def test_unet_odd_batches_and_ragged_shapes():
         e = rel_l2(outs[(torch.bfloat16, B, H, W)], outs[(torch.float32, B, H, W)])
         print(f"B={B} (4,{H},{W}): bf16 vs fp32 {e:.3e}")
         assert e < 3e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1.5e-2)], ids=["f32", "bf16"])
+def test_up_block_skip_conv_at_source_size_matches_full_size(dtype, tol, monkeypatch):
+    """engine.RES_UP: the 1x1 skip conv of an up block runs before the resample and conv_res1 gathers the half-size residual.
+    Same dot products per pixel as conv_skip(upsample(x)): fp32 differs by summation order of a different kernel choice at most."""
+    from dualdiffusion_amd import engine
+    outs = []
+    for flag in (True, False):
+        monkeypatch.setattr(engine, "RES_UP", flag)
+        unet, t, m, cfg, sd = _build("unet_small", dtype)
+        fmt = _Fmt(*m["freq_range"])
+        with torch.no_grad():
+            emb = unet.get_embeddings(t["clap"], t["mask"].bool())
+            outs.append(unet(t["x_in"].cuda(), t["sigma"].cuda(), fmt, emb).float())
+    e = rel_l2(outs[0], outs[1])
+    print(f"RES_UP on vs off: {e:.3e}")
+    assert e < tol
