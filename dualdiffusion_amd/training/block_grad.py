@@ -23,7 +23,7 @@ from typing import Optional
 
 import torch
 
-from .. import ops
+from .. import engine, ops
 from .._lib import PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_DOWN_BWD, RESAMPLE_UP, RESAMPLE_UP_BWD
 from .attention_grad import attention_backward
 
@@ -81,6 +81,7 @@ class BlockTape:
     a01: Optional[torch.Tensor] = None
     a1: Optional[torch.Tensor] = None
     out_twin: Optional[torch.Tensor] = None
+    up_skip: bool = False             # the skip branch ran at the source size (up block)
 
 
 def _prep(w: BlockWeightsT, key: str, weight: torch.Tensor, groups: int, dt, **kw):
@@ -160,6 +161,7 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
         ops.linear_small(table, 1, Cmid, emb, B, w.emb_linear.dtype)
     pw = {"res0": _prep(w, "conv_res0", w.conv_res0, G, dt), "res1": _prep(w, "conv_res1", w.conv_res1, G, dt)}
     xs = x1 = a01 = None
+    up_skip = False
     if flavor == "enc":
         assert src1 is None and s0 == 1.0
         if w.conv_skip is not None:
@@ -175,12 +177,15 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
         a00 = _resample(act0, resample) if act0 is not None else ops.silu_scale_fwd(src0, None, s0)
         if src1 is not None:
             a01 = _resample(act1, resample) if act1 is not None else ops.silu_scale_fwd(src1, None, s1)
+        # up block: the 1x1 skip conv commutes with the nearest resample, so it runs at the source size and conv_res1 gathers the
+        # half-size residual (engine.RES_UP; ddx_conv_desc::residual_up) -- forward, data and weight gradient at a quarter of the pixels
+        up_skip = engine.RES_UP and resample == "up" and src1 is None
         if w.conv_skip is not None:
             pw["skip"] = _prep(w, "conv_skip", w.conv_skip, 1, dt, in_split=C0 if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
-            sk = ops.conv2d(src0, pw["skip"], src1=src1)
+            sk = ops.conv2d(in0, pw["skip"]) if up_skip else ops.conv2d(src0, pw["skip"], src1=src1)
         else:
             assert src1 is None and s0 == 1.0
-            sk = src0
+            sk = in0 if up_skip else src0
     y0 = torch.empty(src0.shape[:3] + (Cmid,), dtype=dt, device=in0.device)
     a1 = torch.empty_like(y0)
     ops.conv2d(a00, pw["res0"], src1=a01, out=y0, out_scale=c, out2=a1)      # y0 and mp_silu(y0 * c)
@@ -190,9 +195,9 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     if twin_scale is not None:
         out_twin = torch.empty(src0.shape[:3] + (w.conv_res1.shape[0],), dtype=dt, device=in0.device)
         tw = dict(out2=out_twin, out2_scale=twin_scale)
-    out = ops.conv2d(a1, pw["res1"], residual=sk, res_t=res_t, clip=0.0 if has_attn else clip, **({} if has_attn else tw))
+    out = ops.conv2d(a1, pw["res1"], residual=sk, res_t=res_t, clip=0.0 if has_attn else clip, residual_up=up_skip, **({} if has_attn else tw))
     tape = BlockTape(w, flavor, resample, in0, in1, src0, src1, s0, s1, emb, c, xs, x1, y0, out, res_t, 0.0 if has_attn else clip, pw)
-    tape.a00, tape.a01, tape.a1, tape.out_twin = a00, a01, a1, out_twin
+    tape.a00, tape.a01, tape.a1, tape.out_twin, tape.up_skip = a00, a01, a1, out_twin, up_skip
     if not has_attn:
         return out, tape
     # ---- self-attention: qk = attn_qk(x * c_qk), v = attn_v(x), y = attn_proj(mp_silu(attention * c_v)), x = mp_sum(x, y, t)
@@ -271,6 +276,17 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     else:
         a00, a01 = t.a00, t.a01
         g["dw_conv_res0"] = _wgrad(w, "conv_res0", t.pw["res0"], dy0, a00, G, 3, x1=a01)
+        if t.up_skip:
+            # the skip branch ran before the resample: its gradient is pooled (2x2 sums) first, then everything is half-size
+            dsk = _resample_bwd(dsk, "up")
+            if w.conv_skip is not None:
+                g["dw_conv_skip"] = _wgrad(w, "conv_skip", t.pw["skip"], dsk, t.in0, 1, 1)
+                dxs = ops.conv2d(dsk, _prep_t(w, "conv_skip", w.conv_skip, 1, dt))
+            else:
+                dxs = dsk
+            dsrc0, _ = ops.conv2d_dgrad_act(dy0, _prep_t(w, "conv_res0", w.conv_res0, G, dt), t.src0, scale0=t.s0)
+            g["din0"], g["din1"] = ops.add3(_resample_bwd(dsrc0, "up"), dxs), None
+            return g
         if w.conv_skip is not None:
             g["dw_conv_skip"] = _wgrad(w, "conv_skip", t.pw["skip"], dsk, t.src0, 1, 1, x1=t.src1)
             dxs = ops.conv2d(dsk, _prep_t(w, "conv_skip", w.conv_skip, 1, dt, in_split=C0 if C1 else 0, in_scale0=t.s0, in_scale1=t.s1))

@@ -18,6 +18,7 @@ CASES = {
     "dec_cat_skip": ("dec", "keep", 128, 64, 128, 2, True),    # (128 + 64) / 2 = 96 channels per group: the source split is tile aligned
     "dec_plain": ("dec", "keep", 128, 0, 128, 8, False),
     "dec_up": ("dec", "up", 128, 0, 128, 8, False),
+    "dec_up_skip": ("dec", "up", 128, 0, 128, 8, True),        # up block with a skip conv: the skip branch runs at the source size
     "enc_down_skip": ("enc", "down", 64, 0, 128, 8, True),
     "enc_plain": ("enc", "keep", 128, 0, 128, 8, False),
     "dec_attn": ("dec", "keep", 128, 0, 128, 8, False),

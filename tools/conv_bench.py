@@ -97,6 +97,11 @@ CASES = {
     "L2_up_skip_raw": (4, 8, 172, 1024, 0, 1024, 1, 1, 1, L.PRO_NONE, False),
     "L2_skip_cat1_raw": (4, 8, 172, 768, 768, 768, 1, 1, 0, L.PRO_NONE, False),
     "L2_skip_cat2_raw": (4, 8, 172, 768, 512, 768, 1, 1, 0, L.PRO_NONE, False),
+    # 1x1 shapes whose unit count divides the 256 CUs exactly (256 x 256 tiles): what the kernel does without tile quantisation
+    "Q0_skip_256_raw": (4, 32, 512, 256, 0, 256, 1, 1, 0, L.PRO_NONE, False),
+    "Q0_skip_cat_raw": (4, 32, 512, 512, 256, 256, 1, 1, 0, L.PRO_NONE, False),
+    "Q1_skip_512_raw": (4, 16, 512, 512, 0, 512, 1, 1, 0, L.PRO_NONE, False),
+    "Q1_skip_cat_raw": (4, 16, 512, 768, 512, 512, 1, 1, 0, L.PRO_NONE, False),
 }
 # the 3x3 layers of the default UNet that run on the LDS-DMA kernel (levels 0-2) and its 1x1 layers of levels 0-2, in network order
 DMA3 = ["L0_res0_enc_raw", "L0_res1_enc_raw", "L1_down_res0_raw", "L1_down_res1_raw", "L1_enc_res0_raw", "L1_res1_raw", "L2_down_res0_raw",
