@@ -88,7 +88,9 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
   static constexpr int CS_OFF = NST * STAGE + NW * EPI_WAVE;
   static constexpr int SMEM = CS_OFF + 2048;
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
-  static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : ((r >> 2) & 3); }
+  // (128-byte rows: ds_read_b128 is served in 16-lane groups over a 256-byte bank row; a row sits in half r & 1 of it, so the
+  // 8 even and the 8 odd rows of a group need 8 distinct slots each -- (r >> 1) & 7 gives that for every group of the instruction)
+  static __device__ __forceinline__ int swz(int r) { return LPR == 2 ? ((r >> 3) & 1) : LPR == 4 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
 };
 
 // Persistent workgroups: gridDim.x workgroups walk the unit list (unit = pixel tile x channel tile x group) with a
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   // ---- DMA source bookkeeping (per lane): this wave moves pieces wave, wave+4, ...
   const int lrow = lane / LPR, lslot = lane % LPR;
   // tile-independent halo coordinates of this lane's rows
-  static_assert(MF <= 2, "at most two pixel fragments per wave");
+  static_assert(MF <= 3, "at most three pixel fragments per wave");
   auto a_row = [&](int i, int lr, int& hh_out, int& ww_out, int& slot_out) {
     const int r = (wave + NW * i) * RPW + lr;
     const int hh = (int)(((float)r + 0.5f) * p.inv_TWP);
@@ -1098,6 +1100,28 @@ bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
   return p.Ng >= 192 && pixel_tiles * ceil_div(p.Ng, 256) >= 128;
 }
 
+// A 1x1 conv has no spatial structure: when nothing in the launch depends on the image index or the row / column of a pixel, the
+// B*H*W pixels are ONE list cut into units of bm pixels x 256 channels (no ragged 2-D tiles), and bm is chosen against the
+// 256 persistent workgroups: units = ceil(M / bm) * ceil(Ng / 256) * G run in ceil(units / 256) rounds of bm pixels each (the
+// 192-pixel unit reads 5 fragments per 6 MFMAs instead of 6 per 8: +5 %).  88064 pixels x 256 channels: 344 units of 256 pixels = 2
+// rounds (512 pixel-times) against 459 of 192 = 2 rounds (384); 22016 x 512: 172 units / 256 CUs against 230 / 256.
+// Returns the unit's pixel count (256 | 192) or 0 (2-D tiles).  DDX_DMA_FLAT=0 off, =256 | 192 forces a unit size.
+int dma_flat_1x1_bm(const ConvParams& p) {
+  static const int knob = std::getenv("DDX_DMA_FLAT") ? atoi(std::getenv("DDX_DMA_FLAT")) : 1;
+  if (!knob || p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
+  if (p.out_cs && p.B > 1) return 0;
+  if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM) return 0;
+  if (p.Ng < 192) return 0;
+  const long M = (long)p.B * p.H * p.W;
+  if (M >= (1l << 30)) return 0;
+  const long nn = (long)ceil_div(p.Ng, 256) * p.G;
+  if (ceil_div(M, 256l) * nn < 128) return 0;      // (too few units for the persistent grid: register-staged kernel)
+  if (knob == 256 || knob == 192) return knob;
+  const double c256 = (double)ceil_div(ceil_div(M, 256l) * nn, 256l) * 256.0;
+  const double c192 = (double)ceil_div(ceil_div(M, 192l) * nn, 256l) * 192.0 * 1.05;
+  return c192 < c256 ? 192 : 256;
+}
+
 // TH x TW with TW a multiple of 32 (fragments never wrap tile rows) and TH*TW = 256
 bool dma_tile(const ConvParams& p, int ksize, int* TH, int* TW, double* util, int bm = kBM, int max_rows_3x3 = DmaGeom<3, 16, 2, 1>::AROWS) {
   const int pad = ksize / 2;
@@ -1143,6 +1167,7 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   // automatic choice: layers with enough units to fill the persistent grid; small-M layers stay on the register-staged
   // kernel (split-K, wider K chunks)
   const long tiles = (long)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * p.G;
+  if (ksize == 1 && p.epilogue != DDX_EPI_SILU_BWD && dma_flat_1x1_bm(p)) return true;
   if (util < 0.6) return false;
   if (ksize == 1 && dma_wide_1x1(p, tiles)) return true;
   // (3x3 from 384 units: the L2 layers with 96 channels per group measure 30.0 us here vs 34.7 us register-staged)
@@ -1216,6 +1241,19 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   }
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
+  // wide 1x1 layers on flat pixel lists: 256 | 192 pixels x 256 channels per unit, whichever leaves the 256 CUs less idle
+  if (const int bm = dma_flat_1x1_bm(p)) {
+    ConvParams q = p;
+    q.B = 1; q.H = q.sH = 1; q.W = q.sW = p.B * p.H * p.W;
+    q.TH = 1; q.TW = bm;
+    q.tiles_h = 1; q.tiles_w = ceil_div(q.W, bm);
+    q.arows_alloc = bm;
+    q.inv_TWP = 1.0f / (float)bm;
+    // 64-channel stages where the layer allows (half as many stage hand-overs: these layers run 1 us per stage whatever its size)
+    static const int sk64_knob = std::getenv("DDX_DMA_SK64") ? atoi(std::getenv("DDX_DMA_SK64")) : 1;
+    if (bm == 192 && sk64_knob && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0) return launch_dma_t<1, 64, 2, 4, 0, 2, 3>(q, s);
+    return bm == 192 ? launch_dma_t<1, 32, 2, 4, 0, 2, 3>(q, s) : launch_dma_t<1, 32, 4, 2>(q, s);
+  }
   const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);
   return wide ? launch_dma_t<1, 32, 4, 2>(p, s) : launch_dma_t<1, 32, 2, 1>(p, s);
 }

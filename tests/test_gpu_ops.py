@@ -733,15 +733,16 @@ import torch
 from dualdiffusion_amd import ops
 g = torch.Generator(device="cuda").manual_seed(3)
 worst = 0.0
-for (B, H, W, C0, C1, Cout, G, res) in [(2, 40, 200, 128, 0, 128, 2, True), (2, 40, 200, 64, 64, 64, 2, False), (4, 32, 344, 256, 0, 512, 8, False),
-                                         (4, 16, 344, 768, 0, 768, 8, True), (4, 32, 700, 512, 0, 256, 8, True)]:
+for (B, H, W, C0, C1, Cout, G, res, ks) in [(2, 40, 200, 128, 0, 128, 2, True, 3), (2, 40, 200, 64, 64, 64, 2, False, 3), (4, 32, 344, 256, 0, 512, 8, False, 3),
+                                             (4, 16, 344, 768, 0, 768, 8, True, 3), (4, 32, 700, 512, 0, 256, 8, True, 3),
+                                             (2, 64, 301, 256, 0, 256, 1, True, 1), (2, 64, 301, 256, 128, 512, 1, False, 1)]:   # wide 1x1 (flat pixel list)
     a0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
     a1 = torch.randn(B, H, W, C1, device="cuda", generator=g).bfloat16() if C1 else None
-    w = torch.randn(Cout, (C0 + C1) // G, 3, 3, device="cuda", generator=g)
+    w = torch.randn(Cout, (C0 + C1) // G, ks, ks, device="cuda", generator=g)
     r = torch.randn(B, H, W, Cout, device="cuda", generator=g).bfloat16() if res else None
     cs = torch.rand(B, Cout, device="cuda", generator=g) + 0.5
     pw = ops.wprep(w, G, torch.bfloat16, npix=B * H * W)
-    kw = dict(src1=a1, residual=r, res_t=0.3, clip=256.0) if res else dict(src1=a1, out_act=True, out_scale=cs)
+    kw = dict(src1=a1, residual=r, res_t=0.3, clip=256.0) if res else (dict(src1=a1, out_act=True, out_scale=cs) if ks == 3 else dict(src1=a1))
     tw_d, tw_m = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16), torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
     y_d = ops.conv2d(a0, pw, path="dma", out2=tw_d if res else None, **kw)
     y_m = ops.conv2d(a0, pw, path="mfma", out2=tw_m if res else None, **kw)
@@ -754,10 +755,10 @@ print("WORST", worst)
 """
 
 
-@pytest.mark.parametrize("knob", ["DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_PCS=0", "DDX_DMA_WS=0"])
+@pytest.mark.parametrize("knob", ["DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_PCS=0", "DDX_DMA_WS=0", "DDX_DMA_FLAT=0", "DDX_DMA_FLAT=192", "DDX_DMA_FLAT=256"])
 def test_conv_dma_experiment_knobs_stay_correct(knob):
     """The LDS-DMA kernel with its mode switches flipped (XCD unit order everywhere, resident / streaming producer-consumer /
-    stationary-weights modes off; read once per process, so each runs in its own interpreter) against the register-staged kernel on
+    stationary-weights modes off, wide 1x1 layers on 2-D tiles / flat lists of 192- / 256-pixel units; read once per process, so each runs in its own interpreter) against the register-staged kernel on
     grouped / two-source / residual layers."""
     import os
     import subprocess
