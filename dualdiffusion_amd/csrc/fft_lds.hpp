@@ -121,8 +121,15 @@ __device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int
       const int p = idx / s, q = idx - p * s;
       Butterfly<R, INV>::run(a[r]);
       x[q + s * (R * p)] = a[r][0];
+      // one table read per butterfly: W^{pk} = (W^p)^k by repeated multiplication (k <= 4: ~3 ulp); the table sits in L2 and
+      // every read is a dependent round trip inside a barrier-separated stage (FGLA 1.87 -> 1.81 ms per iteration)
+      const cf w1 = twiddle<INV>(tw, p * tstep);
+      cf wk = w1;
 #pragma unroll
-      for (int k = 1; k < R; ++k) x[q + s * (R * p + k)] = cmul(a[r][k], twiddle<INV>(tw, p * k * tstep));
+      for (int k = 1; k < R; ++k) {
+        x[q + s * (R * p + k)] = cmul(a[r][k], wk);
+        wk = cmul(wk, w1);
+      }
     }
   }
   __syncthreads();
