@@ -86,7 +86,9 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
   // output channel scales of the unit's BN channels, staged by DMA with the unit's first stage (two 1-KiB DMA targets, units
   // alternate): a global load inside the epilogue would wait behind the next unit's first stage, which is in flight there
   static constexpr int CS_OFF = NST * STAGE + NW * EPI_WAVE;
-  static constexpr int SMEM = CS_OFF + 2048;
+  // per-wave partial sums of squares of the pixel-norm epilogue when WN waves share a pixel row (wide 1x1 units)
+  static constexpr int PN_OFF = CS_OFF + 2048;
+  static constexpr int SMEM = PN_OFF + (KS == 1 && WN > 1 ? NW * MF * 32 * 4 : 0);
   // 16-byte slot swizzle of LDS row r (conflict-free ds_read_b128 over 32 consecutive rows)
   // (128-byte rows: ds_read_b128 is served in 16-lane groups over a 256-byte bank row; a row sits in half r & 1 of it, so the
   // 8 even and the 8 odd rows of a group need 8 distinct slots each -- (r >> 1) & 7 gives that for every group of the instruction)
@@ -696,6 +698,39 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
 
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
     if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
+    if constexpr (!EB && KS == 1 && WN > 1) {
+      if (p.epilogue == DDX_EPI_PIXELNORM) {
+        // wide 1x1 units: the WN waves of a pixel row each hold NF * 32 of its channels; partial sums of squares meet in LDS
+        // (one workgroup barrier: every wave runs every unit's epilogue; the next write is a whole stage loop away)
+        float* pn = reinterpret_cast<float*>(smem + GEO::PN_OFF);
+        const float inv_sqrt_c = __builtin_amdgcn_rsqf((float)p.Cout);
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            // (fragments past the padded channel count were fed clamped weight rows: not part of the pixel)
+            if (t.n0 + (wn * NF + i) * 32 >= p.NgP) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ss = fmaf(acc[i][j][r], acc[i][j][r], ss);
+          }
+          ss += __shfl_xor(ss, 32, 64);
+          if (khalf == 0) pn[(wave * MF + j) * 32 + l31] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+          float ss = 0.f;
+#pragma unroll
+          for (int k = 0; k < WN; ++k) ss += pn[((wm * WN + k) * MF + j) * 32 + l31];
+          const float inv = 1.0f / (p.norm_eps + sqrtf(ss) * inv_sqrt_c);
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+        }
+      }
+    }
     if constexpr (!EB && WN == 1 && NF <= 2 && MF <= 2) {
       if (p.epilogue == DDX_EPI_PIXELNORM) {
         // normalize(y, dim = channels) on the accumulators: a lane holds 16 of the 32 channels of pixel (lane & 31) per fragment,
@@ -1110,8 +1145,9 @@ int dma_flat_1x1_bm(const ConvParams& p) {
   static const int knob = std::getenv("DDX_DMA_FLAT") ? atoi(std::getenv("DDX_DMA_FLAT")) : 1;
   if (!knob || p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
   if (p.out_cs && p.B > 1) return 0;
-  if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM) return 0;
+  if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM && p.epilogue != DDX_EPI_PIXELNORM) return 0;
   if (p.Ng < 192) return 0;
+  if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 256)) return 0;      // all channels of a pixel in ONE unit
   const long M = (long)p.B * p.H * p.W;
   if (M >= (1l << 30)) return 0;
   const long nn = (long)ceil_div(p.Ng, 256) * p.G;
@@ -1159,7 +1195,8 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   if (p.Ng % 8 || p.Cout % 8) return false;
   if (p.epilogue == DDX_EPI_MPSUM && p.out_act && p.out_cs && (p.Cout % 4)) return false;
   if (p.epilogue == DDX_EPI_SILU_BWD && dma_bwd_bn(p) == 0) return false;  // every channel tile must lie in ONE part
-  if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 64)) return false;  // all output channels of a pixel in one wave's fragments
+  // pixel norm: all output channels of a pixel in one wave's fragments, or in one 256-channel unit of a wide 1x1 layer
+  if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 64) && !(ksize == 1 && dma_flat_1x1_bm(p))) return false;
   if ((size_t)p.B * p.sH * p.sW >= (size_t)1 << 31) return false;
   int TH, TW; double util;
   if (!dma_tile(p, ksize, &TH, &TW, &util)) return false;

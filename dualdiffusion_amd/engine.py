@@ -53,6 +53,9 @@ SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
 # skip conv runs at the SOURCE size (a quarter of the matrix work and output bytes) and conv_res1 gathers the half-size
 # residual in its epilogue (ddx_conv_desc::residual_up).  Inference plans; DDX_RES_UP=0 restores the full-size skip conv.
 RES_UP = os.environ.get("DDX_RES_UP", "1") != "0"
+# encoder blocks: normalize(conv_skip(x)) and its activated twin from the skip conv's epilogue where one unit holds all channels of a pixel
+FUSE_PIXELNORM = os.environ.get("DDX_FUSE_PIXELNORM", "1") != "0"
+PIXELNORM_EPS = 1e-4     # eps of normalize() (mp_tools.py:42-49), the default of ops.pixelnorm
 
 
 class PlanBuilder:
@@ -183,6 +186,9 @@ class PlanBuilder:
                 S(lambda: ops.resample2d(src0, xd, rs))
                 S(lambda: ops.conv2d(xd, pw_skip, out=x1))
                 S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
+            elif pw_skip is not None and rs == RESAMPLE_KEEP and self._fused_pixelnorm(src0, pw_skip, x1, x1a):
+                # wide 1x1 skip conv with the pixel norm and the activated twin in its epilogue (one 256-channel unit sees a whole pixel)
+                S(lambda: ops.conv2d(src0, pw_skip, out=x1, out2=x1a, out2_scale=1.0, pixelnorm_eps=PIXELNORM_EPS))
             elif pw_skip is not None:
                 S(lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), resample=rs, out=x1))
                 S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
@@ -270,6 +276,15 @@ class PlanBuilder:
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
+
+    def _fused_pixelnorm(self, src0, pw_skip, x1, x1a) -> bool:
+        """Does the library run this encoder skip conv with DDX_EPI_PIXELNORM (bf16 inference plans; DDX_FUSE_PIXELNORM=0: never)?"""
+        if not FUSE_PIXELNORM or self.training or self.dt != torch.bfloat16:
+            return False
+        try:
+            return ops.conv2d(src0, pw_skip, out=x1, out2=x1a, out2_scale=1.0, pixelnorm_eps=PIXELNORM_EPS, query=True) == 3
+        except Exception:
+            return False
 
     def _block_layouts(self, act0, act1, in0, pw_res0, kw0, y0, pw_res1, kw1, twin) -> None:
         """Decide which tensors of a block are channel-blocked (ops.mark_c16): the library is asked which kernel each of the two 3x3

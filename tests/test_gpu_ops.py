@@ -597,6 +597,34 @@ def test_conv_pixelnorm_epilogue(Cin, Cout, ks):
         ops.conv2d(to_nhwc(x, torch.float32), ops.wprep(w.cuda(), 1, torch.float32), pixelnorm_eps=1e-4)
 
 
+@pytest.mark.parametrize("Cin,Cout,W", [(256, 256, 301), (128, 192, 512), (384, 224, 300)])
+def test_conv_pixelnorm_epilogue_wide_1x1(Cin, Cout, W):
+    """DDX_EPI_PIXELNORM on the wide 1x1 units (192 | 256 pixels x up to 256 channels, the waves of a pixel row exchange partial sums of
+    squares through LDS): the skip conv of a full-resolution encoder block with normalize() and the activated twin in its epilogue."""
+    ops = _ops()
+    from dualdiffusion_amd._lib import DDXError
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(17 + Cout)
+    B, H = 2, 64
+    x = _round(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g)
+    wp_ref = _round(O.prepared_weight(w), dtype)
+    y = torch.nn.functional.conv2d(x, wp_ref)
+    ref = y / (1e-4 + y.norm(dim=1, keepdim=True) / Cout ** 0.5)
+    pw = ops.wprep(w.cuda(), 1, dtype, npix=B * H * W)
+    xn = to_nhwc(x, dtype)
+    twin = torch.empty(B, H, W, Cout, dtype=dtype, device="cuda")
+    assert ops.conv2d(xn, pw, pixelnorm_eps=1e-4, out2=twin, query=True) == 3
+    out = ops.conv2d(xn, pw, pixelnorm_eps=1e-4, out2=twin)
+    torch.cuda.synchronize()
+    assert rel_l2(to_nchw(out), ref) < TOL[dtype]
+    assert rel_l2(to_nchw(twin), torch.nn.functional.silu(ref) / 0.596) < 2 * TOL[dtype]
+    rms = to_nchw(out).float().square().mean(dim=1).sqrt()
+    assert float((rms - 1).abs().max()) < 2e-2
+    with pytest.raises(DDXError):       # 512 output channels: two units per pixel
+        ops.conv2d(xn, ops.wprep(torch.randn(512, Cin, 1, 1).cuda(), 1, dtype), pixelnorm_eps=1e-4)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_cat2_act(dtype):
     """ddx_cat2_act: mp_cat materialised with its mp_silu'd twin in one pass."""
@@ -755,7 +783,7 @@ print("WORST", worst)
 """
 
 
-@pytest.mark.parametrize("knob", ["DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_PCS=0", "DDX_DMA_WS=0", "DDX_DMA_FLAT=0", "DDX_DMA_FLAT=192", "DDX_DMA_FLAT=256"])
+@pytest.mark.parametrize("knob", ["DDX_DMA_XCD=2", "DDX_DMA_RES=0", "DDX_DMA_PCS=0", "DDX_DMA_WS=0", "DDX_DMA_FLAT=0", "DDX_DMA_FLAT=192", "DDX_DMA_FLAT=256", "DDX_DMA_SK64=0"])
 def test_conv_dma_experiment_knobs_stay_correct(knob):
     """The LDS-DMA kernel with its mode switches flipped (XCD unit order everywhere, resident / streaming producer-consumer /
     stationary-weights modes off, wide 1x1 layers on 2-D tiles / flat lists of 192- / 256-pixel units; read once per process, so each runs in its own interpreter) against the register-staged kernel on
