@@ -215,7 +215,7 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
   if (d.epilogue == DDX_EPI_PIXELNORM) {
     p.norm_eps = d.res_t;
     if (d.force_direct == 1 || d.force_direct == 2 || d.force_direct >= 16 || !conv_dma_supported(p, ks, dt, /*any_size=*/true))
-      return set_error(DDX_ERR_UNSUPPORTED, "conv: the pixel-norm epilogue is built for the LDS-DMA kernel (one group; Cout <= 64, or a wide 1x1 layer with 192 ... 256 output channels)");
+      return set_error(DDX_ERR_UNSUPPORTED, "conv: the pixel-norm epilogue is built for the LDS-DMA kernel (one group; Cout <= 64, or a wide 1x1 layer with 192 ... 512 output channels)");
   }
   // d.force_direct selects the kernel: 0 = automatic, 1 = scalar reference kernel, 2 = register-staged MFMA kernel,
   // 3 = LDS-DMA MFMA kernel (error when the layer does not qualify)

@@ -1140,16 +1140,18 @@ bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
 // 256 persistent workgroups: units = ceil(M / bm) * ceil(Ng / 256) * G run in ceil(units / 256) rounds of bm pixels each (the
 // 192-pixel unit reads 5 fragments per 6 MFMAs instead of 6 per 8: +5 %).  88064 pixels x 256 channels: 344 units of 256 pixels = 2
 // rounds (512 pixel-times) against 459 of 192 = 2 rounds (384); 22016 x 512: 172 units / 256 CUs against 230 / 256.
-// Returns the unit's pixel count (256 | 192) or 0 (2-D tiles).  DDX_DMA_FLAT=0 off, =256 | 192 forces a unit size.
+// Returns the unit's pixel count (256 | 192; 96 = the 512-channel pixel-norm unit) or 0 (2-D tiles).  DDX_DMA_FLAT=0 off, =256 | 192 forces a unit size.
 int dma_flat_1x1_bm(const ConvParams& p) {
   static const int knob = std::getenv("DDX_DMA_FLAT") ? atoi(std::getenv("DDX_DMA_FLAT")) : 1;
   if (!knob || p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
   if (p.out_cs && p.B > 1) return 0;
   if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM && p.epilogue != DDX_EPI_PIXELNORM) return 0;
   if (p.Ng < 192) return 0;
-  if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 256)) return 0;      // all channels of a pixel in ONE unit
+  if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 512)) return 0;      // all channels of a pixel in ONE unit
   const long M = (long)p.B * p.H * p.W;
   if (M >= (1l << 30)) return 0;
+  // pixel norm over 257 ... 512 channels: units of 96 pixels x 512 channels (eight waves of 64 channels each)
+  if (p.epilogue == DDX_EPI_PIXELNORM && p.Cout > 256) return (knob && ceil_div(M, 96l) >= 128) ? 96 : 0;
   const long nn = (long)ceil_div(p.Ng, 256) * p.G;
   if (ceil_div(M, 256l) * nn < 128) return 0;      // (too few units for the persistent grid: register-staged kernel)
   if (knob == 256 || knob == 192) return knob;
@@ -1288,6 +1290,7 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     q.inv_TWP = 1.0f / (float)bm;
     // 64-channel stages where the layer allows (half as many stage hand-overs: these layers run 1 us per stage whatever its size)
     static const int sk64_knob = std::getenv("DDX_DMA_SK64") ? atoi(std::getenv("DDX_DMA_SK64")) : 1;
+    if (bm == 96) return launch_dma_t<1, 32, 2, 8, 0, 1, 3>(q, s);
     if (bm == 192 && sk64_knob && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0) return launch_dma_t<1, 64, 2, 4, 0, 2, 3>(q, s);
     return bm == 192 ? launch_dma_t<1, 32, 2, 4, 0, 2, 3>(q, s) : launch_dma_t<1, 32, 4, 2>(q, s);
   }

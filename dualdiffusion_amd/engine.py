@@ -184,8 +184,11 @@ class PlanBuilder:
                 # four strided loads per staged vector and serialises the small-M layers
                 xd = self.act(h, w, src0.shape[3])
                 S(lambda: ops.resample2d(src0, xd, rs))
-                S(lambda: ops.conv2d(xd, pw_skip, out=x1))
-                S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
+                if self._fused_pixelnorm(xd, pw_skip, x1, x1a):
+                    S(lambda: ops.conv2d(xd, pw_skip, out=x1, out2=x1a, out2_scale=1.0, pixelnorm_eps=PIXELNORM_EPS))
+                else:
+                    S(lambda: ops.conv2d(xd, pw_skip, out=x1))
+                    S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
             elif pw_skip is not None and rs == RESAMPLE_KEEP and self._fused_pixelnorm(src0, pw_skip, x1, x1a):
                 # wide 1x1 skip conv with the pixel norm and the activated twin in its epilogue (one 256-channel unit sees a whole pixel)
                 S(lambda: ops.conv2d(src0, pw_skip, out=x1, out2=x1a, out2_scale=1.0, pixelnorm_eps=PIXELNORM_EPS))

@@ -93,8 +93,8 @@ enum { DDX_EPI_STORE = 0, DDX_EPI_MPSUM = 1, DDX_EPI_SILU_BWD = 2 /* internal: d
        /* out = normalize(y, dim = channels) (mp_tools.py:42-49: y / (eps + rms_c(y)), eps = res_t) on the fp32 accumulators, then clip /
         * out2 as usual: the pixel norm that follows the skip conv of an encoder block (unet_edm2_ddec_mclt_b1.py:107-109) without its
         * own pass.  LDS-DMA kernel only, one group, all output channels in ONE channel tile (Cout <= 64; <= 32 when Cout <= 32) or in one
-        * 256-channel unit of a wide 1x1 layer (192 <= Cout <= 256, plain bf16 operands; the waves of a pixel row exchange their partial
-        * sums of squares through LDS): DDX_ERR_UNSUPPORTED otherwise. */
+        * unit of a wide 1x1 layer (192 <= Cout <= 512, plain bf16 operands; the waves of a pixel row exchange their partial sums of
+        * squares through LDS): DDX_ERR_UNSUPPORTED otherwise. */
        DDX_EPI_PIXELNORM = 3 };
 enum { DDX_PAD_ZERO = 0, DDX_PAD_REFLECT_W = 1,
        /* flag, OR-ed in: src1 is read from the pair-swapped image (index b ^ 1; B even) -- the second depth tap of a (2,k,k)

@@ -597,7 +597,7 @@ def test_conv_pixelnorm_epilogue(Cin, Cout, ks):
         ops.conv2d(to_nhwc(x, torch.float32), ops.wprep(w.cuda(), 1, torch.float32), pixelnorm_eps=1e-4)
 
 
-@pytest.mark.parametrize("Cin,Cout,W", [(256, 256, 301), (128, 192, 512), (384, 224, 300)])
+@pytest.mark.parametrize("Cin,Cout,W", [(256, 256, 301), (128, 192, 512), (384, 224, 300), (256, 512, 150), (512, 384, 129)])
 def test_conv_pixelnorm_epilogue_wide_1x1(Cin, Cout, W):
     """DDX_EPI_PIXELNORM on the wide 1x1 units (192 | 256 pixels x up to 256 channels, the waves of a pixel row exchange partial sums of
     squares through LDS): the skip conv of a full-resolution encoder block with normalize() and the activated twin in its epilogue."""
@@ -621,8 +621,8 @@ def test_conv_pixelnorm_epilogue_wide_1x1(Cin, Cout, W):
     assert rel_l2(to_nchw(twin), torch.nn.functional.silu(ref) / 0.596) < 2 * TOL[dtype]
     rms = to_nchw(out).float().square().mean(dim=1).sqrt()
     assert float((rms - 1).abs().max()) < 2e-2
-    with pytest.raises(DDXError):       # 512 output channels: two units per pixel
-        ops.conv2d(xn, ops.wprep(torch.randn(512, Cin, 1, 1).cuda(), 1, dtype), pixelnorm_eps=1e-4)
+    with pytest.raises(DDXError):       # 768 output channels: more than one unit per pixel
+        ops.conv2d(xn, ops.wprep(torch.randn(768, Cin, 1, 1).cuda(), 1, dtype), pixelnorm_eps=1e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
