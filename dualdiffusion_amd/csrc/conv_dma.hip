@@ -1140,7 +1140,7 @@ bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
 // 256 persistent workgroups: units = ceil(M / bm) * ceil(Ng / 256) * G run in ceil(units / 256) rounds of bm pixels each (the
 // 192-pixel unit reads 5 fragments per 6 MFMAs instead of 6 per 8: +5 %).  88064 pixels x 256 channels: 344 units of 256 pixels = 2
 // rounds (512 pixel-times) against 459 of 192 = 2 rounds (384); 22016 x 512: 172 units / 256 CUs against 230 / 256.
-// Returns the unit's pixel count (256 | 192; 96 = the 512-channel pixel-norm unit) or 0 (2-D tiles).  DDX_DMA_FLAT=0 off, =256 | 192 forces a unit size.
+// Returns the unit's pixel count (256 | 192 | 96; -96 = the 96-pixel x 512-channel pixel-norm unit) or 0 (2-D tiles).  DDX_DMA_FLAT=0 off, =256 | 192 forces a unit size.
 int dma_flat_1x1_bm(const ConvParams& p) {
   static const int knob = std::getenv("DDX_DMA_FLAT") ? atoi(std::getenv("DDX_DMA_FLAT")) : 1;
   if (!knob || p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
@@ -1150,10 +1150,16 @@ int dma_flat_1x1_bm(const ConvParams& p) {
   if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 512)) return 0;      // all channels of a pixel in ONE unit
   const long M = (long)p.B * p.H * p.W;
   if (M >= (1l << 30)) return 0;
-  // pixel norm over 257 ... 512 channels: units of 96 pixels x 512 channels (eight waves of 64 channels each)
-  if (p.epilogue == DDX_EPI_PIXELNORM && p.Cout > 256) return (knob && ceil_div(M, 96l) >= 128) ? 96 : 0;
+  // pixel norm over 257 ... 512 channels: units of 96 pixels x 512 channels (eight waves of 64 channels each).  Every unit streams the
+  // whole weight matrix for its 96 pixels: worth it from 512 input channels (level-1 512 -> 512: 52 -> 39 us with the norm; 256 -> 512
+  // measured 36.9 us fused against 16.5 + 20 apart)
+  if (p.epilogue == DDX_EPI_PIXELNORM && p.Cout > 256) return (knob && p.Cg >= 512 && ceil_div(M, 96l) >= 48) ? -96 : 0;
   const long nn = (long)ceil_div(p.Ng, 256) * p.G;
-  if (ceil_div(M, 256l) * nn < 128) return 0;      // (too few units for the persistent grid: register-staged kernel)
+  // (too few units for the persistent grid: register-staged kernel.  A fused pixel norm saves a launch and a round trip of the
+  // tensor, which pays from 64 units; small-M layers with long K take 96-pixel units from 128 of them)
+  const bool small_units = ceil_div(M, 256l) * nn < 128;
+  if (small_units && p.epilogue == DDX_EPI_PIXELNORM) return ceil_div(M, 192l) * nn >= 64 ? 192 : 0;
+  if (small_units) return (knob == 1 && p.Cg >= 1024 && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0 && ceil_div(M, 96l) * nn >= 128) ? 96 : 0;
   if (knob == 256 || knob == 192) return knob;
   const double c256 = (double)ceil_div(ceil_div(M, 256l) * nn, 256l) * 256.0;
   const double c192 = (double)ceil_div(ceil_div(M, 192l) * nn, 256l) * 192.0 * 1.05;
@@ -1281,7 +1287,8 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
   // wide 1x1 layers on flat pixel lists: 256 | 192 pixels x 256 channels per unit, whichever leaves the 256 CUs less idle
-  if (const int bm = dma_flat_1x1_bm(p)) {
+  if (const int bm_code = dma_flat_1x1_bm(p)) {
+    const int bm = bm_code < 0 ? -bm_code : bm_code;
     ConvParams q = p;
     q.B = 1; q.H = q.sH = 1; q.W = q.sW = p.B * p.H * p.W;
     q.TH = 1; q.TW = bm;
@@ -1290,7 +1297,8 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     q.inv_TWP = 1.0f / (float)bm;
     // 64-channel stages where the layer allows (half as many stage hand-overs: these layers run 1 us per stage whatever its size)
     static const int sk64_knob = std::getenv("DDX_DMA_SK64") ? atoi(std::getenv("DDX_DMA_SK64")) : 1;
-    if (bm == 96) return launch_dma_t<1, 32, 2, 8, 0, 1, 3>(q, s);
+    if (bm_code == -96) return launch_dma_t<1, 32, 2, 8, 0, 1, 3>(q, s);      // 96 pixels x 512 channels (pixel norm)
+    if (bm == 96) return launch_dma_t<1, 64, 1, 8, 0, 1, 3>(q, s);       // 96 pixels x 256 channels, 64-channel stages (small-M, long K)
     if (bm == 192 && sk64_knob && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0) return launch_dma_t<1, 64, 2, 4, 0, 2, 3>(q, s);
     return bm == 192 ? launch_dma_t<1, 32, 2, 4, 0, 2, 3>(q, s) : launch_dma_t<1, 32, 4, 2>(q, s);
   }

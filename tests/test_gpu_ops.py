@@ -597,7 +597,7 @@ def test_conv_pixelnorm_epilogue(Cin, Cout, ks):
         ops.conv2d(to_nhwc(x, torch.float32), ops.wprep(w.cuda(), 1, torch.float32), pixelnorm_eps=1e-4)
 
 
-@pytest.mark.parametrize("Cin,Cout,W", [(256, 256, 301), (128, 192, 512), (384, 224, 300), (256, 512, 150), (512, 384, 129)])
+@pytest.mark.parametrize("Cin,Cout,W", [(256, 256, 301), (128, 192, 512), (384, 224, 300), (512, 512, 150), (512, 384, 129), (256, 256, 100)])
 def test_conv_pixelnorm_epilogue_wide_1x1(Cin, Cout, W):
     """DDX_EPI_PIXELNORM on the wide 1x1 units (192 | 256 pixels x up to 256 channels, the waves of a pixel row exchange partial sums of
     squares through LDS): the skip conv of a full-resolution encoder block with normalize() and the activated twin in its epilogue."""
@@ -623,6 +623,9 @@ def test_conv_pixelnorm_epilogue_wide_1x1(Cin, Cout, W):
     assert float((rms - 1).abs().max()) < 2e-2
     with pytest.raises(DDXError):       # 768 output channels: more than one unit per pixel
         ops.conv2d(xn, ops.wprep(torch.randn(768, Cin, 1, 1).cuda(), 1, dtype), pixelnorm_eps=1e-4)
+    if Cin < 512:                       # 512-channel units re-stream the whole weight matrix per 96 pixels: only built from 512 input channels
+        with pytest.raises(DDXError):
+            ops.conv2d(xn, ops.wprep(torch.randn(512, Cin, 1, 1).cuda(), 1, dtype), pixelnorm_eps=1e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -763,7 +766,8 @@ g = torch.Generator(device="cuda").manual_seed(3)
 worst = 0.0
 for (B, H, W, C0, C1, Cout, G, res, ks) in [(2, 40, 200, 128, 0, 128, 2, True, 3), (2, 40, 200, 64, 64, 64, 2, False, 3), (4, 32, 344, 256, 0, 512, 8, False, 3),
                                              (4, 16, 344, 768, 0, 768, 8, True, 3), (4, 32, 700, 512, 0, 256, 8, True, 3),
-                                             (2, 64, 301, 256, 0, 256, 1, True, 1), (2, 64, 301, 256, 128, 512, 1, False, 1)]:   # wide 1x1 (flat pixel list)
+                                             (2, 64, 301, 256, 0, 256, 1, True, 1), (2, 64, 301, 256, 128, 512, 1, False, 1),   # wide 1x1 (flat pixel list)
+                                             (4, 8, 172, 1024, 768, 768, 1, False, 1)]:                                        # small-M, long K: 96-pixel units
     a0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
     a1 = torch.randn(B, H, W, C1, device="cuda", generator=g).bfloat16() if C1 else None
     w = torch.randn(Cout, (C0 + C1) // G, ks, ks, device="cuda", generator=g)
