@@ -169,7 +169,7 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   p.src0_alt = d.src0_alt; p.out2_cs = d.out2_chan_scale; p.out2_linear = d.out2_linear;
   if (d.out2_linear && (!d.out2 || !d.out2_chan_scale)) return set_error(DDX_ERR_ARG, "conv: out2_linear needs out2 and out2_chan_scale");
-  if ((d.src0_alt || d.out2_linear) && d.CK != 16) return set_error(DDX_ERR_UNSUPPORTED, "conv: src0_alt / out2_linear are served by the small-M kernel only (CK = 16)");
+  if (d.src0_alt && (d.prologue != DDX_PRO_NONE || d.prologue_rows <= 0)) return set_error(DDX_ERR_ARG, "conv: src0_alt needs prologue_rows > 0 and no prologue");
   p.layout = d.layout;
   if (d.layout) {
     if (d.layout & ~15) return set_error(DDX_ERR_ARG, "conv: layout");
@@ -239,6 +239,9 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
   const bool dma = d.force_direct == 3 || d.epilogue == DDX_EPI_PIXELNORM ||
                    (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
   if (d.force_direct >= 16 && !mfma) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the register-staged MFMA kernel");
+  if (d.out2_linear && d.CK != 16 && (dma || !mfma))
+    return set_error(DDX_ERR_UNSUPPORTED, "conv: out2_linear is served by the small-M kernel (CK = 16) and the register-staged MFMA kernel only");
+  if (d.src0_alt && !dma) return set_error(DDX_ERR_UNSUPPORTED, "conv: src0_alt is served by the small-M kernel (CK = 16) and the wide 1x1 units of the LDS-DMA kernel only");
   if (query) return dma ? 3 : mfma ? 2 : 1;
   if (d.layout && (!dma || p.epilogue == DDX_EPI_PIXELNORM)) return set_error(DDX_ERR_UNSUPPORTED, "conv: channel-blocked tensors need the LDS-DMA kernel (ddx_mpconv2d_path)");
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   for (int i = 0; i < BI; ++i) b_row(i, lrow, btap[i], bn[i], bslot[i]);
   const rsrc_t rs0 = make_rsrc(p.src0, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
   const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
+  // src0_alt: the output-channel tiles below pro_rows read a second tensor of src0's shape (merged attn_qk | attn_v conv over [x * c_qk | x])
+  const rsrc_t rs0a = p.src0_alt ? make_rsrc(p.src0_alt, (size_t)p.B * p.sH * p.sW * p.C0 * 2) : rs0;
   const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.G * p.nchunk * TAPS * p.NgP * p.CK * 2);
   const rsrc_t rscs = make_rsrc(p.out_cs ? (const void*)p.out_cs : p.wp, p.out_cs ? (size_t)p.B * p.Cout * 4 : 0);
   constexpr bool CS_LDS = !EB && NF <= 2 && MF <= 2;   // (the 8-fragment variants have no registers to spare for it)
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     }
     const int cin_src = src_id ? cabs - p.C0 : cabs;
     const int soff_a = c16 ? (cin_src >> 4) * p.sH * p.sW * 32 : cin_src * 2;
-    const rsrc_t rsa = src_id ? rs1 : rs0;
+    const rsrc_t rsa = src_id ? rs1 : ((KS == 1 && p.src0_alt && it.g * p.Ng + it.n0 < p.pro_rows) ? rs0a : rs0);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int piece = wave + NW * i;
@@ -1145,6 +1147,7 @@ int dma_flat_1x1_bm(const ConvParams& p) {
   static const int knob = std::getenv("DDX_DMA_FLAT") ? atoi(std::getenv("DDX_DMA_FLAT")) : 1;
   if (!knob || p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
   if (p.out_cs && p.B > 1) return 0;
+  if (p.src0_alt && (p.src1 || p.pro_rows <= 0 || p.pro_rows % 256 || p.G != 1)) return 0;   // a unit's 256 channels read ONE source
   if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM && p.epilogue != DDX_EPI_PIXELNORM) return 0;
   if (p.Ng < 192) return 0;
   if (p.epilogue == DDX_EPI_PIXELNORM && (p.G != 1 || p.Cout > 512)) return 0;      // all channels of a pixel in ONE unit
@@ -1194,6 +1197,7 @@ static int dma_bwd_bn(const ConvParams& p) {
 
 bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size) {
   if (dtype != DDX_BF16 || (ksize != 1 && ksize != 3)) return false;
+  if (p.src0_alt && !(ksize == 1 && dma_flat_1x1_bm(p) > 0)) return false;   // per-tile source switch: wide 1x1 units only
   if (p.prologue != DDX_PRO_NONE || p.scale0 != 1.0f || (p.src1 && p.scale1 != 1.0f)) return false;
   if (p.resample == DDX_RESAMPLE_DOWN) return false;
   const int SK = ksize == 3 ? 16 : 32;

@@ -417,7 +417,12 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
     if (eoff[it] < 0) continue;
     if (p.out2) {  // activated twin for the next block's conv_res0
       Vec4<T> tv;
-      if (p.out_cs && !p.out_act) {  // raw main output: the channel scale belongs to the twin (training forward keeps y AND mp_silu(y * c))
+      if (p.out2_linear) {   // linear twin y * c2[b][c]: the operand x * c_qk of the attention block's q|k conv, written by the conv that makes x
+        const int ch = g * p.Ng + n0 + (idx % G4) * 4;
+        const f32x4 c4v = *reinterpret_cast<const f32x4*>(p.out2_cs + (size_t)b * p.Cout + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tv.set(e, y[e] * c4v[e]);
+      } else if (p.out_cs && !p.out_act) {  // raw main output: the channel scale belongs to the twin (training forward keeps y AND mp_silu(y * c))
         const int ch = g * p.Ng + n0 + (idx % G4) * 4;
         const f32x4 c4v = *reinterpret_cast<const f32x4*>(p.out_cs + (size_t)b * p.Cout + ch);
 #pragma unroll

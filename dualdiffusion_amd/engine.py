@@ -55,6 +55,9 @@ SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
 RES_UP = os.environ.get("DDX_RES_UP", "1") != "0"
 # encoder blocks: normalize(conv_skip(x)) and its activated twin from the skip conv's epilogue where one unit holds all channels of a pixel
 FUSE_PIXELNORM = os.environ.get("DDX_FUSE_PIXELNORM", "1") != "0"
+# attention blocks outside the small-M regime, large batches: x * c_qk as a materialised twin + the merged qkv conv on the wide 1x1 units of
+# the LDS-DMA kernel (0 = never)
+QKV_TWIN_MIN_PIXELS = int(os.environ.get("DDX_QKV_TWIN_MIN_PIXELS", "2048"))
 PIXELNORM_EPS = 1e-4     # eps of normalize() (mp_tools.py:42-49), the default of ops.pixelnorm
 
 
@@ -269,6 +272,19 @@ class PlanBuilder:
             qk, vv = qkv[..., :2 * cout], qkv[..., 2 * cout:]
             if pw_qkv.CK == 16:
                 S(lambda: ops.conv2d(xo, pw_qkv, src0_alt=xs, prologue_rows=2 * cout, out=qkv))
+            elif self._qkv_twin_ok(xo, pw_qkv, cout, qkv, npix):
+                # large batches: x * c_qk is written once (one element-wise pass) and the q|k output tiles of the merged conv read it through
+                # src0_alt, so the conv takes raw operands and runs on the wide 1x1 units of the LDS-DMA kernel (B=32: 430 -> 700+ TFLOP/s)
+                xs2 = self.act(h, w, cout)
+                try:    # conv_res1 on the register-staged kernel writes the twin itself (kw1 is read when the queued step runs)
+                    twin_in_conv = ops.conv2d(y0, pw_res1, query=True, **dict(kw1, out2=xs2, out2_chan_scale=c_qk)) == 2
+                except Exception:
+                    twin_in_conv = False
+                if twin_in_conv:
+                    kw1.update(out2=xs2, out2_chan_scale=c_qk)
+                else:
+                    S(lambda: ops.silu_scale_fwd(xo, c_qk, 1.0, act=False, out=xs2))
+                S(lambda: ops.conv2d(xo, pw_qkv, src0_alt=xs2, prologue_rows=2 * cout, out=qkv))
             else:
                 S(lambda: ops.conv2d(xo, pw_qkv, prologue=PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * cout, out=qkv))
         else:
@@ -279,6 +295,16 @@ class PlanBuilder:
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
+
+    def _qkv_twin_ok(self, xo, pw_qkv, cout, qkv, npix) -> bool:
+        """Merged attn_qk | attn_v conv on the LDS-DMA kernel with a materialised x * c_qk twin (src0_alt)?  From QKV_TWIN_MIN_PIXELS
+        pixels: at the benchmark batch (1376 pixels at level 3) the extra pass costs what the faster conv gains (4.60 vs 4.59 ms)."""
+        if self.training or self.dt != torch.bfloat16 or QKV_TWIN_MIN_PIXELS <= 0 or npix < QKV_TWIN_MIN_PIXELS:
+            return False
+        try:
+            return ops.conv2d(xo, pw_qkv, src0_alt=xo, prologue_rows=2 * cout, out=qkv, query=True) == 3
+        except Exception:
+            return False
 
     def _fused_pixelnorm(self, src0, pw_skip, x1, x1a) -> bool:
         """Does the library run this encoder skip conv with DDX_EPI_PIXELNORM (bf16 inference plans; DDX_FUSE_PIXELNORM=0: never)?"""

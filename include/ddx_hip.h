@@ -145,11 +145,13 @@ typedef struct {
   /* > 0: the prologue (chan_scale / mp_silu) only applies to output channels below prologue_rows; the rest read the raw
    * input (merged attn_qk | attn_v conv: qk = conv(x * c_qk), v = conv(x)).  Must be a multiple of 64. */
   int32_t prologue_rows;
-  /* small-M kernel (conv_sm.hip) only:
+  /* operand twins of the attention block (small-M kernel conv_sm.hip; where noted also other kernels):
    *   out2_linear = 1: out2 = y_final * out2_chan_scale[b][cout] (no activation) -- the scaled twin x * c_qk that attn_qk reads
-   *                (unet_edm2_b4.py:131-133), written by the conv that produces x;
+   *                (unet_edm2_b4.py:131-133), written by the conv that produces x (also the register-staged MFMA kernel);
    *   src0_alt != NULL (with prologue == NONE and prologue_rows > 0): output channels below prologue_rows read src0_alt instead
-   *                of src0 -- merged attn_qk | attn_v conv over [x * c_qk | x] without a per-element prologue. */
+   *                of src0 -- merged attn_qk | attn_v conv over [x * c_qk | x] without a per-element prologue.  Also served by the
+   *                wide 1x1 units of the LDS-DMA kernel (one group, no src1, prologue_rows a multiple of 256: a unit's 256 output
+   *                channels read ONE source); DDX_ERR_UNSUPPORTED on the other kernels. */
   int32_t out2_linear;
   /* Channel-blocked tensors (LDS-DMA kernel, bf16 inference plans): a flagged tensor is stored [B][C/16][H][W][16] instead of NHWC,
    * so that a K-stage of the 3x3 kernel (16 input channels of a halo row) is ONE contiguous run of (TW+2) * 32 bytes instead of

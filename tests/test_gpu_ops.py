@@ -723,6 +723,44 @@ def test_merged_qk_v_conv_matches_separate_convs(dtype):
     assert rel_l2(out.float(), ref.float()) <= tol
 
 
+def test_conv_src0_alt_on_the_wide_1x1_units():
+    """src0_alt on the LDS-DMA kernel: the merged attn_qk | attn_v conv of a level-3-sized attention block (1376 pixels, 1024 -> 3072)
+    reads the materialised twin x * c_qk for its q|k tiles (prologue_rows) and x for the v tiles -- against the channel-scale prologue of
+    the register-staged kernel (same bf16 operand values after rounding)."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    from dualdiffusion_amd._lib import DDXError
+    dev, dtype = "cuda", torch.bfloat16
+    torch.manual_seed(6)
+    B, H, W, Cn = 4, 4, 86, 1024
+    x = torch.randn(B, H, W, Cn, device=dev).to(dtype)
+    c_qk = torch.rand(B, Cn, device=dev) + 0.5
+    w = torch.randn(3 * Cn, Cn, 1, 1, device=dev)
+    pw = ops.wprep(w, 1, dtype, npix=B * H * W)
+    ref = ops.conv2d(x, pw, prologue=L.PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * Cn, path="mfma")
+    xs = ops.silu_scale_fwd(x, c_qk, 1.0, act=False)
+    assert ops.conv2d(x, pw, src0_alt=xs, prologue_rows=2 * Cn, query=True) == 3
+    out = ops.conv2d(x, pw, src0_alt=xs, prologue_rows=2 * Cn)
+    torch.cuda.synchronize()
+    assert rel_l2(out[..., :2 * Cn].float(), ref[..., :2 * Cn].float()) < 2e-3
+    assert rel_l2(out[..., 2 * Cn:].float(), ref[..., 2 * Cn:].float()) < 2e-3
+    # not vacuous: without the twin the q|k tiles differ
+    plain = ops.conv2d(x, pw, path="mfma")
+    assert rel_l2(plain[..., :2 * Cn].float(), ref[..., :2 * Cn].float()) > 5e-2
+    with pytest.raises(DDXError):       # a source switch inside a 256-channel unit
+        ops.conv2d(x, pw, src0_alt=xs, prologue_rows=2 * Cn + 64)
+    # the producer side: conv_res1 on the register-staged kernel writes the linear twin x * c_qk next to x (out2_chan_scale)
+    w3 = torch.randn(Cn, Cn // 8, 3, 3, device=dev)
+    pw3 = ops.wprep(w3, 8, dtype, npix=B * H * W)
+    res = torch.randn(B, H, W, Cn, device=dev).to(dtype)
+    tw = torch.empty_like(res)
+    y = ops.conv2d(x, pw3, residual=res, res_t=0.3, path="mfma", out2=tw, out2_chan_scale=c_qk)
+    y_ref = ops.conv2d(x, pw3, residual=res, res_t=0.3, path="mfma")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    assert rel_l2(tw.float(), y_ref.float() * c_qk[:, None, None, :]) < 4e-3
+
+
 def test_conv_autotune_choice_is_consistent():
     """ops.tuning(): a conv times its kernel candidates once per layer signature (ddx_conv_desc.force_direct >= 16 selects the
     tile / split-K configuration of the register-staged kernel); whatever wins computes the same conv (bf16: 2e-3)."""

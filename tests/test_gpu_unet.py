@@ -239,3 +239,40 @@ def test_up_block_skip_conv_at_source_size_matches_full_size(dtype, tol, monkeyp
     e = rel_l2(outs[0], outs[1])
     print(f"RES_UP on vs off: {e:.3e}")
     assert e < tol
+
+
+def test_qkv_twin_path_matches_the_prologue_path(monkeypatch):
+    """Large batches: the merged attn_qk | attn_v conv reads a materialised x * c_qk twin (src0_alt) on the LDS-DMA kernel instead of
+    scaling its operand in the register-staged kernel's prologue.  Default-size UNet at B=8 (2752 pixels at level 3), both ways."""
+    from dualdiffusion_amd import engine
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    torch.manual_seed(3)
+    cfg = UNetConfig()
+    unet = UNet(cfg).requires_grad_(False).train(False)
+    for k, v in unet.state_dict().items():
+        if v.ndim == 0:
+            v.fill_(0.7)
+    sd = {k: v.clone() for k, v in unet.state_dict().items()}
+    fmt = _Fmt()
+    B = 8
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(B, 4, 32, 688, device="cuda", generator=g)
+    sigma = torch.rand(B, device="cuda", generator=g) * 3 + 0.1
+    clap = torch.randn(B, cfg.in_channels_emb, device="cuda", generator=g)
+    outs, steps = [], []
+    for min_px in (1, 0):
+        monkeypatch.setattr(engine, "QKV_TWIN_MIN_PIXELS", min_px)
+        u = UNet(cfg).requires_grad_(False).train(False)
+        u.load_state_dict(sd)
+        u = u.to(device="cuda", dtype=torch.bfloat16)
+        u.normalize_weights()
+        with torch.no_grad():
+            emb = u.get_embeddings(clap, torch.ones(B, dtype=torch.bool, device="cuda"))
+            outs.append(u(x, sigma, fmt, emb).float())
+        steps.append(len(u._engine_for(B, 32, 688, False).pb.steps))
+        del u
+        torch.cuda.empty_cache()
+    e = rel_l2(outs[0], outs[1])
+    print(f"qkv twin path vs prologue path: rel-L2 {e:.3e}; plan steps {steps}")
+    assert torch.isfinite(outs[0]).all() and e < 1.5e-2
+    assert steps[0] >= steps[1]       # (the twin comes out of conv_res1's epilogue, or from one extra element-wise step per block)
