@@ -232,6 +232,14 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
     return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_sm(p, ks, s); }, stream, ks == 3 ? "conv3x3_sm" : "conv1x1_sm", flops_sm, bytes_sm);
   }
   if (d.force_direct == 4) return set_error(DDX_ERR_UNSUPPORTED, "conv: the small-M kernel needs weights prepared with CK = 16");
+  // the input convs (3x3 over 8 zero-padded channels, plain store + twin) have their own kernel
+  if (d.force_direct == 5 && !conv_few_supported(p, ks, dt)) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the few-input-channel kernel");
+  if ((d.force_direct == 0 || d.force_direct == 5) && d.epilogue == DDX_EPI_STORE && conv_few_supported(p, ks, dt)) {
+    if (query) return 5;
+    const double flops_f = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
+    const double bytes_f = 2.0 * ((double)p.B * p.H * p.W * (p.Cin + (double)p.Cout * (d.out2 ? 2.0 : 1.0)));
+    return dispatch([p](hipStream_t s) -> int { return launch_conv_few(p, s); }, stream, "conv3x3_few", flops_f, bytes_f);
+  }
   const bool mfma = d.force_direct != 1 && conv_mfma_supported(p, ks, dt);
   static const bool dma_enabled = []() { const char* e = std::getenv("DDX_CONV_DMA"); return !e || e[0] != '0'; }();
   if (d.force_direct == 3 && !conv_dma_supported(p, ks, dt, /*any_size=*/true))

@@ -62,6 +62,8 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
 int launch_conv_dma(const ConvParams& p, int ksize, hipStream_t s);
 bool conv_sm_supported(const ConvParams& p, int ksize, int dtype);  // conv_sm.hip (small-M weight-streaming kernel, CK = 16 layout)
 int launch_conv_sm(const ConvParams& p, int ksize, hipStream_t s);
+bool conv_few_supported(const ConvParams& p, int ksize, int dtype);  // conv_few.hip (3x3 over 8 zero-padded input channels: the input convs)
+int launch_conv_few(const ConvParams& p, hipStream_t s);
 size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize);  // per (unit, wave) channel sums of the DDX_EPI_SILU_BWD epilogue
 
 }  // namespace ddx

@@ -93,7 +93,7 @@ def normalize_weights_(weight: torch.Tensor) -> None:
 # its real operands (heuristic choice, LDS-DMA kernel, every built tile / split-K configuration of the register-staged kernel)
 # and remembers the fastest per layer signature; later calls (the plan recording) ask for that kernel.  The heuristic stays
 # unless a candidate is at least 4 % faster.
-_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3, "sm": 4}
+_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3, "sm": 4, "few": 5}
 _conv_choice: dict = {}
 _tuning = False
 
@@ -179,6 +179,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | "sm" (small-M weight-streaming kernel; weights prepared with CK = 16, which also selects it automatically)
+    | "few" (3x3 over 8 zero-padded input channels: the input convs; the automatic choice where it applies)
     | an integer force_direct code (16 + 3 * tile + k: one tile / split-K configuration of the register-staged kernel).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
     (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y)).

@@ -761,6 +761,31 @@ def test_conv_src0_alt_on_the_wide_1x1_units():
     assert rel_l2(tw.float(), y_ref.float() * c_qk[:, None, None, :]) < 4e-3
 
 
+@pytest.mark.parametrize("Cout,H,W,twin", [(256, 32, 96, True), (96, 19, 70, True), (32, 8, 33, False), (160, 5, 31, True)])
+def test_conv_few_input_channels(Cout, H, W, twin):
+    """conv_few.hip: the input convs (3x3 over 8 zero-padded channels, plain store + activated twin) on their own kernel -- five
+    k-steps per pixel, whole NHWC rows stored from an LDS tile -- against the register-staged kernel, ragged tiles included."""
+    ops = _ops()
+    dev, dtype = "cuda", torch.bfloat16
+    torch.manual_seed(9 + Cout)
+    B = 3
+    x = torch.zeros(B, H, W, 8, device=dev, dtype=dtype)
+    x[..., :6] = torch.randn(B, H, W, 6, device=dev).to(dtype)           # (4 latent channels + constant + ln-frequency channel, padded to 8)
+    w = torch.randn(Cout, 6, 3, 3, device=dev)
+    pw = ops.wprep(w, 1, dtype, cg_pad=8, npix=B * H * W)
+    assert ops.conv2d(x, pw, query=True) == 5
+    t_f = torch.empty(B, H, W, Cout, device=dev, dtype=dtype) if twin else None
+    t_m = torch.empty(B, H, W, Cout, device=dev, dtype=dtype) if twin else None
+    y_f = ops.conv2d(x, pw, out2=t_f, out2_scale=0.8)
+    y_m = ops.conv2d(x, pw, out2=t_m, out2_scale=0.8, path="mfma")
+    torch.cuda.synchronize()
+    assert rel_l2(y_f.float(), y_m.float()) < 2e-3 and float(y_m.float().norm()) > 0
+    if twin:
+        assert rel_l2(t_f.float(), t_m.float()) < 4e-3
+    # other layer types stay on the general kernels
+    assert ops.conv2d(x, pw, clip=2.0, query=True) != 5
+
+
 def test_conv_autotune_choice_is_consistent():
     """ops.tuning(): a conv times its kernel candidates once per layer signature (ddx_conv_desc.force_direct >= 16 selects the
     tile / split-K configuration of the register-staged kernel); whatever wins computes the same conv (bf16: 2e-3)."""
