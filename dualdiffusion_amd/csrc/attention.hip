@@ -149,8 +149,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 #pragma unroll
       for (int e = 0; e < EV; ++e) yk.set(e, fk[e] * sck);
       *reinterpret_cast<decltype(yk.v)*>(sK + r * QS + sv * EV) = yk.v;
+      if constexpr (sizeof(T) == 2) {
+        // bf16: V stays row-major [key][dim] like K (one 16-byte write); the PV operand is read with the transpose read below
+        Vec16<T> yv;
 #pragma unroll
-      for (int e = 0; e < EV; ++e) sVt[(sv * EV + e) * VS + r] = from_f32<T>(fv[e] * scv);
+        for (int e = 0; e < EV; ++e) yv.set(e, fv[e] * scv);
+        *reinterpret_cast<decltype(yv.v)*>(sVt + r * QS + sv * EV) = yv.v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EV; ++e) sVt[(sv * EV + e) * VS + r] = from_f32<T>(fv[e] * scv);
+      }
     }
     __syncthreads();
     if (c0 + KC < Tn) issue_kv(c0 + KC);  // the next chunk travels while this one is multiplied
@@ -211,15 +219,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
           bf16x8 pf;
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) pf[kk] = (bf16)s[kt][8 * j + kk];
-          const int kb = kt * 32 + 16 * j + 4 * khalf;
+          // A operand = V^T: lane (dim l31, khalf) needs keys kt*32 + 16j + 4 khalf + {0..3, 8..11} of its dim column.  ds_read_b64_tr_b16
+          // hands every lane 4 consecutive ROWS of its column of a [4 rows][16 columns] block addressed by its 16-lane group (lane i of
+          // the group supplies row i >> 2, 4-element run i & 3): group gq = (khalf, dim half), two reads 8 keys apart.
+          const int gq = lane >> 4, li = lane & 15;
+          const int kb = kt * 32 + 16 * j + 4 * (gq >> 1) + (li >> 2);
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) {
-            const T* vp = sVt + (dt * 32 + l31) * VS + kb;
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp);
-            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vp + 8);
-            bf16x8 vf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+            const T* vp = sVt + kb * QS + dt * 32 + (gq & 1) * 16 + (li & 3) * 4;
+            typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * QS));
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
           }
         }
@@ -264,7 +276,8 @@ template <typename T, int D, int KC>
 static int launch_attn_kc(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
                           int v_ld, int fold) {
   constexpr int EV = 16 / (int)sizeof(T);
-  const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + (size_t)D * (KC + AttnMma<T>::VPAD)) * sizeof(T);
+  // Q tile + K chunk + V chunk (bf16: row-major [KC][D + EV] like K, read transposed; fp32: transposed [D][KC + pad])
+  const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + std::max((size_t)D * (KC + AttnMma<T>::VPAD), (size_t)KC * (D + EV))) * sizeof(T);
   if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim too large for this dtype");
   auto kern = attn_fwd_kernel<T, D, KC>;
   static bool attr_done = false;
