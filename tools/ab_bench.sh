@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B of builds of libddx_hip.so on the headline bench inside ONE box: variants/lib_base.so vs variants/lib_<name>.so ...
-L=dualdiffusion_amd/lib/libddx_hip.so
-for r in 1 2; do
-  for v in base "$@"; do
-    cp variants/lib_$v.so $L
-    echo -n "$v: "; python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])"
-  done
+# A/B of one run-time switch on ONE box (box-to-box spread is +-2-3 %, larger than most single changes):
+#   tools/ab_bench.sh DDX_DMA_SK64=0 [batch]      -> alternates the default build and the build with the switch, twice, prints ms per step + families
+sw=${1:?switch, e.g. DDX_RES_UP=0}; b=${2:-4}
+for i in 1 2; do
+  python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('default', j['ms_per_step'], j['roofline']['families_ms'])"
+  env $sw python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$sw', j['ms_per_step'], j['roofline']['families_ms'])"
 done
