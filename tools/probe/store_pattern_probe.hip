@@ -6,6 +6,8 @@
 //   pattern 2: 8 bytes per lane, lane l -> piece + 8 l, two instructions per KiB
 //   pattern 3: as 0 with non-temporal stores                           pattern 4: as 1 with non-temporal stores
 //   pattern 5: 16 bytes per lane, 32-byte runs 512 bytes apart (an NHWC row of 256 channels, 16-channel slice per pixel)
+//   pattern 6: four such instructions back to back writing ADJACENT 32-byte runs (128 bytes = one cache line per pixel, rows 1 KiB apart):
+//              what a register epilogue with an NHWC output of 512 channels would do for a 64-channel tile      pattern 7: two (64 bytes per pixel)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -34,12 +36,18 @@ __global__ __launch_bounds__(512) void store_kernel(char* buf, size_t total, int
       const size_t base = (((size_t)i * nwave + gw) * 32 * 512) % (total - 32 * 512);
       *reinterpret_cast<u32x4*>(buf + base + (lane >> 1) * 512 + (lane & 1) * 16) = v;
     }
+    if constexpr (PAT == 6 || PAT == 7) {
+      constexpr int NR = PAT == 6 ? 4 : 2;
+      const size_t base = (((size_t)i * nwave + gw) * 32 * 1024) % (total - 32 * 1024);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) *reinterpret_cast<u32x4*>(buf + base + (lane >> 1) * 1024 + r * 32 + (lane & 1) * 16) = v;
+    }
     v[0] += 1;
   }
 }
 
 template <int PAT> int run(char* buf, size_t total, const char* what) {
-  const int ni = (int)(total / 1024 / (256 * 8));
+  const int ni = (int)(total / 1024 / (256 * 8)) / (PAT == 6 ? 4 : PAT == 7 ? 2 : 1);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(store_kernel<PAT>, dim3(256), dim3(512), 0, 0, buf, total, ni);
@@ -50,7 +58,7 @@ template <int PAT> int run(char* buf, size_t total, const char* what) {
   CK(hipDeviceSynchronize());
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
-  const double us = ms * 1e3 / reps, bytes = (double)ni * 256 * 8 * 1024;
+  const double us = ms * 1e3 / reps, bytes = (double)ni * 256 * 8 * 1024 * (PAT == 6 ? 4 : PAT == 7 ? 2 : 1);
   printf("pattern %d (%s): %.1f us per %.0f MB = %.2f TB/s; %.0f cycles (2.4 GHz) per store instruction and wave\n", PAT, what, us, bytes / 1e6, bytes / us / 1e6,
          us * 2400.0 / ni / (PAT == 2 ? 2 : 1));
   return 0;
@@ -67,5 +75,7 @@ int main(int argc, char** argv) {
   if (run<3>(buf, total, "lane-linear 16 B nt")) return 1;
   if (run<4>(buf, total, "half-interleaved 16 B nt")) return 1;
   if (run<5>(buf, total, "32-byte runs, 512-byte stride")) return 1;
+  if (run<6>(buf, total, "4 adjacent 32-byte runs per pixel row (128 B), rows 1 KiB apart")) return 1;
+  if (run<7>(buf, total, "2 adjacent 32-byte runs per pixel row (64 B), rows 1 KiB apart")) return 1;
   return 0;
 }
