@@ -1,25 +1,24 @@
-// Magnitude-preserving conv2d forward for the SMALL-M layers of the UNet (levels 3 / 4 of the default model: 344 or 86 pixels per
-// image, 83 % of the weights, reference src/modules/unets/unet_edm2_b4.py:110-158 at H x W = 4 x 86 / 2 x 43): weight-streaming
-// implicit GEMMs built around latency, not around tile throughput.
+// Magnitude-preserving conv2d forward for the SMALL-M layers of the UNet (level 4 of the default model: 86 pixels per image, 344 at
+// B = 4; reference src/modules/unets/unet_edm2_b4.py:110-158 at H x W = 2 x 43): implicit GEMMs built around latency, not around
+// tile throughput.
 //
-// What bounds these layers is the number of SERIAL memory round trips inside a launch (2-5 us of roofline work took 11-25 us on
-// the register-staged kernel: K loop of dependent chunks, 4-step LDS split-K reduction, residual and scale loads behind the
-// matrix phase).  Here every byte a workgroup needs is requested as early as the hardware lets it and nothing waits on a
-// workgroup barrier inside the K loop:
+// What bounds these layers is the number of SERIAL memory round trips inside a launch (2-3 us of roofline work took 12-20 us: a K
+// loop of dependent chunks on the register-staged kernel, a ring of four weight fragments per wave in the first version of this
+// file).  Round-4 structure: a workgroup is EIGHT waves that split K eight ways, and every byte the workgroup needs is requested in
+// ONE burst before anything waits:
 //   * weights never touch LDS: prepared with 16-channel chunks (wp[g][c16][tap][NgP][16]) a 32-row x 16-channel MFMA A fragment is
-//     ONE contiguous 1 KiB block, loaded straight into the A operand registers by a per-wave ring that runs D steps ahead;
-//   * the 4 waves of a workgroup split K, each wave's accumulators cover the whole (32 PF pixels) x (32 NF channels) tile and
-//     nothing is exchanged until ONE two-round reduction through LDS at the end;
-//   * 1x1 layers (conv_sm1): the activation fragments go global -> registers too (a lane = one pixel, 16 bytes of its channel row
-//     per step; a wave owns a contiguous quarter of the channels, i.e. whole 128-byte lines) -- no LDS, no barrier until the end;
-//   * 3x3 layers (conv_sm3): the halo tile of ALL channels of the group is brought into LDS once by LDS-DMA (buffer_load ... lds,
-//     every piece in flight at the same time, zero padding by out-of-range offsets, rows padded by one 16-byte slot so that
-//     fragment reads are bank-conflict free), ONE barrier, then nine taps of matrix work per staged byte;
-//   * residual rows and channel scales of the epilogue are requested before the reduction.
+//     ONE contiguous 1 KiB block; a wave loads ALL fragments of its K share (<= NP steps) straight into the A operand registers;
+//   * 3x3 layers (conv_sm3): the halo tile of ALL channels of the group goes into LDS by LDS-DMA (buffer_load ... lds, zero padding
+//     by out-of-range offsets, rows padded by one 16-byte slot so that fragment reads are bank-conflict free);
+//   * 1x1 layers (conv_sm1): the pixel rows of the tile (whole 128-byte lines, all input channels of a K pass) go into LDS the same
+//     way; layers with more than 80 chunks per pixel tile run two K passes;
+//   * ONE wait + ONE barrier, then <= NP matrix steps per wave, then the eight partial tiles are summed through LDS inside the fused
+//     epilogue (fixed order: deterministic); residual rows and channel scales are requested before the reduction.
 // Operands are raw (producer-side activation); the one per-channel prologue of these levels, attn_qk reading
 // x * c, is served by a scaled twin written by the producing conv (`out2_linear`) and selected per output-channel tile (`src0_alt`).
 // Workgroups that read the same weights are laid on the same XCD (observed block -> XCD map b % 8: speed only).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "conv_params.hpp"
@@ -30,6 +29,7 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int kOob = 0x7fffff00;  // voffset of a lane that must read zeros
+constexpr int kWaves = 8, kThreads = kWaves * 64;
 
 __device__ __forceinline__ void dma16(rsrc_t rs, int voff, void* l) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, 0, 0, 0);
@@ -41,118 +41,117 @@ __device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x +
 
 struct SmArgs {
   int TH, TW, TWP, tiles_h, tiles_w, R;  // 3x3: pixel tile inside an image, staged rows (halo included)
-  int V, slots;                          // 3x3: 16-byte slots per staged row (without the pad slot), slots of the slab
-  int nsteps;                            // K steps per wave (3x3: ceil(9 * Cg/16 / 4); 1x1: Cin/16 / 4)
+  int V, slots;                          // 16-byte slots per staged row (without the pad slot), slots of the staged slab
+  int SC, ppw;                           // K steps (3x3: 9 * Cg/16 pairs (tap, chunk); 1x1: chunks per pass), steps per wave
+  int npass, SCtot;                      // 1x1: K passes through LDS, chunks of the whole layer
   int PT, WT, ntiles;                    // pixel tiles, weight tiles (= G * ntiles), channel tiles per group
-  int M, HW;                             // 1x1: B*H*W, H*W
+  int M, HW;                             // B*H*W, H*W
+  int dbg;                               // DDX_SM_DBG ablation bits (timing experiments; wrong results): 1 no weight loads, 2 no operand DMA, 4 no MFMA, 8 no reduction
   float inv_TW, inv_TWP, inv_V1, inv_ks16, inv_HW, inv_W;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- epilogue
-// Cross-wave K reduction (waves 0, 1 write two fp32 regions, waves 2, 3 add) + fused element-wise tail, coalesced on NHWC rows.
-// pix_of(ml) = global output pixel of tile row ml, or -1.
-template <int PF, int NF, typename PixFn>
-__device__ __forceinline__ void sm_epilogue(const ConvParams& p, const SmArgs& a, f32x16 (&acc)[NF][PF], char* smem, int q, int g, int n0,
-                                            PixFn pix_of, bool slab_in_use) {
-  constexpr int BM = PF * 32, BN = NF * 32, ES = BN + 4, G4 = BN / 4, EI = (BM * G4 + 255) / 256;
-  const int tid = threadIdx.x, lane = tid & 63, khalf = lane >> 5, l31 = lane & 31;
-  bf16* out = reinterpret_cast<bf16*>(p.out);
-  const bf16* res = reinterpret_cast<const bf16*>(p.res);
+// Cross-wave K reduction (every wave writes its partial tile, the store phase sums the eight in a fixed order) + fused element-wise
+// tail, coalesced on NHWC rows.  pix_of(ml) = global output pixel of tile row ml, or -1.
+// Epilogue operands of a thread's items, requested at kernel start so that their latency hides behind the operand burst.
+template <int EI>
+struct SmEpiPre {
   long eoff[EI];
-  [[maybe_unused]] long roff[EI];
-  int ebc[EI];
   bf16x4 rres[EI];
   f32x4 ecs[EI], ecs2[EI];
+};
+
+template <int PF, int NF, typename PixFn>
+__device__ __forceinline__ void sm_epilogue_prefetch(const ConvParams& p, const SmArgs& a, int g, int n0, PixFn pix_of,
+                                                     SmEpiPre<(PF * 32 * NF * 8 + kThreads - 1) / kThreads>& e) {
+  constexpr int BM = PF * 32, BN = NF * 32, G4 = BN / 4, EI = (BM * G4 + kThreads - 1) / kThreads;
+  const int tid = threadIdx.x;
+  const bf16* res = reinterpret_cast<const bf16*>(p.res);
 #pragma unroll
   for (int it = 0; it < EI; ++it) {
-    const int idx = tid + it * 256;
+    const int idx = tid + it * kThreads;
     const int ml = idx / G4, c4 = idx % G4;
     const int n = n0 + c4 * 4;
     const int pix = (idx < BM * G4 && n < p.Ng) ? pix_of(ml) : -1;
-    eoff[it] = pix >= 0 ? (long)pix * p.Cout + (size_t)g * p.Ng + n : -1;
+    e.eoff[it] = pix >= 0 ? (long)pix * p.Cout + (size_t)g * p.Ng + n : -1;
     const int b = fdiv(max(pix, 0), a.inv_HW);
+    long roff = e.eoff[it] < 0 ? 0 : e.eoff[it];
     if (p.res_up) {   // residual at half size: pixel (b, h, w) reads (b, h / 2, w / 2)
       const int hw = max(pix, 0) - b * p.H * p.W, h = fdiv(hw, a.inv_W), w = hw - h * p.W;
-      roff[it] = pix >= 0 ? (long)((b * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Cout + (size_t)g * p.Ng + n : 0;
+      roff = pix >= 0 ? (long)((b * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.Cout + (size_t)g * p.Ng + n : 0;
     }
-    ebc[it] = b * p.Cout + min(g * p.Ng + n, p.Cout - 4);
+    const int ebc = b * p.Cout + min(g * p.Ng + n, p.Cout - 4);
+    if (p.epilogue == DDX_EPI_MPSUM) e.rres[it] = *reinterpret_cast<const bf16x4*>(res + roff);
+    if (p.out_cs) e.ecs[it] = *reinterpret_cast<const f32x4*>(p.out_cs + ebc);
+    if (p.out2_cs) e.ecs2[it] = *reinterpret_cast<const f32x4*>(p.out2_cs + ebc);
   }
-  if (p.epilogue == DDX_EPI_MPSUM) {
+}
+
+// Cross-wave K reduction (every wave writes its partial tile, the store phase sums the eight in a fixed order) + fused element-wise
+// tail, coalesced on NHWC rows.
+template <int PF, int NF>
+__device__ __forceinline__ void sm_epilogue(const ConvParams& p, const SmArgs& a, f32x16 (&acc)[NF][PF], char* smem, int q,
+                                            const SmEpiPre<(PF * 32 * NF * 8 + kThreads - 1) / kThreads>& pre) {
+  constexpr int BM = PF * 32, BN = NF * 32, ES = BN + 4, G4 = BN / 4, EI = (BM * G4 + kThreads - 1) / kThreads;
+  const int tid = threadIdx.x, lane = tid & 63, khalf = lane >> 5, l31 = lane & 31;
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+  __syncthreads();  // every wave is done reading the staged operand the partial tiles overlay
+  float* sE = reinterpret_cast<float*>(smem) + (size_t)q * BM * ES;
+  if (!(a.dbg & 8) || q == 0) {
 #pragma unroll
-    for (int it = 0; it < EI; ++it) rres[it] = *reinterpret_cast<const bf16x4*>(res + (p.res_up ? roff[it] : (eoff[it] < 0 ? 0 : eoff[it])));
-  }
-  if (p.out_cs) {
+    for (int j = 0; j < PF; ++j) {
+      const int ml = j * 32 + l31;
 #pragma unroll
-    for (int it = 0; it < EI; ++it) ecs[it] = *reinterpret_cast<const f32x4*>(p.out_cs + ebc[it]);
-  }
-  if (p.out2_cs) {
+      for (int i = 0; i < NF; ++i)
 #pragma unroll
-    for (int it = 0; it < EI; ++it) ecs2[it] = *reinterpret_cast<const f32x4*>(p.out2_cs + ebc[it]);
-  }
-  if (slab_in_use) __syncthreads();  // every wave is done reading the activation slab the regions overlay
-  float* sE = reinterpret_cast<float*>(smem) + (size_t)(q & 1) * BM * ES;
+        for (int k4 = 0; k4 < 4; ++k4) {
+          f32x4 y4;
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    if ((q >> 1) == round) {
-#pragma unroll
-      for (int j = 0; j < PF; ++j) {
-        const int ml = j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-#pragma unroll
-          for (int k4 = 0; k4 < 4; ++k4) {
-            float* dst = sE + (size_t)ml * ES + i * 32 + 8 * k4 + 4 * khalf;
-            f32x4 y4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * k4 + e];
-            if (round == 1) {
-              const f32x4 o4 = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) y4[e] += o4[e];
-            }
-            *reinterpret_cast<f32x4*>(dst) = y4;
-          }
-      }
+          for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * k4 + e];
+          *reinterpret_cast<f32x4*>(sE + (size_t)ml * ES + i * 32 + 8 * k4 + 4 * khalf) = y4;
+        }
     }
-    __syncthreads();
   }
+  __syncthreads();
   const float* sE0 = reinterpret_cast<const float*>(smem);
 #pragma unroll
   for (int it = 0; it < EI; ++it) {
-    const int idx = min(tid + it * 256, BM * G4 - 1);
+    const int idx = min(tid + it * kThreads, BM * G4 - 1);
     const int ml = idx / G4, c4 = idx % G4;
-    const f32x4 ya = *reinterpret_cast<const f32x4*>(sE0 + (size_t)ml * ES + c4 * 4);
-    const f32x4 yb = *reinterpret_cast<const f32x4*>(sE0 + (size_t)BM * ES + (size_t)ml * ES + c4 * 4);
+    f32x4 part[kWaves];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) part[w] = *reinterpret_cast<const f32x4*>(sE0 + (size_t)((a.dbg & 8) ? 0 : w) * BM * ES + (size_t)ml * ES + c4 * 4);
     float y[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = ya[e] + yb[e];
+    for (int e = 0; e < 4; ++e)
+      y[e] = ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]));
     if (p.epilogue == DDX_EPI_MPSUM) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = (float)rres[it][e] * p.res_a + y[e] * p.res_b;
+      for (int e = 0; e < 4; ++e) y[e] = (float)pre.rres[it][e] * p.res_a + y[e] * p.res_b;
     }
     if (p.clip > 0.f) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
     }
-    if (eoff[it] < 0) continue;
+    if (pre.eoff[it] < 0) continue;
     if (p.out2) {
       bf16x4 tv;
       if (p.out2_linear) {  // scaled twin y * c2[b][c] (operand of attn_qk)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tv[e] = (bf16)(y[e] * ecs2[it][e]);
+        for (int e = 0; e < 4; ++e) tv[e] = (bf16)(y[e] * pre.ecs2[it][e]);
       } else if (p.out_cs && !p.out_act) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tv[e] = (bf16)mp_silu_f(y[e] * ecs[it][e] * p.out2_scale);
+        for (int e = 0; e < 4; ++e) tv[e] = (bf16)mp_silu_f(y[e] * pre.ecs[it][e] * p.out2_scale);
       } else {  // activated twin for the next block's conv_res0
 #pragma unroll
         for (int e = 0; e < 4; ++e) tv[e] = (bf16)mp_silu_f(y[e] * p.out2_scale);
       }
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out2) + eoff[it]) = tv;
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out2) + pre.eoff[it]) = tv;
     }
     if (p.out_act) {  // producer-side mp_silu(y * c)
       if (p.out_cs) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] *= ecs[it][e];
+        for (int e = 0; e < 4; ++e) y[e] *= pre.ecs[it][e];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = mp_silu_f(y[e]);
@@ -160,7 +159,7 @@ __device__ __forceinline__ void sm_epilogue(const ConvParams& p, const SmArgs& a
     bf16x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = (bf16)y[e];
-    *reinterpret_cast<bf16x4*>(out + eoff[it]) = ov;
+    *reinterpret_cast<bf16x4*>(out + pre.eoff[it]) = ov;
   }
 }
 
@@ -173,11 +172,26 @@ __device__ __forceinline__ bool sm_decode(const SmArgs& a, int* wt, int* px) {
   return *wt < a.WT;
 }
 
+// one staged 16-byte slot: source select between the two tensors of an mp_cat (complementary lane masks when a piece straddles them)
+__device__ __forceinline__ void stage_slot(const ConvParams& p, rsrc_t rs0, rsrc_t rs1, bool ok, int pix, int cabs, char* dst, bool one_src,
+                                           bool only1) {
+  if (one_src) {
+    const int voff = ok ? (only1 ? pix * p.C1 + (cabs - p.C0) : pix * p.C0 + cabs) * 2 : kOob;
+    dma16(only1 ? rs1 : rs0, voff, dst);
+  } else {
+    const bool first = cabs < p.C0;
+    if (first || !ok) dma16(rs0, ok ? (pix * p.C0 + cabs) * 2 : kOob, dst);
+    if (!first && ok) dma16(rs1, (pix * p.C1 + (cabs - p.C0)) * 2, dst);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- 1x1
-// D steps of {NF weight fragments, PF activation fragments} in flight per wave; wave q owns channels [q K/4, (q+1) K/4).
-template <int PF, int NF, int D, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_sm1_kernel(const ConvParams p, const SmArgs a) {
-  constexpr int BM = PF * 32, BN = NF * 32;
+// Tile = PF * 32 consecutive pixels of the flat pixel list x NF * 32 output channels.  Per K pass: the pass's channels of the tile's
+// pixel rows go into LDS (plus one all-zero row), wave q loads the weight fragments of chunks [q ppw, (q + 1) ppw) of the pass; the
+// matrix loop is branch-free: steps past a wave's share multiply (finite, re-read) weights with the zero row.
+template <int PF, int NF, int NP>
+__global__ __launch_bounds__(kThreads, 2) void conv_sm1_kernel(const ConvParams p, const SmArgs a) {
+  constexpr int BM = PF * 32, BN = NF * 32, EI = (BM * NF * 8 + kThreads - 1) / kThreads;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,45 +201,18 @@ __global__ __launch_bounds__(256, OCC) void conv_sm1_kernel(const ConvParams p, 
   const int n0 = wt * BN;           // one group
   const int m0 = px * BM;
 
+  SmEpiPre<EI> pre;
+  sm_epilogue_prefetch<PF, NF>(p, a, 0, n0, [&](int ml) { const int m = m0 + ml; return m < a.M ? m : -1; }, pre);
+
   // output-channel tiles below pro_rows read the alternative source (x * c twin)
-  const bf16* s0p = reinterpret_cast<const bf16*>((p.src0_alt && n0 < p.pro_rows) ? p.src0_alt : p.src0);
-  const bf16* s1p = reinterpret_cast<const bf16*>(p.src1);
+  const void* s0p = (p.src0_alt && n0 < p.pro_rows) ? p.src0_alt : p.src0;
+  const rsrc_t rs0 = make_rsrc(s0p, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
+  const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
   const bf16* wp = reinterpret_cast<const bf16*>(p.wp);
   const bf16* wlane[NF];
 #pragma unroll
   for (int i = 0; i < NF; ++i) wlane[i] = wp + (size_t)min(n0 + i * 32 + l31, p.NgP - 1) * 16 + khalf * 8;
-  // this lane's pixels (rows past M read the tile's first pixel; their results are never stored)
-  int xoff0[PF], xoff1[PF];
-#pragma unroll
-  for (int j = 0; j < PF; ++j) {
-    int m = m0 + j * 32 + l31;
-    if (m >= a.M) m = m0;
-    int sp = m;
-    if (p.resample == DDX_RESAMPLE_UP) {
-      const int b = fdiv(m, a.inv_HW), r = m - b * a.HW;
-      const int h = fdiv(r, a.inv_W), w = r - h * p.W;
-      sp = (b * p.sH + (h >> 1)) * p.sW + (w >> 1);
-    }
-    xoff0[j] = sp * p.C0 + khalf * 8;
-    xoff1[j] = sp * p.C1 + khalf * 8 - p.C0;   // (+ channel: second source starts at channel C0)
-  }
-  const int ks0 = q * a.nsteps;  // first 16-channel step of this wave
 
-  bf16x8 wr[D][NF], xr[D][PF];
-  auto issue = [&](int u, int t) {   // step t of this wave into ring slot u (steps past the end re-read the last one; unused)
-    const int ks = ks0 + min(t, a.nsteps - 1);
-    const int c = ks * 16;
-    const size_t woff = (size_t)ks * p.NgP * 16;
-#pragma unroll
-    for (int i = 0; i < NF; ++i) wr[u][i] = *reinterpret_cast<const bf16x8*>(wlane[i] + woff);
-    if (c < p.C0) {
-#pragma unroll
-      for (int j = 0; j < PF; ++j) xr[u][j] = *reinterpret_cast<const bf16x8*>(s0p + xoff0[j] + c);
-    } else {
-#pragma unroll
-      for (int j = 0; j < PF; ++j) xr[u][j] = *reinterpret_cast<const bf16x8*>(s1p + xoff1[j] + c);
-    }
-  };
   f32x16 acc[NF][PF];
 #pragma unroll
   for (int i = 0; i < NF; ++i)
@@ -233,27 +220,92 @@ __global__ __launch_bounds__(256, OCC) void conv_sm1_kernel(const ConvParams p, 
     for (int j = 0; j < PF; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-  for (int u = 0; u < D; ++u) issue(u, u);
-  for (int t0 = 0; t0 < a.nsteps; t0 += D) {
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-      if (t0 + u < a.nsteps) {   // (wave-uniform; the last turn of the ring may be partial)
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-#pragma unroll
-          for (int j = 0; j < PF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[u][i], xr[u][j], acc[i][j], 0, 0, 0);
+
+  const int V = a.V, rstride = (V + 1) * 8;   // elements
+  const int npieces = (a.slots + 63) >> 6;
+  const bf16* sA = reinterpret_cast<const bf16*>(smem);
+  for (int pass = 0; pass < a.npass; ++pass) {
+    const int pc0 = pass * a.SC;                    // first chunk of the pass
+    const int pcn = min(a.SC, a.SCtot - pc0);       // chunks of this pass
+    if (pass > 0) __syncthreads();   // every wave is done with the previous pass's rows
+    // ---- pixel rows of the tile, channels of the pass: slot sidx = r * (V + 1) + v (v == V: pad slot), 64 consecutive slots per wave
+    // instruction; row BM is the zero row
+    {
+      const int c_lo = pc0 * 16, c_hi = (pc0 + pcn) * 16;
+      const bool one_src = p.src1 == nullptr || c_hi <= p.C0 || c_lo >= p.C0;   // (workgroup-uniform)
+      const bool only1 = p.src1 != nullptr && c_lo >= p.C0;
+      for (int piece = q; piece < ((a.dbg & 2) ? 0 : npieces); piece += kWaves) {
+        const int sidx = piece * 64 + lane;
+        const int r = fdiv(sidx, a.inv_V1), v = sidx - r * (V + 1);
+        const int m = m0 + r;
+        const int cabs = c_lo + v * 8;
+        const bool ok = r < BM && v < V && m < a.M && cabs < c_hi;
+        int sp = m;
+        if (p.resample == DDX_RESAMPLE_UP) {
+          const int b = fdiv(m, a.inv_HW), hw = m - b * a.HW;
+          const int h = fdiv(hw, a.inv_W), w = hw - h * p.W;
+          sp = (b * p.sH + (h >> 1)) * p.sW + (w >> 1);
+        }
+        stage_slot(p, rs0, rs1, ok, sp, cabs, smem + piece * 1024, one_src, only1);
       }
-      issue(u, t0 + u + D);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- this wave's weight fragments, all in flight behind the rows
+    bf16x8 wr[NP][NF];
+    if (!(a.dbg & 1)) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int c = min(pc0 + q * a.ppw + i, a.SCtot - 1);
+        const size_t woff = (size_t)c * p.NgP * 16;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) wr[i][n] = *reinterpret_cast<const bf16x8*>(wlane[n] + woff);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wr[i][n][e] = (bf16)1.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the rows (issued first: memory returns in order) have landed when at most the weight loads are outstanding
+    // (raw barrier: __syncthreads() would drain vmcnt to 0 because LDS-DMA writes are pending LDS stores to the compiler's fence)
+    if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * NF) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.dbg & 4)) {
+      // fragments of step i + 2 are read while step i multiplies (ring of three register sets)
+      bf16x8 xf[3][PF];
+      auto read_x = [&](int i, int u) {
+        const int cl = q * a.ppw + i;   // chunk inside the pass
+        const bool valid = i < a.ppw && cl < pcn;   // (wave-uniform)
+        const int clc = valid ? cl : 0;
+#pragma unroll
+        for (int j = 0; j < PF; ++j) xf[u][j] = *reinterpret_cast<const bf16x8*>(sA + (size_t)(valid ? j * 32 + l31 : BM) * rstride + clc * 16 + khalf * 8);
+      };
+      read_x(0, 0);
+      read_x(1, 1);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i + 2 < NP) read_x(i + 2, (i + 2) % 3);
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+          for (int j = 0; j < PF; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[i][n], xf[i % 3][j], acc[n][j], 0, 0, 0);
+      }
     }
   }
-  sm_epilogue<PF, NF>(p, a, acc, smem, q, 0, n0, [&](int ml) { const int m = m0 + ml; return m < a.M ? m : -1; }, false);
+  sm_epilogue<PF, NF>(p, a, acc, smem, q, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- 3x3
-template <int PF, int NF, int D, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_sm3_kernel(const ConvParams p, const SmArgs a) {
-  constexpr int BN = NF * 32;
+// Tile = TH x TW pixels of one image (<= PF * 32) x NF * 32 output channels of one group; wave q owns the (tap, chunk) pairs
+// s = tap * Cg/16 + chunk in [q ppw, (q + 1) ppw).  Slab row R is the zero row (see conv_sm1_kernel).
+template <int PF, int NF, int NP>
+__global__ __launch_bounds__(kThreads, 2) void conv_sm3_kernel(const ConvParams p, const SmArgs a) {
+  constexpr int BN = NF * 32, EI = (PF * 32 * NF * 8 + kThreads - 1) / kThreads;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -264,23 +316,15 @@ __global__ __launch_bounds__(256, OCC) void conv_sm3_kernel(const ConvParams p, 
   const int tx = px % a.tiles_w, ty = (px / a.tiles_w) % a.tiles_h, b = px / (a.tiles_w * a.tiles_h);
   const int h0 = ty * a.TH, w0 = tx * a.TW;
   const int TW = a.TW, TWP = a.TWP, MT = a.TH * TW;
-  const int ks16 = p.Cg >> 4, SC = 9 * ks16;
+  const int ks16 = p.Cg >> 4, SC = a.SC;
+  const int s0 = q * a.ppw;
 
-  // ---- weight ring first: step s = tap * ks16 + c16 (s = 4 t + q for this wave)
-  const bf16* wp = reinterpret_cast<const bf16*>(p.wp);
-  const bf16* wlane[NF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i) wlane[i] = wp + ((size_t)g * ks16 * 9 * p.NgP + min(n0 + i * 32 + l31, p.NgP - 1)) * 16 + khalf * 8;
-  bf16x8 wr[D][NF];
-  auto issue_w = [&](int u, int t) {
-    const int s = min(4 * t + q, SC - 1);
-    const int tap = fdiv(s, a.inv_ks16), c16 = s - tap * ks16;
-    const size_t off = ((size_t)c16 * 9 + tap) * p.NgP * 16;
-#pragma unroll
-    for (int i = 0; i < NF; ++i) wr[u][i] = *reinterpret_cast<const bf16x8*>(wlane[i] + off);
-  };
-#pragma unroll
-  for (int u = 0; u < D; ++u) issue_w(u, u);
+  SmEpiPre<EI> pre;
+  sm_epilogue_prefetch<PF, NF>(p, a, g, n0, [&](int ml) {
+    const int th = fdiv(ml, a.inv_TW), tw = ml - th * TW;
+    const int h = h0 + th, w = w0 + tw;
+    return (ml < MT && h < p.H && w < p.W) ? (b * p.H + h) * p.W + w : -1;
+  }, pre);
 
   // ---- activation slab by LDS-DMA: slot sidx = r * (V + 1) + v (v == V: pad slot), 64 consecutive slots per wave instruction
   {
@@ -290,25 +334,42 @@ __global__ __launch_bounds__(256, OCC) void conv_sm3_kernel(const ConvParams p, 
     const int cg0 = g * p.Cg;
     const bool one_src = p.src1 == nullptr || cg0 + p.Cg <= p.C0 || cg0 >= p.C0;   // (workgroup-uniform)
     const bool only1 = p.src1 != nullptr && cg0 >= p.C0;
-    for (int piece = q; piece < npieces; piece += 4) {
+    for (int piece = q; piece < ((a.dbg & 2) ? 0 : npieces); piece += kWaves) {
       const int sidx = piece * 64 + lane;
       const int r = fdiv(sidx, a.inv_V1), v = sidx - r * (a.V + 1);
       const int hh = fdiv(r, a.inv_TWP), ww = r - hh * TWP;
       const int ih = h0 - 1 + hh, iw = w0 - 1 + ww;
       const bool ok = r < a.R && v < a.V && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
       const int pix = (p.resample == DDX_RESAMPLE_UP) ? (b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (b * p.sH + ih) * p.sW + iw;
-      const int cabs = cg0 + v * 8;
-      char* dst = smem + piece * 1024;
-      if (one_src) {
-        const int voff = ok ? (only1 ? pix * p.C1 + (cabs - p.C0) : pix * p.C0 + cabs) * 2 : kOob;
-        dma16(only1 ? rs1 : rs0, voff, dst);
-      } else {  // the group straddles the two sources of an mp_cat: two passes under complementary lane masks
-        const bool first = cabs < p.C0;
-        if (first || !ok) dma16(rs0, ok ? (pix * p.C0 + cabs) * 2 : kOob, dst);
-        if (!first && ok) dma16(rs1, (pix * p.C1 + (cabs - p.C0)) * 2, dst);
-      }
+      stage_slot(p, rs0, rs1, ok, pix, cg0 + v * 8, smem + piece * 1024, one_src, only1);
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- weights behind the slab (they come from HBM): all fragments of this wave's pairs
+  const bf16* wp = reinterpret_cast<const bf16*>(p.wp);
+  const bf16* wlane[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) wlane[i] = wp + ((size_t)g * ks16 * 9 * p.NgP + min(n0 + i * 32 + l31, p.NgP - 1)) * 16 + khalf * 8;
+  bf16x8 wr[NP][NF];
+  if (!(a.dbg & 1)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int s = min(s0 + i, SC - 1);
+      const int tap = fdiv(s, a.inv_ks16), c16 = s - tap * ks16;
+      const size_t off = ((size_t)c16 * 9 + tap) * p.NgP * 16;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) wr[i][n] = *reinterpret_cast<const bf16x8*>(wlane[n] + off);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[i][n][e] = (bf16)1.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
 
   int arow[PF];
 #pragma unroll
@@ -325,47 +386,47 @@ __global__ __launch_bounds__(256, OCC) void conv_sm3_kernel(const ConvParams p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces (and its first weight fragments) have landed
-  __syncthreads();
+  // the slab (issued first: memory returns in order) has landed when at most the weight loads are outstanding
+  // (raw barrier: __syncthreads() would drain vmcnt to 0 because LDS-DMA writes are pending LDS stores to the compiler's fence)
+  if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * NF) : "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 
   const bf16* sA = reinterpret_cast<const bf16*>(smem);
   const int rstride = (a.V + 1) * 8;  // elements
-  for (int t0 = 0; t0 < a.nsteps; t0 += D) {
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-      const int s = 4 * (t0 + u) + q;
-      const bool valid = s < SC;
+  if (!(a.dbg & 4)) {
+    // fragments of step i + 2 are read while step i multiplies (ring of three register sets)
+    bf16x8 xf[3][PF];
+    auto read_x = [&](int i, int u) {
+      const int s = s0 + i;
+      const bool valid = i < a.ppw && s < SC;   // (wave-uniform)
       const int sc = valid ? s : 0;
       const int tap = fdiv(sc, a.inv_ks16), c16 = sc - tap * ks16;
       const int t3 = tap / 3;
       const int toff = t3 * TWP + (tap - 3 * t3);
-      bf16x8 xf[PF];
 #pragma unroll
-      for (int j = 0; j < PF; ++j) {
-        xf[j] = *reinterpret_cast<const bf16x8*>(sA + (size_t)(arow[j] + toff) * rstride + c16 * 16 + khalf * 8);
-        if (!valid) {   // steps past the end (at most D - 1 + 3 per wave): zero operand against the (finite) weights they re-read
+      for (int j = 0; j < PF; ++j) xf[u][j] = *reinterpret_cast<const bf16x8*>(sA + (size_t)(valid ? arow[j] + toff : a.R) * rstride + c16 * 16 + khalf * 8);
+    };
+    read_x(0, 0);
+    read_x(1, 1);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) xf[j][e] = (bf16)0.f;
-        }
-      }
+    for (int i = 0; i < NP; ++i) {
+      if (i + 2 < NP) read_x(i + 2, (i + 2) % 3);
 #pragma unroll
-      for (int i = 0; i < NF; ++i)
+      for (int n = 0; n < NF; ++n)
 #pragma unroll
-        for (int j = 0; j < PF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[u][i], xf[j], acc[i][j], 0, 0, 0);
-      issue_w(u, t0 + u + D);
+        for (int j = 0; j < PF; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[i][n], xf[i % 3][j], acc[n][j], 0, 0, 0);
     }
   }
-  sm_epilogue<PF, NF>(p, a, acc, smem, q, g, n0, [&](int ml) {
-    const int th = fdiv(ml, a.inv_TW), tw = ml - th * TW;
-    const int h = h0 + th, w = w0 + tw;
-    return (ml < MT && h < p.H && w < p.W) ? (b * p.H + h) * p.W + w : -1;
-  }, true);
+  sm_epilogue<PF, NF>(p, a, acc, smem, q, pre);
 }
 
 // ------------------------------------------------------------------------------------------- host side
 
-struct SmPlan { SmArgs a; int PF, NF, OCC, D; size_t smem; long wgs; };
-constexpr size_t kLdsTwo = 78 * 1024, kLdsOne = 156 * 1024;
+struct SmPlan { SmArgs a; int PF, NF, NP; size_t smem; long wgs; };
+constexpr size_t kLdsMax = 156 * 1024;
+constexpr int kNP1 = 10;   // 1x1: weight fragments per wave and K pass
 
 // pixel tile TH x TW <= BM of an H x W image: fewest tiles, then fewest staged rows
 void sm_tile(int H, int W, int BM, int* TH, int* TW) {
@@ -381,58 +442,80 @@ void sm_tile(int H, int W, int BM, int* TH, int* TW) {
 int env_int(const char* name) { const char* e = std::getenv(name); return e ? atoi(e) : 0; }
 
 bool sm_plan(const ConvParams& p, int ks, SmPlan* out) {
-  static const int force_pf = env_int("DDX_SM_PF"), force_nf = env_int("DDX_SM_NF");
-  static const int env_d1 = env_int("DDX_SM_D1"), env_d3 = env_int("DDX_SM_D3");
-  const int kD1 = env_d1 ? env_d1 : 4, kD3 = env_d3 ? env_d3 : 4;
+  static const int force_pf = env_int("DDX_SM_PF"), force_nf = env_int("DDX_SM_NF"), dbg = env_int("DDX_SM_DBG");
   SmPlan best{}; double best_cost = 1e30; bool found = false;
-  for (int PF = 2; PF <= 4; ++PF) {
+  for (int PF = 1; PF <= 3; ++PF) {
     if (force_pf && PF != force_pf) continue;
     for (int NF = 1; NF <= 2; ++NF) {
       if (force_nf && NF != force_nf) continue;
-      if (PF == 4 && NF == 1) continue;    // not built
+      if (ks == 3 && PF == 1) continue;   // built: 3x3 PF 2 | 3 (NF 2 only with <= 12 steps per wave); 1x1 PF 1 | 2
+      if (ks == 1 && PF == 3) continue;
+      if (NF == 2 && p.Ng <= 32) continue;
       SmArgs a{};
+      a.dbg = dbg;
       const int BM = PF * 32, BN = NF * 32;
-      const size_t red = (size_t)2 * BM * (BN + 4) * sizeof(float);
-      size_t smem = red;
+      const size_t red = (size_t)kWaves * BM * (BN + 4) * sizeof(float);
+      size_t smem;
+      int NP;
       double util;
       a.HW = p.H * p.W; a.M = p.B * a.HW;
       a.inv_HW = 1.0f / (float)a.HW; a.inv_W = 1.0f / (float)p.W;
       a.ntiles = ceil_div(p.Ng, BN);
       a.WT = p.G * a.ntiles;
       if (ks == 1) {
-        if (p.G != 1 || p.Cin % 64) continue;
-        a.nsteps = p.Cin / 64;
-        if (a.nsteps % 4) continue;   // a wave owns whole 64-channel lines
+        if (p.G != 1) continue;
+        a.SCtot = p.Cin / 16;
+        // K passes: <= 8 * kNP1 chunks per pass, and the staged rows (one pad slot each) must fit LDS
+        const int max_chunks_lds = (int)((kLdsMax / ((size_t)(BM + 1) * 16) - 1) / 2);
+        const int max_chunks = std::min(kWaves * kNP1, max_chunks_lds);
+        if (max_chunks < 8) continue;
+        a.npass = ceil_div(a.SCtot, max_chunks);
+        a.SC = ceil_div(a.SCtot, a.npass);
+        a.ppw = ceil_div(a.SC, kWaves);
+        NP = kNP1;
+        a.V = a.SC * 2;
+        a.slots = (BM + 1) * (a.V + 1);   // + the zero row
+        a.inv_V1 = 1.0f / (float)(a.V + 1);
         a.PT = ceil_div(a.M, BM);
         util = (double)a.M / ((double)a.PT * BM);
+        smem = std::max(red, (size_t)round_up(a.slots, 64) * 16);
       } else {
         sm_tile(p.H, p.W, BM, &a.TH, &a.TW);
         a.TWP = a.TW + 2;
         a.tiles_h = ceil_div(p.H, a.TH); a.tiles_w = ceil_div(p.W, a.TW);
         a.R = (a.TH + 2) * a.TWP;
         a.V = p.Cg / 8;
-        a.slots = a.R * (a.V + 1);
-        a.nsteps = round_up(ceil_div(9 * (p.Cg / 16), 4), kD3);
+        a.slots = (a.R + 1) * (a.V + 1);   // + the zero row
+        a.SC = 9 * (p.Cg / 16); a.SCtot = a.SC; a.npass = 1;
+        a.ppw = ceil_div(a.SC, kWaves);
+        if (a.ppw > 24) continue;
+        NP = a.ppw <= 12 ? 12 : 24;
+        if (NF == 2 && NP != 12) continue;
         a.PT = p.B * a.tiles_h * a.tiles_w;
         a.inv_TW = 1.0f / (float)a.TW; a.inv_TWP = 1.0f / (float)a.TWP; a.inv_V1 = 1.0f / (float)(a.V + 1); a.inv_ks16 = 1.0f / (float)(p.Cg / 16);
         smem = std::max(red, (size_t)round_up(a.slots, 64) * 16);
-        if (smem > kLdsOne) continue;
         util = (double)p.H * p.W / ((double)a.tiles_h * a.tiles_w * BM);
       }
-      const int D = ks == 1 ? kD1 : kD3;
-      // registers: accumulators + D ring steps of (NF weight + PF activation | NF weight) fragments
-      const int regs = PF * NF * 16 + D * 4 * (ks == 1 ? NF + PF : NF) + 40;
-      if (regs > 480) continue;
-      const int occ = (smem <= kLdsTwo && regs <= 250) ? 2 : 1;
+      if (smem > kLdsMax) continue;
       const long wgs = (long)a.PT * a.WT;
-      // relative cost: rounds of resident workgroups x (matrix time of one workgroup + fixed latency), padding waste included
-      const double rounds = std::ceil((double)wgs / (256.0 * occ));
-      const double mfma_us = (double)a.nsteps * PF * NF * 32.0 / 2100.0 * (NF == 1 ? 1.4 : 1.0) * (occ == 2 ? 1.5 : 1.0);
-      const double cost = rounds * (mfma_us + 3.0) / std::max(util, 0.1) * (util < 0.7 ? 1.3 : 1.0);
-      if (cost < best_cost) { best_cost = cost; best = SmPlan{a, PF, NF, occ, D, smem, wgs}; found = true; }
+      // relative cost (us): rounds of resident workgroups (one per CU) x (bytes a workgroup pulls at ~100 GB/s + matrix steps + fixed latency)
+      const double rounds = std::ceil((double)wgs / 256.0);
+      const double kk = (double)p.Cg * ks * ks;
+      const double bytes = 2.0 * (BN * kk + (ks == 1 ? (double)BM * p.Cin : (double)a.R * p.Cg));
+      const double mfma_us = (double)a.ppw * a.npass * PF * NF * 32.0 / 2100.0;
+      double cost = rounds * (bytes / 100e3 + mfma_us + 3.0) / std::max(util, 0.1);
+      // measured (MI355X, tools/conv_bench.py --cases small --path sm, DDX_SM_PF / DDX_SM_NF): 1x1 layers with 64-pixel x 32-channel tiles
+      // beat the 32 x 64 ones of equal byte count (L4 proj 10.7 vs 14.4 us, skip over mp_cat 15.6 vs 21.7: 20 weight fragments per wave
+      // in flight are slower than 10 + a second operand pass)
+      if (ks == 1 && NF == 2) cost *= 1.3;
+      if (cost < best_cost) { best_cost = cost; best = SmPlan{a, PF, NF, NP, smem, wgs}; found = true; }
     }
   }
   if (found) *out = best;
+  static const int verbose = env_int("DDX_SM_VERBOSE");
+  if (found && verbose)
+    fprintf(stderr, "conv_sm ks=%d M=%d Cin=%d Cout=%d G=%d: PF=%d NF=%d NP=%d ppw=%d npass=%d wgs=%ld smem=%zu\n", ks, best.a.M, p.Cin, p.Cout, p.G, best.PF,
+            best.NF, best.NP, best.a.ppw, best.a.npass, best.wgs, best.smem);
   return found;
 }
 
@@ -444,22 +527,15 @@ int launch_kernel(K kern, const ConvParams& p, const SmPlan& pl, hipStream_t s, 
     *attr_done = true;
   }
   const int grid = pl.a.PT * round_up(pl.a.WT, 8);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.smem, s, p, pl.a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), pl.smem, s, p, pl.a);
   return check_launch("conv_sm");
 }
 
-template <int KS, int PF, int NF, int OCC, int D>
-int launch_sm_d(const ConvParams& p, const SmPlan& pl, hipStream_t s) {
-  static bool attr_done = false;
-  if constexpr (KS == 1) return launch_kernel(conv_sm1_kernel<PF, NF, D, OCC>, p, pl, s, &attr_done);
-  else return launch_kernel(conv_sm3_kernel<PF, NF, D, OCC>, p, pl, s, &attr_done);
-}
-template <int KS, int PF, int NF, int OCC>
+template <int KS, int PF, int NF, int NP>
 int launch_sm(const ConvParams& p, const SmPlan& pl, hipStream_t s) {
-  if (pl.D == 4) return launch_sm_d<KS, PF, NF, OCC, 4>(p, pl, s);
-  if (pl.D == 8) return launch_sm_d<KS, PF, NF, OCC, 8>(p, pl, s);
-  if constexpr (KS == 3) { if (pl.D == 12) return launch_sm_d<KS, PF, NF, OCC, 12>(p, pl, s); }
-  return set_error(DDX_ERR_UNSUPPORTED, "conv_sm: ring depth not built");
+  static bool attr_done = false;
+  if constexpr (KS == 1) return launch_kernel(conv_sm1_kernel<PF, NF, NP>, p, pl, s, &attr_done);
+  else return launch_kernel(conv_sm3_kernel<PF, NF, NP>, p, pl, s, &attr_done);
 }
 
 }  // namespace
@@ -480,11 +556,10 @@ bool conv_sm_supported(const ConvParams& p, int ksize, int dtype) {
 int launch_conv_sm(const ConvParams& p, int ksize, hipStream_t s) {
   SmPlan pl;
   if (!sm_plan(p, ksize, &pl)) return set_error(DDX_ERR_UNSUPPORTED, "conv_sm: no tile fits LDS");
-#define DDX_SM(KS_, PF_, NF_)                                                          \
-  if (ksize == KS_ && pl.PF == PF_ && pl.NF == NF_)                                    \
-    return pl.OCC == 2 ? launch_sm<KS_, PF_, NF_, 2>(p, pl, s) : launch_sm<KS_, PF_, NF_, 1>(p, pl, s)
-  DDX_SM(3, 2, 1); DDX_SM(3, 2, 2); DDX_SM(3, 3, 1); DDX_SM(3, 3, 2); DDX_SM(3, 4, 2);
-  DDX_SM(1, 2, 1); DDX_SM(1, 2, 2); DDX_SM(1, 3, 1); DDX_SM(1, 3, 2); DDX_SM(1, 4, 2);
+#define DDX_SM(KS_, PF_, NF_, NP_) \
+  if (ksize == KS_ && pl.PF == PF_ && pl.NF == NF_ && pl.NP == NP_) return launch_sm<KS_, PF_, NF_, NP_>(p, pl, s)
+  DDX_SM(3, 2, 1, 12); DDX_SM(3, 2, 1, 24); DDX_SM(3, 3, 1, 12); DDX_SM(3, 3, 1, 24); DDX_SM(3, 2, 2, 12); DDX_SM(3, 3, 2, 12);
+  DDX_SM(1, 1, 1, kNP1); DDX_SM(1, 1, 2, kNP1); DDX_SM(1, 2, 1, kNP1); DDX_SM(1, 2, 2, kNP1);
 #undef DDX_SM
   return set_error(DDX_ERR_UNSUPPORTED, "conv_sm: configuration not built");
 }

@@ -90,7 +90,7 @@ class PlanBuilder:
     def pick_ck(self, Cg: int, ks: int, npix: int) -> int:
         # (1x1 layers: a wave of the small-M kernel owns a quarter of the channels in whole 64-channel lines, four steps in flight)
         if (not self.training and self.dt == torch.bfloat16 and 0 < npix <= SM_MAX_PIXELS and Cg >= 32 and
-                ((SM_3X3 and Cg % 16 == 0) if ks == 3 else Cg % 256 == 0)):
+                ((SM_3X3 and Cg % 16 == 0 and Cg <= 336) if ks == 3 else Cg % 256 == 0)):
             return 16
         return ops.pick_ck(Cg, ks, self.dt, npix)
 
