@@ -26,6 +26,19 @@ template <> struct AttnMma<float> {
   using Frag = float;
 };
 
+// Sum over aligned groups of N consecutive lanes (N = 16-byte vectors per token row), every lane gets the total.  DPP moves inside a
+// 16-lane row (quad permutes, row_half_mirror, row_mirror: pure VALU, a few cycles) instead of a chain of ds_bpermute round trips;
+// the staging of a key chunk runs two such reductions per token row.
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (N >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  if constexpr (N >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if constexpr (N >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if constexpr (N >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+  if constexpr (N >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
 template <typename T, int D, int KC_>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
                                                        const float* __restrict__ out_cs, int B, int Tn, int heads, float eps, int qk_ld, int v_ld,
@@ -42,9 +55,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   using Frag = typename AttnMma<T>::Frag;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Q tile, then two {K chunk, V chunk} buffers: chunk c + 1 is staged into the other buffer while chunk c is multiplied (one barrier per chunk)
+  constexpr int KVS = KC * QS + (sizeof(T) == 2 ? KC * QS : D * VS);   // elements of one {K, V} buffer
   T* sQ = reinterpret_cast<T*>(smem);
-  T* sK = sQ + 128 * QS;
-  T* sVt = sK + KC * QS;
+  T* sKV = sQ + 128 * QS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -100,8 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
     float ss = 0.f;
 #pragma unroll
     for (int e = 0; e < EV; ++e) { f[e] = x.get(e); ss += f[e] * f[e]; }
-#pragma unroll
-    for (int o = VPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = group_sum<VPR>(ss);
     const float sc = inv_sqrt_d / (eps + sqrtf(ss) * inv_sqrt_d);
     Vec16<T> y;
 #pragma unroll
@@ -126,9 +139,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
     for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  for (int c0 = 0; c0 < Tn; c0 += KC) {
-    __syncthreads();  // previous chunk fully consumed
-    // ---- stage K (normalised) and V^T (normalised, transposed) from the registers loaded ahead
+  // ---- stage K (normalised) and V^T (normalised, transposed) of one chunk from the registers loaded ahead
+  auto stage_kv = [&](T* sK, T* sVt) {
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
       const int r = sr + i * RPP;
@@ -141,8 +153,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
         fk[e] = xk.get(e); ssk += fk[e] * fk[e];
         fv[e] = xv.get(e); ssv += fv[e] * fv[e];
       }
-#pragma unroll
-      for (int o = VPR / 2; o > 0; o >>= 1) { ssk += __shfl_xor(ssk, o, 64); ssv += __shfl_xor(ssv, o, 64); }
+      ssk = group_sum<VPR>(ssk);
+      ssv = group_sum<VPR>(ssv);
       const float sck = 1.0f / (eps + sqrtf(ssk) * inv_sqrt_d);
       const float scv = 1.0f / (eps + sqrtf(ssv) * inv_sqrt_d);
       Vec16<T> yk;
@@ -160,8 +172,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
         for (int e = 0; e < EV; ++e) sVt[(sv * EV + e) * VS + r] = from_f32<T>(fv[e] * scv);
       }
     }
-    __syncthreads();
-    if (c0 + KC < Tn) issue_kv(c0 + KC);  // the next chunk travels while this one is multiplied
+  };
+  stage_kv(sKV, sKV + KC * QS);
+  if (KC < Tn) issue_kv(KC);
+  __syncthreads();
+
+  int cur = 0;
+  for (int c0 = 0; c0 < Tn; c0 += KC, cur ^= 1) {
+    const T* sK = sKV + cur * KVS;
+    const T* sVt = sK + KC * QS;
+    // the next chunk's rows go into the other buffer (every wave left it at the barrier that ended the previous iteration), and
+    // the chunk after that starts travelling
+    if (c0 + KC < Tn) {
+      stage_kv(sKV + (cur ^ 1) * KVS, sKV + (cur ^ 1) * KVS + KC * QS);
+      if (c0 + 2 * KC < Tn) issue_kv(c0 + 2 * KC);
+    }
 
     // ---- S^T = K . Q^T for the NKT key tiles of the chunk
     f32x16 s[NKT];
@@ -245,6 +270,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
         }
       }
     }
+    __syncthreads();  // this chunk's buffer is free, the next chunk's rows are in place
   }
 
   // ---- finalise: O / l, lane owns query q, 4 consecutive dims per register group
@@ -277,7 +303,7 @@ static int launch_attn_kc(const void* qk, const void* v, void* out, const float*
                           int v_ld, int fold) {
   constexpr int EV = 16 / (int)sizeof(T);
   // Q tile + K chunk + V chunk (bf16: row-major [KC][D + EV] like K, read transposed; fp32: transposed [D][KC + pad])
-  const size_t smem = ((size_t)128 * (D + EV) + (size_t)KC * (D + EV) + std::max((size_t)D * (KC + AttnMma<T>::VPAD), (size_t)KC * (D + EV))) * sizeof(T);
+  const size_t smem = ((size_t)128 * (D + EV) + 2 * ((size_t)KC * (D + EV) + (sizeof(T) == 2 ? (size_t)KC * (D + EV) : (size_t)D * (KC + AttnMma<T>::VPAD)))) * sizeof(T);
   if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "attn: head_dim too large for this dtype");
   auto kern = attn_fwd_kernel<T, D, KC>;
   static bool attr_done = false;
@@ -294,12 +320,20 @@ static int launch_attn_kc(const void* qk, const void* v, void* out, const float*
 template <typename T, int D>
 static int launch_attn(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
                        int v_ld, int fold = 1) {
-  // 64-key chunks for the bf16 head_dim-64 kernel of the UNet (experiment knob DDX_ATTN_KC=128: the former 128-key chunks)
+  // keys per chunk: what two {K, V} chunk buffers + the Q tile leave room for in 160 KB of LDS (bf16 head_dim 64, the UNet: 64 -- 172
+  // registers, two workgroups per CU; experiment knob DDX_ATTN_KC=128: 128-key chunks)
   static const int kc_knob = std::getenv("DDX_ATTN_KC") ? atoi(std::getenv("DDX_ATTN_KC")) : 64;
-  if constexpr (sizeof(T) == 2 && D == 64) {
-    if (kc_knob == 64) return launch_attn_kc<T, D, 64>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+  if constexpr (sizeof(T) == 2) {
+    if constexpr (D == 32) return launch_attn_kc<T, D, 128>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+    if constexpr (D == 64) {
+      if (kc_knob == 128) return launch_attn_kc<T, D, 128>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+    }
+    return launch_attn_kc<T, D, 64>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+  } else {
+    if constexpr (D == 32) return launch_attn_kc<T, D, 128>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+    if constexpr (D == 64) return launch_attn_kc<T, D, 64>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
+    return launch_attn_kc<T, D, 32>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
   }
-  return launch_attn_kc<T, D, 128>(qk, v, out, cs, B, Tn, heads, eps, s, qk_ld, v_ld, fold);
 }
 
 }  // namespace ddx

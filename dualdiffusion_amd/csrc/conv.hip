@@ -204,7 +204,7 @@ extern "C" int ddx_mpconv2d_path(const ddx_conv_desc* dp) {
   return conv_fwd_impl(d, nullptr, true);
 }
 
-// query: return the kernel the descriptor selects (1 scalar, 2 register-staged MFMA, 3 LDS-DMA, 4 small-M) instead of launching it
+// query: return the kernel the descriptor selects (1 scalar, 2 register-staged MFMA, 3 LDS-DMA, 4 small-M, 5 few-channel, 6 1x1 GEMM) instead of launching it
 static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) {
   if (d.epilogue != DDX_EPI_STORE && d.epilogue != DDX_EPI_MPSUM && d.epilogue != DDX_EPI_PIXELNORM) return set_error(DDX_ERR_ARG, "conv: epilogue");
   if (d.epilogue == DDX_EPI_PIXELNORM && (d.residual || d.out_act || d.out_scale || !(d.res_t > 0.f)))
@@ -233,12 +233,21 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
   }
   if (d.force_direct == 4) return set_error(DDX_ERR_UNSUPPORTED, "conv: the small-M kernel needs weights prepared with CK = 16");
   // the input convs (3x3 over 8 zero-padded channels, plain store + twin) have their own kernel
-  if (d.force_direct == 5 && !conv_few_supported(p, ks, dt)) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the few-input-channel kernel");
+  if (d.force_direct == 5 && (d.epilogue != DDX_EPI_STORE || !conv_few_supported(p, ks, dt)))
+    return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the few-input-channel kernel (3x3 over 8 padded channels, plain store + twin)");
   if ((d.force_direct == 0 || d.force_direct == 5) && d.epilogue == DDX_EPI_STORE && conv_few_supported(p, ks, dt)) {
     if (query) return 5;
     const double flops_f = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
     const double bytes_f = 2.0 * ((double)p.B * p.H * p.W * (p.Cin + (double)p.Cout * (d.out2 ? 2.0 : 1.0)));
     return dispatch([p](hipStream_t s) -> int { return launch_conv_few(p, s); }, stream, "conv3x3_few", flops_f, bytes_f);
+  }
+  // mid-size raw 1x1 layers (levels 2 / 3): 128 x 128 GEMM tiles on a deep LDS-DMA ring
+  if (d.force_direct == 6 && !conv_gemm_supported(p, ks, dt, false)) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the 1x1 GEMM kernel");
+  if (d.force_direct == 6 || (d.force_direct == 0 && !d.out2_linear && conv_gemm_supported(p, ks, dt, true))) {
+    if (query) return 6;
+    const double flops_g = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg;
+    const double bytes_g = 2.0 * ((double)p.B * p.H * p.W * (p.Cin + (double)p.Cout) + (double)p.Cout * p.Cg);
+    return dispatch([p](hipStream_t s) -> int { return launch_conv_gemm(p, s); }, stream, "conv1x1_gemm", flops_g, bytes_g);
   }
   const bool mfma = d.force_direct != 1 && conv_mfma_supported(p, ks, dt);
   static const bool dma_enabled = []() { const char* e = std::getenv("DDX_CONV_DMA"); return !e || e[0] != '0'; }();

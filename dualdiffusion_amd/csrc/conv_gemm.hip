@@ -1,0 +1,215 @@
+// 1x1 magnitude-preserving conv as a plain GEMM for the MID-SIZE layers of the UNet (levels 2 / 3 of the default model: 1376 ... 5504
+// pixels at B = 4; reference src/modules/unets/unet_edm2_b4.py:110-158: conv_skip over mp_cat, the merged attn_qk | attn_v conv).
+//
+// Why another kernel: between the wide LDS-DMA units (256 x 256, levels 0 / 1) and the small-M kernels these layers have too few
+// pixels x channels for 256-wide units to fill 256 CUs, and on 128 x 64 register-staged tiles they move 1.5 x the bytes through
+// L2 -> LDS, which is what bounds them (round 4: a CU sustains what it keeps in flight -- one 16 ... 24 KB stage per workgroup gave
+// ~45 GB/s per CU).  Here:
+//   * 128 pixels x 128 channels per workgroup (4 waves, 64 x 64 each: 4 fragment reads per 4 MFMAs), two workgroups per CU,
+//     one unit per workgroup (grid = units: 264 for the level-3 qkv conv, 258 for the level-2 skip over mp_cat);
+//   * 32-channel K stages by LDS-DMA into a ring of FOUR slots, THREE stages in flight per workgroup (counted vmcnt, raw
+//     barrier: a __syncthreads() would drain the queue), one barrier per stage;
+//   * rows are 64 bytes, 16-byte slots XOR-swizzled on the SOURCE address (conv_dma.hip's scheme) -- conflict-free ds_read_b128;
+//   * raw operands only (two sources of an mp_cat with the scales folded into the weights, `src0_alt` per channel tile), plain
+//     store (+ clip) epilogue through an LDS transpose (the layers served need nothing else).
+#include <algorithm>
+#include <cstdlib>
+
+#include "conv_params.hpp"
+
+namespace ddx {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kOob = 0x7fffff00;
+constexpr int GM = 128, GN = 128, GK = 32, NS = 4;
+constexpr int kStage = (GM + GN) * GK * 2;           // 16 KB
+constexpr int kRing = NS * kStage;                   // 64 KB
+constexpr int ES = GN + 4;                           // fp32 row stride of the epilogue tile
+constexpr int kSmem = GM * ES * 4 > kRing ? GM * ES * 4 : kRing;
+
+__device__ __forceinline__ void dma16(rsrc_t rs, int voff, int soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)std::min<size_t>(bytes, 0x7ffffff0u), 0x00020000);
+}
+__device__ __forceinline__ int swz(int r) { return (r >> 2) & 3; }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct GemmArgs { int M, MT, NT, by_n, nst; };
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  // unit decode: the tiles that share an operand meet on one XCD (observed block -> XCD map id % 8: speed only)
+  int mt, nt;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    if (a.by_n) { mt = slot % a.MT; nt = (slot / a.MT) * 8 + xcd; }
+    else { nt = slot % a.NT; mt = (slot / a.NT) * 8 + xcd; }
+    if (mt >= a.MT || nt >= a.NT) return;
+  }
+  const int m0 = mt * GM, n0 = nt * GN;
+
+  const void* s0p = (p.src0_alt && n0 < p.pro_rows) ? p.src0_alt : p.src0;
+  const rsrc_t rs0 = make_rsrc(s0p, (size_t)a.M * p.C0 * 2);
+  const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)a.M * p.C1 * 2) : rs0;
+  const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.nchunk * p.NgP * p.CK * 2);
+  const int ck_shift = __builtin_ctz(p.CK);
+
+  // ---- DMA bookkeeping: a stage is 8 activation pieces + 8 weight pieces of 1 KiB (16 rows x 64 B); wave w moves pieces w, w + 4
+  // of each.  Per lane: byte offsets of its row inside the tensors; the K advance is the scalar offset.
+  const int lrow = lane >> 2, lslot = lane & 3;
+  int av0[2], av1[2], bv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave + 4 * i) * 16 + lrow;
+    const int m = m0 + r;
+    const int sl = (lslot ^ swz(r)) * 16;
+    av0[i] = m < a.M ? m * p.C0 * 2 + sl : kOob;
+    av1[i] = m < a.M ? m * p.C1 * 2 + sl : kOob;
+    const int n = min(n0 + r, p.NgP - 1);   // rows past NgP only feed outputs that are never stored
+    bv[i] = ((n << ck_shift) * 2) + sl;
+  }
+  auto issue = [&](int s) {   // stage s -> ring slot s % NS
+    char* base = smem + (s & (NS - 1)) * kStage;
+    const int k0 = s * GK;
+    const bool first = k0 < p.C0;
+    const int soff_a = (first ? k0 : k0 - p.C0) * 2;
+    const int soff_b = ((((k0 >> ck_shift) * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave + 4 * i;
+      if (first) dma16(rs0, av0[i], soff_a, base + piece * 1024);
+      else dma16(rs1, av1[i], soff_a, base + piece * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(rsw, bv[i], soff_b, base + GM * GK * 2 + (wave + 4 * i) * 1024);
+  };
+
+  // ---- fragment read offsets inside a stage (bytes): weights = A operand (rows = output channels), activations = B (columns = pixels)
+  int xoff[2], woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wm * 64 + j * 32 + l31;
+    xoff[j] = r * 64 + ((khalf ^ swz(r)) << 4);
+    const int rw = wn * 64 + j * 32 + l31;
+    woff[j] = GM * GK * 2 + rw * 64 + ((khalf ^ swz(rw)) << 4);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nst = a.nst;
+  issue(0);
+  if (nst > 1) issue(1);
+  if (nst > 2) issue(2);
+  for (int s = 0; s < nst; ++s) {
+    // stage s has landed when at most the younger stages' pieces (4 per stage and wave) are outstanding
+    const int younger = min(nst - 1 - s, 2);
+    if (younger == 2) wait_vmcnt<8>();
+    else if (younger == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done reading stage s - 1, whose slot is refilled now
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 3 < nst) issue(s + 3);
+    const char* st = smem + (s & (NS - 1)) * kStage;
+    bf16x8 wf[2][2], xf[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        wf[ks][j] = *reinterpret_cast<const bf16x8*>(st + (woff[j] ^ (ks << 5)));
+        xf[ks][j] = *reinterpret_cast<const bf16x8*>(st + (xoff[j] ^ (ks << 5)));
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();   // (nothing in flight any more) every wave is done with the ring the output tile overlays
+
+  // ---- epilogue: accumulators (lane = one pixel, runs of 4 channels) -> LDS [pixel][channel] fp32 -> 8-byte bf16 stores on NHWC rows
+  float* sE = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ml = wm * 64 + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        f32x4 y4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y4[e] = acc[i][j][4 * k4 + e];
+        *reinterpret_cast<f32x4*>(sE + (size_t)ml * ES + wn * 64 + i * 32 + 8 * k4 + 4 * khalf) = y4;
+      }
+  }
+  __syncthreads();
+  bf16* out = reinterpret_cast<bf16*>(p.out);
+#pragma unroll
+  for (int it = 0; it < GM * (GN / 4) / 256; ++it) {
+    const int idx = tid + it * 256;
+    const int ml = idx >> 5, c4 = idx & 31;
+    const int m = m0 + ml, n = n0 + c4 * 4;
+    if (m >= a.M || n >= p.Ng) continue;
+    const f32x4 y4 = *reinterpret_cast<const f32x4*>(sE + (size_t)ml * ES + c4 * 4);
+    bf16x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = (bf16)(p.clip > 0.f ? fminf(fmaxf(y4[e], -p.clip), p.clip) : y4[e]);
+    *reinterpret_cast<bf16x4*>(out + (size_t)m * p.Cout + n) = ov;
+  }
+}
+
+}  // namespace
+
+// raw 1x1 layers, one group, plain store; `auto_pick`: also the size window where this kernel is the default choice
+bool conv_gemm_supported(const ConvParams& p, int ksize, int dtype, bool auto_pick) {
+  if (dtype != DDX_BF16 || ksize != 1 || p.G != 1) return false;
+  if (p.prologue != DDX_PRO_NONE || p.scale0 != 1.0f || (p.src1 && p.scale1 != 1.0f)) return false;
+  if (p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.layout) return false;
+  if (p.epilogue != DDX_EPI_STORE || p.out2 || p.out_act || p.out_cs) return false;
+  if (p.C0 % GK || (p.src1 && p.C1 % GK) || p.CK % GK || p.Cout % 4) return false;
+  if (p.src0_alt && (p.src1 || p.pro_rows <= 0 || p.pro_rows % GN)) return false;
+  const long M = (long)p.B * p.H * p.W;
+  if (M * std::max(p.C0, p.C1) * 2 >= 0x7fffff00l) return false;
+  if (!auto_pick) return true;
+  static const int knob = std::getenv("DDX_CONV_GEMM") ? atoi(std::getenv("DDX_CONV_GEMM")) : 1;
+  if (!knob) return false;
+  // units: at least half a round of the 512 slots, at most ~2 rounds (beyond that the 256-wide LDS-DMA units fill the chip)
+  const long units = (long)ceil_div((int)M, GM) * ceil_div(p.Ng, GN);
+  return p.Cin >= 256 && units >= 160 && units <= 1100;
+}
+
+int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
+  GemmArgs a{};
+  a.M = p.B * p.H * p.W;
+  a.MT = ceil_div(a.M, GM);
+  a.NT = ceil_div(p.Ng, GN);
+  a.nst = p.Cin / GK;
+  // which tile index is dealt over the XCDs: the one whose count splits more evenly into eight
+  const double imb_n = (double)ceil_div(a.NT, 8) * 8 / a.NT, imb_m = (double)ceil_div(a.MT, 8) * 8 / a.MT;
+  a.by_n = imb_n <= imb_m ? 1 : 0;
+  const int grid = a.by_n ? a.MT * round_up(a.NT, 8) : a.NT * round_up(a.MT, 8);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_gemm)");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv_gemm_kernel, dim3(grid), dim3(256), kSmem, s, p, a);
+  return check_launch("conv_gemm");
+}
+
+}  // namespace ddx

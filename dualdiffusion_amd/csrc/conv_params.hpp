@@ -64,6 +64,8 @@ bool conv_sm_supported(const ConvParams& p, int ksize, int dtype);  // conv_sm.h
 int launch_conv_sm(const ConvParams& p, int ksize, hipStream_t s);
 bool conv_few_supported(const ConvParams& p, int ksize, int dtype);  // conv_few.hip (3x3 over 8 zero-padded input channels: the input convs)
 int launch_conv_few(const ConvParams& p, hipStream_t s);
+bool conv_gemm_supported(const ConvParams& p, int ksize, int dtype, bool auto_pick);  // conv_gemm.hip (mid-size raw 1x1 layers: 128 x 128 GEMM tiles, deep LDS-DMA ring)
+int launch_conv_gemm(const ConvParams& p, hipStream_t s);
 size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize);  // per (unit, wave) channel sums of the DDX_EPI_SILU_BWD epilogue
 
 }  // namespace ddx

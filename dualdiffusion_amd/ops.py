@@ -93,7 +93,7 @@ def normalize_weights_(weight: torch.Tensor) -> None:
 # its real operands (heuristic choice, LDS-DMA kernel, every built tile / split-K configuration of the register-staged kernel)
 # and remembers the fastest per layer signature; later calls (the plan recording) ask for that kernel.  The heuristic stays
 # unless a candidate is at least 4 % faster.
-_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3, "sm": 4, "few": 5}
+_PATH_CODE = {"auto": 0, "direct": 1, "mfma": 2, "dma": 3, "sm": 4, "few": 5, "gemm": 6}
 _conv_choice: dict = {}
 _tuning = False
 
@@ -112,7 +112,8 @@ class tuning:
 
 def _conv_signature(d: "L.ConvDesc") -> tuple:
     return (d.B, d.H, d.W, d.C0, d.C1, d.Cout, d.groups, d.ksize, d.CK, d.resample, d.prologue, d.epilogue, d.dtype, d.out_act,
-            bool(d.chan_scale), bool(d.out_scale), bool(d.out2), d.pad_mode, d.prologue_rows, d.scale0 == 1.0, d.scale1 == 1.0, d.clip > 0)
+            bool(d.chan_scale), bool(d.out_scale), bool(d.out2), d.pad_mode, d.prologue_rows, d.scale0 == 1.0, d.scale1 == 1.0, d.clip > 0,
+            bool(d.src0_alt), d.out2_linear, d.residual_up)
 
 
 def _tune_conv(d: "L.ConvDesc") -> int:
@@ -180,6 +181,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | "sm" (small-M weight-streaming kernel; weights prepared with CK = 16, which also selects it automatically)
     | "few" (3x3 over 8 zero-padded input channels: the input convs; the automatic choice where it applies)
+    | "gemm" (mid-size raw 1x1 layers: 128 x 128 GEMM tiles on a deep LDS-DMA ring; the automatic choice inside its size window)
     | an integer force_direct code (16 + 3 * tile + k: one tile / split-K configuration of the register-staged kernel).
     out_act: store mp_silu(y * out_scale[b, cout]) instead of y; out2: also store mp_silu(out2_scale * y_final)
     (with out_act=False and out_scale given: out = y and out2 = mp_silu(out2_scale * out_scale[b, cout] * y)).
@@ -198,6 +200,10 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     C1 = src1.shape[3] if src1 is not None else 0
     if out is None:
         out = torch.empty(B, H, W, pw.Cout, dtype=src0.dtype, device=src0.device)
+    if residual is not None:
+        want = (B, H // 2, W // 2, pw.Cout) if residual_up else (B, H, W, pw.Cout)
+        if tuple(residual.shape) != want:
+            raise L.DDXError(f"conv2d: residual has shape {tuple(residual.shape)}, expected {want} (residual_up={residual_up})")
     d = L.ConvDesc(src0=ptr(src0), src1=ptr(src1), chan_scale=ptr(chan_scale), wp=ptr(pw.wp), residual=ptr(residual), out=ptr(out),
                    B=B, H=H, W=W, C0=C0, C1=C1, Cout=pw.Cout, groups=pw.groups, ksize=pw.ksize, CK=pw.CK, resample=resample,
                    prologue=prologue, epilogue=L.EPI_PIXELNORM if pixelnorm_eps > 0 else (L.EPI_MPSUM if residual is not None else L.EPI_STORE),

@@ -126,6 +126,7 @@ typedef struct {
                              * 4 small-M weight-streaming MFMA (conv_sm.hip; needs wp prepared with CK = 16 -- with CK = 16 it is
                              * also the automatic choice, the layout is its own),
                              * 5 the few-input-channel kernel (conv_few.hip: 3x3 over 8 zero-padded channels, plain store + twin),
+                             * 6 the mid-size 1x1 GEMM kernel (conv_gemm.hip: raw operands, one group, plain store; 128 x 128 tiles),
                              * 16 + 3 * tile + k: register-staged MFMA with tile 0..3 = 256x64, 256x32, 128x64, 128x32 (pixels x
                              * channels) and split-K 1 << k (k = 0..2); DDX_ERR_UNSUPPORTED when the combination is not built.
                              * Used by plan-time autotuning (the host times the candidates once per layer shape). */
@@ -172,7 +173,7 @@ typedef struct {
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
 /* Which kernel ddx_mpconv2d_fwd would run for this descriptor (no launch): 1 scalar, 2 register-staged MFMA, 3 LDS-DMA MFMA,
- * 4 small-M, 5 few-input-channel; negative = error code.  The host asks before it decides the layout of a tensor (`layout` is ignored here). */
+ * 4 small-M, 5 few-input-channel, 6 mid-size 1x1 GEMM; negative = error code.  The host asks before it decides the layout of a tensor (`layout` is ignored here). */
 int ddx_mpconv2d_path(const ddx_conv_desc* d);
 /* CK the library wants for a conv of this shape (call before wprep).  npix = B*H*W of the output (0 = unknown). */
 int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix);

@@ -150,8 +150,6 @@ def test_attention(shape, dtype):
     """shape = (B, H, W, heads, d); T = H*W covers <1 chunk, exactly 128-multiples and ragged tails (344, 86, 150, 400, 7)."""
     ops = _ops()
     B, H, W, heads, d = shape
-    if d == 128 and dtype == torch.float32:
-        pytest.skip("head_dim 128 in fp32 exceeds LDS (unsupported by design)")
     C = heads * d
     g = torch.Generator().manual_seed(B * 1000 + H * W)
     qk = _round(torch.randn(B, 2 * C, H, W, generator=g) * 2.0, dtype)        # reference order (head, d, s)
@@ -1042,6 +1040,59 @@ def test_conv_sm(name):
     # what the small-M kernels do not serve is refused, not mis-computed
     with pytest.raises(Exception):
         ops.conv2d(to_nhwc(a, dtype), pw, prologue=L.PRO_SILU, **common)
+
+
+GEMM_CASES = {
+    # name: (B, H, W, C0, C1, Cout, special)
+    "qkv_alt": (2, 4, 86, 256, 0, 384, "alt_rows"),     # 688 pixels (ragged last pixel tile), the first 256 output rows read the x * c twin
+    "cat": (1, 8, 43, 256, 128, 192, None),            # two sources, ragged channel tile (192 = 128 + 64)
+    "ragged": (1, 5, 27, 128, 0, 132, None),           # 135 pixels, 132 channels: almost empty second tiles both ways
+    "l2_like": (1, 8, 172, 512, 256, 256, None),       # 1376 pixels, K = 768 = 24 stages (ring wraps six times)
+    "short_k": (1, 4, 40, 64, 0, 128, None),           # two stages only (prologue shorter than the ring)
+}
+
+
+@pytest.mark.parametrize("name", list(GEMM_CASES))
+def test_conv_gemm(name):
+    """Mid-size 1x1 GEMM kernel (conv_gemm.hip: 128 x 128 tiles, four-slot LDS-DMA ring) against the oracle conv on the same bf16 operands
+    and against the register-staged kernel."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dtype = torch.bfloat16
+    B, H, W, C0, C1, Cout, special = GEMM_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    a = _round(torch.randn(B, C0, H, W, generator=g) * 1.3, dtype)
+    b = _round(torch.randn(B, C1, H, W, generator=g), dtype) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 1, 1, generator=g)
+    x = torch.cat([a, b], 1) if C1 else a
+    wq = _round(O.prepared_weight(w), dtype)
+    kw, kw_old = {}, {}
+    if special == "alt_rows":
+        rows = 256
+        cin_scale = torch.rand(B, C0, generator=g) + 0.5
+        xs = _round(x * cin_scale[:, :, None, None], dtype)
+        ref = torch.cat([torch.nn.functional.conv2d(xs, wq[:rows]), torch.nn.functional.conv2d(x, wq[rows:])], 1)
+        kw = dict(src0_alt=to_nhwc(xs, dtype), prologue_rows=rows)
+        kw_old = dict(prologue=L.PRO_SCALE, chan_scale=cin_scale.cuda(), prologue_rows=rows)
+    else:
+        ref = torch.nn.functional.conv2d(x, wq)
+    pw = ops.wprep(w.cuda(), 1, dtype, npix=B * H * W)
+    common = dict(src1=to_nhwc(b, dtype) if C1 else None)
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=dtype)
+    ops.conv2d(to_nhwc(a, dtype), pw, path="gemm", out=out, **common, **kw)
+    old = ops.conv2d(to_nhwc(a, dtype), pw, path="mfma", **common, **kw_old)
+    torch.cuda.synchronize()
+    e, e_old = rel_l2(to_nchw(out), ref), rel_l2(to_nchw(old), ref)
+    print(f"conv_gemm {name}: {e:.3e} (register-staged kernel {e_old:.3e})")
+    assert torch.isfinite(out.float()).all()
+    assert e < TOL[dtype], (name, e)
+    assert rel_l2(to_nchw(out), to_nchw(old)) < 6e-3
+    # deterministic, and clip is the one epilogue piece it applies
+    out2 = ops.conv2d(to_nhwc(a, dtype), pw, path="gemm", clip=0.5, **common, **kw)
+    assert torch.equal(out2, out.clamp(-0.5, 0.5))
+    # what it does not serve is refused, not mis-computed
+    with pytest.raises(Exception):
+        ops.conv2d(to_nhwc(a, dtype), pw, path="gemm", residual=out, res_t=0.3, **common, **kw)
 
 
 @pytest.mark.parametrize("path,dtype,shape", [

@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--cases", default=",".join(CASES))
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--path", default="auto", help="auto | mfma | dma | sm | dma16 (LDS-DMA kernel on channel-blocked tensors) | both; a+b runs several")
+    ap.add_argument("--path", default="auto", help="auto | mfma | dma | sm | gemm | dma16 (LDS-DMA kernel on channel-blocked tensors) | both; a+b runs several")
     ap.add_argument("--cold", type=int, default=0, help="N > 0: cycle through N distinct prepared-weight buffers inside the timed graph (weights stream from HBM as in the network, instead of staying cache-resident)")
     ap.add_argument("--epi", default="plain", help="plain | real (conv_res0: activated output with channel scales; conv_res1: residual + activated twin)")
     a = ap.parse_args()
