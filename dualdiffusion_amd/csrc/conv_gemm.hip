@@ -23,11 +23,9 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int kOob = 0x7fffff00;
-constexpr int GM = 128, GN = 128, GK = 32, NS = 4;
-constexpr int kStage = (GM + GN) * GK * 2;           // 16 KB
-constexpr int kRing = NS * kStage;                   // 64 KB
+constexpr int GM = 128, GN = 128;
 constexpr int ES = GN + 4;                           // fp32 row stride of the epilogue tile
-constexpr int kSmem = GM * ES * 4 > kRing ? GM * ES * 4 : kRing;
+constexpr int smem_bytes(int gk, int ns) { return GM * ES * 4 > ns * (GM + GN) * gk * 2 ? GM * ES * 4 : ns * (GM + GN) * gk * 2; }
 
 __device__ __forceinline__ void dma16(rsrc_t rs, int voff, int soff, void* l) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)l, 16, voff, soff, 0, 0);
@@ -35,12 +33,19 @@ __device__ __forceinline__ void dma16(rsrc_t rs, int voff, int soff, void* l) {
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)std::min<size_t>(bytes, 0x7ffffff0u), 0x00020000);
 }
-__device__ __forceinline__ int swz(int r) { return (r >> 2) & 3; }
+// 16-byte slot swizzle of LDS row r (conv_dma.hip's DmaGeom::swz): 64-byte rows (r >> 2) & 3, 128-byte rows (r >> 1) & 7
+template <int GK> __device__ __forceinline__ int swz(int r) { return GK == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct GemmArgs { int M, MT, NT, by_n, nst; };
 
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, const GemmArgs a) {
+// GK = channels per K stage (LDS rows of 2 GK bytes), NS = ring slots (NS - 1 stages in flight)
+template <int GK, int NS>
+__global__ __launch_bounds__(256, smem_bytes(GK, NS) <= 80 * 1024 ? 2 : 1) void conv_gemm_kernel(const ConvParams p, const GemmArgs a) {
+  constexpr int kStage = (GM + GN) * GK * 2;
+  constexpr int RB = GK * 2, LPR = RB / 16, RPW = 1024 / RB;      // bytes per row, 16-byte slots per row, rows per DMA instruction
+  constexpr int PPW = GM / RPW / 4;                               // pieces per wave and operand
+  constexpr int KS = GK / 16;                                     // MFMA k-steps per stage
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,34 +67,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.nchunk * p.NgP * p.CK * 2);
   const int ck_shift = __builtin_ctz(p.CK);
 
-  // ---- DMA bookkeeping: a stage is 8 activation pieces + 8 weight pieces of 1 KiB (16 rows x 64 B); wave w moves pieces w, w + 4
-  // of each.  Per lane: byte offsets of its row inside the tensors; the K advance is the scalar offset.
-  const int lrow = lane >> 2, lslot = lane & 3;
-  int av0[2], av1[2], bv[2];
+  // ---- DMA bookkeeping: a stage is GM / RPW activation pieces + as many weight pieces of 1 KiB (RPW rows of RB bytes); wave w moves
+  // pieces w, w + 4, ... of each.  Per lane: byte offsets of its row inside the tensors; the K advance is the scalar offset.
+  const int lrow = lane / LPR, lslot = lane % LPR;
+  int av0[PPW], av1[PPW], bv[PPW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (wave + 4 * i) * 16 + lrow;
+  for (int i = 0; i < PPW; ++i) {
+    const int r = (wave + 4 * i) * RPW + lrow;
     const int m = m0 + r;
-    const int sl = (lslot ^ swz(r)) * 16;
+    const int sl = (lslot ^ swz<GK>(r)) * 16;
     av0[i] = m < a.M ? m * p.C0 * 2 + sl : kOob;
     av1[i] = m < a.M ? m * p.C1 * 2 + sl : kOob;
     const int n = min(n0 + r, p.NgP - 1);   // rows past NgP only feed outputs that are never stored
     bv[i] = ((n << ck_shift) * 2) + sl;
   }
   auto issue = [&](int s) {   // stage s -> ring slot s % NS
-    char* base = smem + (s & (NS - 1)) * kStage;
+    char* base = smem + (s % NS) * kStage;
     const int k0 = s * GK;
     const bool first = k0 < p.C0;
     const int soff_a = (first ? k0 : k0 - p.C0) * 2;
     const int soff_b = ((((k0 >> ck_shift) * p.NgP) << ck_shift) + (k0 & (p.CK - 1))) * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PPW; ++i) {
       const int piece = wave + 4 * i;
       if (first) dma16(rs0, av0[i], soff_a, base + piece * 1024);
       else dma16(rs1, av1[i], soff_a, base + piece * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(rsw, bv[i], soff_b, base + GM * GK * 2 + (wave + 4 * i) * 1024);
+    for (int i = 0; i < PPW; ++i) dma16(rsw, bv[i], soff_b, base + GM * RB + (wave + 4 * i) * 1024);
   };
 
   // ---- fragment read offsets inside a stage (bytes): weights = A operand (rows = output channels), activations = B (columns = pixels)
@@ -97,9 +102,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int r = wm * 64 + j * 32 + l31;
-    xoff[j] = r * 64 + ((khalf ^ swz(r)) << 4);
+    xoff[j] = r * RB + ((khalf ^ swz<GK>(r)) << 4);    // k-step ks adds 2 ks to the slot: XOR commutes below
     const int rw = wn * 64 + j * 32 + l31;
-    woff[j] = GM * GK * 2 + rw * 64 + ((khalf ^ swz(rw)) << 4);
+    woff[j] = GM * RB + rw * RB + ((khalf ^ swz<GK>(rw)) << 4);
   }
 
   f32x16 acc[2][2];
@@ -111,33 +116,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nst = a.nst;
-  issue(0);
-  if (nst > 1) issue(1);
-  if (nst > 2) issue(2);
+  static_assert(NS >= 2 && NS <= 4, "ring of two to four slots (deeper rings measured 50 % slower: the LDS-DMA queue stalls the issuing waves)");
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nst) issue(i);
   for (int s = 0; s < nst; ++s) {
-    // stage s has landed when at most the younger stages' pieces (4 per stage and wave) are outstanding
-    const int younger = min(nst - 1 - s, 2);
-    if (younger == 2) wait_vmcnt<8>();
-    else if (younger == 1) wait_vmcnt<4>();
+    // stage s has landed when at most the younger stages' pieces (2 PPW per stage and wave) are outstanding
+    const int younger = min(nst - 1 - s, NS - 2);
+    if (younger >= 2) wait_vmcnt<2 * 2 * PPW>();
+    else if (younger == 1) wait_vmcnt<2 * PPW>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // ... for every wave; and every wave is done reading stage s - 1, whose slot is refilled now
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 3 < nst) issue(s + 3);
-    const char* st = smem + (s & (NS - 1)) * kStage;
-    bf16x8 wf[2][2], xf[2][2];
+    if (s + NS - 1 < nst) issue(s + NS - 1);
+    const char* st = smem + (s % NS) * kStage;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 wf[2], xf[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        wf[ks][j] = *reinterpret_cast<const bf16x8*>(st + (woff[j] ^ (ks << 5)));
-        xf[ks][j] = *reinterpret_cast<const bf16x8*>(st + (xoff[j] ^ (ks << 5)));
+        wf[j] = *reinterpret_cast<const bf16x8*>(st + (woff[j] ^ (ks << 5)));
+        xf[j] = *reinterpret_cast<const bf16x8*>(st + (xoff[j] ^ (ks << 5)));
       }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][i], xf[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
   }
   __syncthreads();   // (nothing in flight any more) every wave is done with the ring the output tile overlays
 
@@ -172,6 +177,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvParams p, c
   }
 }
 
+template <int GK, int NS>
+int launch_cfg(const ConvParams& p, GemmArgs a, int grid, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<GK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(GK, NS)) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_gemm)");
+    attr_done = true;
+  }
+  a.nst = p.Cin / GK;
+  hipLaunchKernelGGL((conv_gemm_kernel<GK, NS>), dim3(grid), dim3(256), smem_bytes(GK, NS), s, p, a);
+  return check_launch("conv_gemm");
+}
+
 }  // namespace
 
 // raw 1x1 layers, one group, plain store; `auto_pick`: also the size window where this kernel is the default choice
@@ -180,16 +198,17 @@ bool conv_gemm_supported(const ConvParams& p, int ksize, int dtype, bool auto_pi
   if (p.prologue != DDX_PRO_NONE || p.scale0 != 1.0f || (p.src1 && p.scale1 != 1.0f)) return false;
   if (p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.layout) return false;
   if (p.epilogue != DDX_EPI_STORE || p.out2 || p.out_act || p.out_cs) return false;
-  if (p.C0 % GK || (p.src1 && p.C1 % GK) || p.CK % GK || p.Cout % 4) return false;
+  if (p.C0 % 32 || (p.src1 && p.C1 % 32) || p.CK % 32 || p.Cout % 4) return false;
   if (p.src0_alt && (p.src1 || p.pro_rows <= 0 || p.pro_rows % GN)) return false;
   const long M = (long)p.B * p.H * p.W;
   if (M * std::max(p.C0, p.C1) * 2 >= 0x7fffff00l) return false;
   if (!auto_pick) return true;
   static const int knob = std::getenv("DDX_CONV_GEMM") ? atoi(std::getenv("DDX_CONV_GEMM")) : 1;
   if (!knob) return false;
-  // units: at least half a round of the 512 slots, at most ~2 rounds (beyond that the 256-wide LDS-DMA units fill the chip)
+  // units: from ~2/3 of the CUs to ~1.5 per CU (measured, tools/conv_bench.py --path gemm+auto with DDX_CONV_GEMM=0: level-3 qkv 22.1 ->
+  // 18.6 us, level-2 skip convs 17.2 -> 12.3, 22.2 -> 15.4, 31.8 -> 28.8 us; from 688 units (level 1) the 256-wide LDS-DMA units win)
   const long units = (long)ceil_div((int)M, GM) * ceil_div(p.Ng, GN);
-  return p.Cin >= 256 && units >= 160 && units <= 1100;
+  return p.Cin >= 256 && units >= 160 && units <= 400;
 }
 
 int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
@@ -197,19 +216,24 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   a.M = p.B * p.H * p.W;
   a.MT = ceil_div(a.M, GM);
   a.NT = ceil_div(p.Ng, GN);
-  a.nst = p.Cin / GK;
   // which tile index is dealt over the XCDs: the one whose count splits more evenly into eight
   const double imb_n = (double)ceil_div(a.NT, 8) * 8 / a.NT, imb_m = (double)ceil_div(a.MT, 8) * 8 / a.MT;
   a.by_n = imb_n <= imb_m ? 1 : 0;
   const int grid = a.by_n ? a.MT * round_up(a.NT, 8) : a.NT * round_up(a.MT, 8);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) != hipSuccess)
-      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_gemm)");
-    attr_done = true;
+  // stage width / ring depth.  Measured (MI355X, tools/conv_bench.py --path gemm, DDX_GEMM_CFG=GK*10+NS): see DESIGN.md section 6d
+  static const int knob = std::getenv("DDX_GEMM_CFG") ? atoi(std::getenv("DDX_GEMM_CFG")) : 0;
+  const int cfg = knob ? knob : 642;
+  const int gk = cfg / 10;
+  if (gk != 32 && gk != 64) return set_error(DDX_ERR_ARG, "conv_gemm: DDX_GEMM_CFG");
+  if (p.C0 % gk || (p.src1 && p.C1 % gk) || p.CK % gk) return launch_cfg<32, 2>(p, a, grid, s);
+  switch (cfg) {
+    case 322: return launch_cfg<32, 2>(p, a, grid, s);
+    case 323: return launch_cfg<32, 3>(p, a, grid, s);
+    case 324: return launch_cfg<32, 4>(p, a, grid, s);
+    case 642: return launch_cfg<64, 2>(p, a, grid, s);
+    case 643: return launch_cfg<64, 3>(p, a, grid, s);
+    default: return set_error(DDX_ERR_ARG, "conv_gemm: DDX_GEMM_CFG");
   }
-  hipLaunchKernelGGL(conv_gemm_kernel, dim3(grid), dim3(256), kSmem, s, p, a);
-  return check_launch("conv_gemm");
 }
 
 }  // namespace ddx

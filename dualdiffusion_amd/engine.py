@@ -55,9 +55,9 @@ SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
 RES_UP = os.environ.get("DDX_RES_UP", "1") != "0"
 # encoder blocks: normalize(conv_skip(x)) and its activated twin from the skip conv's epilogue where one unit holds all channels of a pixel
 FUSE_PIXELNORM = os.environ.get("DDX_FUSE_PIXELNORM", "1") != "0"
-# attention blocks outside the small-M regime, large batches: x * c_qk as a materialised twin + the merged qkv conv on the wide 1x1 units of
-# the LDS-DMA kernel (0 = never)
-QKV_TWIN_MIN_PIXELS = int(os.environ.get("DDX_QKV_TWIN_MIN_PIXELS", "2048"))
+# attention blocks outside the small-M regime: x * c_qk as a materialised twin (written by conv_res1 where it runs on the register-staged
+# kernel) + the merged qkv conv on the 1x1 GEMM kernel / the wide 1x1 units of the LDS-DMA kernel (0 = never)
+QKV_TWIN_MIN_PIXELS = int(os.environ.get("DDX_QKV_TWIN_MIN_PIXELS", "1024"))
 PIXELNORM_EPS = 1e-4     # eps of normalize() (mp_tools.py:42-49), the default of ops.pixelnorm
 
 
@@ -302,7 +302,7 @@ class PlanBuilder:
         if self.training or self.dt != torch.bfloat16 or QKV_TWIN_MIN_PIXELS <= 0 or npix < QKV_TWIN_MIN_PIXELS:
             return False
         try:
-            return ops.conv2d(xo, pw_qkv, src0_alt=xo, prologue_rows=2 * cout, out=qkv, query=True) == 3
+            return ops.conv2d(xo, pw_qkv, src0_alt=xo, prologue_rows=2 * cout, out=qkv, query=True) in (3, 6)
         except Exception:
             return False
 
