@@ -260,6 +260,9 @@ def main() -> None:
                     "kernel": dom[0], "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
                     "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms / total_ms, 3),
                     "step_tflops": round(B * FLOP_PER_SAMPLE / (elapsed / a.steps) / 1e12, 1),
+                    # model FLOPs of the reference forward (489.3 GFLOP per sample), not executed MACs: the plan runs the up blocks' skip
+                    # convs before the resample (~3 % fewer MACs), so this is throughput in the reference's units, not hardware utilisation
+                    "flops": "model",
                     "families_ms": {k: round(v[3], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][3])}}
         if a.layer_table:
             for i, (tag, fl_, by_, ms_) in enumerate(prof):

@@ -140,9 +140,15 @@ class LinearJob(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
+# ctypes mirrors in the order of ddx_abi_sizeof() (include/ddx_hip.h); tests/test_abi.py compares sizes and tail offsets with the library
+ABI_MIRRORS = [WPrepDesc, ConvDesc, DgradActDesc, WgradDesc, LinearBwdJob, WPathJob, LinearJob, MelStftDesc, MsMelDesc, BgemmDesc, MssDesc,
+               OptimJob, OptimJobEx]
+
 PROTOTYPES = {
     "ddx_version": (C.c_char_p, []),
     "ddx_last_error": (C.c_char_p, []),
+    "ddx_abi_sizeof": (C.c_int64, [C.c_int32]),
+    "ddx_abi_offsetof_tail": (C.c_int64, [C.c_int32]),
     "ddx_wprep_bytes": (C.c_size_t, [C.c_int32] * 6),
     "ddx_mpconv_wprep": (C.c_int, [C.POINTER(WPrepDesc), C.c_void_p]),
     "ddx_normalize_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),

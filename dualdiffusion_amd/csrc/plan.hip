@@ -62,6 +62,45 @@ int dispatch(LaunchFn&& fn, ddx_stream stream, const char* tag, double flops, do
 }  // namespace ddx
 
 extern "C" const char* ddx_version(void) { return "libddx_hip 0.1 (gfx950)"; }
+
+// sizeof / offset of the last field of the header's descriptor structs as compiled (bindings check their mirrors against these)
+#include <cstddef>
+extern "C" int64_t ddx_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(ddx_wprep_desc);
+    case 1: return sizeof(ddx_conv_desc);
+    case 2: return sizeof(ddx_dgrad_act_desc);
+    case 3: return sizeof(ddx_wgrad_desc);
+    case 4: return sizeof(ddx_linear_bwd_job);
+    case 5: return sizeof(ddx_wpath_job);
+    case 6: return sizeof(ddx_linear_job);
+    case 7: return sizeof(ddx_melstft_desc);
+    case 8: return sizeof(ddx_msmel_desc);
+    case 9: return sizeof(ddx_bgemm_desc);
+    case 10: return sizeof(ddx_mss_desc);
+    case 11: return sizeof(ddx_optim_job);
+    case 12: return sizeof(ddx_optim_job_ex);
+    default: return -1;
+  }
+}
+extern "C" int64_t ddx_abi_offsetof_tail(int32_t which) {
+  switch (which) {
+    case 0: return offsetof(ddx_wprep_desc, rows_total);
+    case 1: return offsetof(ddx_conv_desc, residual_up);
+    case 2: return offsetof(ddx_dgrad_act_desc, scale1);
+    case 3: return offsetof(ddx_wgrad_desc, accumulate);
+    case 4: return offsetof(ddx_linear_bwd_job, groups);
+    case 5: return offsetof(ddx_wpath_job, in_scale1);
+    case 6: return offsetof(ddx_linear_job, normalize);
+    case 7: return offsetof(ddx_melstft_desc, scale);
+    case 8: return offsetof(ddx_msmel_desc, offset);
+    case 9: return offsetof(ddx_bgemm_desc, alpha);
+    case 10: return offsetof(ddx_mss_desc, loss_scale);
+    case 11: return offsetof(ddx_optim_job, n);
+    case 12: return offsetof(ddx_optim_job_ex, reserved);
+    default: return -1;
+  }
+}
 extern "C" const char* ddx_last_error(void) { return ddx::g_last_error.c_str(); }
 
 extern "C" ddx_plan* ddx_plan_begin(void) {

@@ -649,6 +649,14 @@ int ddx_plan_profile(ddx_plan* p, ddx_stream stream, int reps, float* ms_out);
 int ddx_plan_include(const ddx_plan* src);
 void ddx_plan_destroy(ddx_plan* p);
 
+/* sizeof() of the descriptor structs of this header as the library was compiled, so that a binding can check its mirrors against
+ * the binary instead of against hand-counted bytes (tests/test_abi.py does): which = 0 ddx_wprep_desc, 1 ddx_conv_desc,
+ * 2 ddx_dgrad_act_desc, 3 ddx_wgrad_desc, 4 ddx_linear_bwd_job, 5 ddx_wpath_job, 6 ddx_linear_job, 7 ddx_melstft_desc, 8 ddx_msmel_desc,
+ * 9 ddx_bgemm_desc, 10 ddx_mss_desc, 11 ddx_optim_job, 12 ddx_optim_job_ex; -1 for any other code.  ddx_abi_offsetof_tail(which) is the
+ * offset of the LAST field of the same struct (catches a mirror that is one trailing field short inside the tail padding). */
+int64_t ddx_abi_sizeof(int32_t which);
+int64_t ddx_abi_offsetof_tail(int32_t which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,19 @@ def test_descriptor_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.LinearJob) == 3 * 8 + 2 * 4 + 4 * 4
     lib = _lib.lib() if os.path.isfile(_lib.LIB_PATH) else None
     if lib is not None:
+        # every mirror against the COMPILED header: size and the offset of the last field (a mirror one trailing int32 short can
+        # hide inside the tail padding of an equal sizeof)
+        for which, mirror in enumerate(_lib.ABI_MIRRORS):
+            assert lib.ddx_abi_sizeof(which) == ctypes.sizeof(mirror), (which, mirror.__name__)
+            last = mirror._fields_[-1][0]
+            assert lib.ddx_abi_offsetof_tail(which) == getattr(mirror, last).offset, (which, mirror.__name__, last)
+        assert lib.ddx_abi_sizeof(len(_lib.ABI_MIRRORS)) == -1
+        # the reference-side binding printed in INTEGRATION.md section 2 is the same struct
+        doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+        block = doc[doc.index("class ConvDesc(C.Structure)"):]
+        block = block[:block.index("_lib.ddx_mpconv2d_fwd.argtypes")]
+        doc_fields = re.findall(r'\("([a-z0-9_A-Z]+)",\s*C\.(c_[a-z0-9_]+)\)', block)
+        assert [(n, getattr(ctypes, t)) for n, t in doc_fields] == [(n, t) for n, t in _lib.ConvDesc._fields_]
         # wprep byte count: groups * ceil(Cg/CK) * taps * roundup(Ng,32) * CK * sizeof
         assert lib.ddx_wprep_bytes(512, 32, 3, 8, 32, _lib.DDX_BF16) == 8 * 1 * 9 * 64 * 32 * 2
         assert lib.ddx_wprep_bytes(4, 256, 3, 1, 32, _lib.DDX_F32) == 1 * 8 * 9 * 32 * 32 * 4
