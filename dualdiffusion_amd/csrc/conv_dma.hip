@@ -1045,14 +1045,11 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   const long total = (long)p.B * p.tiles_h * p.tiles_w * ntile_n * p.G;
   int grid = (int)std::min<long>(total, GEO::NW == 4 ? 512 : 256);  // persistent: every CU holds 8 waves
   if (WS) grid = 512;   // (the launcher checked: 512 % (8 * combos) == 0)
-  static const int grid_knob = getenv("DDX_DMA_GRID") ? atoi(getenv("DDX_DMA_GRID")) : 0;   // experiment knob: persistent grid size
-  if (grid_knob > 0) grid = (int)std::min<long>(total, grid_knob);
   // XCD-aware unit order where it was measured to cut HBM fetches: 3x3 layers whose group slice of a pixel is half a cache
   // line (Cg = 32: -39 % FETCH_SIZE) or whose unit covers a whole group's 32 output channels (-16 %).  Elsewhere the plain
   // order already keeps a pixel tile on one XCD (B * tiles divisible by 8) and the contiguous order fetched 20-100 % more.
-  static const int xcd_knob = getenv("DDX_DMA_XCD") ? atoi(getenv("DDX_DMA_XCD")) : 1;
   int per_xcd = 0;
-  if (!EB && KS == 3 && WN == 1 && xcd_knob && total >= 64 && (xcd_knob == 2 || p.Cg <= 32 || p.Ng <= 32)) {
+  if (!EB && KS == 3 && WN == 1 && total >= 64 && (p.Cg <= 32 || p.Ng <= 32)) {
     grid &= ~7;
     per_xcd = (int)((total + 7) / 8);
   }
@@ -1114,10 +1111,9 @@ int launch_dma_pcs(const ConvParams& p, hipStream_t s) {
 // which resident variant serves the layer: 0 none, else 1 + (NF - 1) + 2 * (NK == 4).  Layers whose epilogue is the register
 // epilogue (plain / clipped / activated store into a channel-blocked output: the conv_res0 type) -- measured -10 ... -25 % there
 // (tools/conv_bench.py --cases dma3 --epi real --path dma16); the residual + twin layers stay on the 4-wave kernels (the resident
-// mode with their LDS-patch epilogue measured 0 ... +7 %: built, measured, removed).  DDX_DMA_RES=0 switches the mode off.
+// mode with their LDS-patch epilogue measured 0 ... +7 %: built, measured, removed).
 int dma_res_variant(const ConvParams& p, int TH, int TW) {
-  static const int knob = std::getenv("DDX_DMA_RES") ? atoi(std::getenv("DDX_DMA_RES")) : 1;
-  if (!knob || p.epilogue != DDX_EPI_STORE || p.out2 || !(p.layout & 4) || p.Ng % 16 || p.Cout % 16 || TH != 8 || TW != 32) return 0;
+  if (p.epilogue != DDX_EPI_STORE || p.out2 || !(p.layout & 4) || p.Ng % 16 || p.Cout % 16 || TH != 8 || TW != 32) return 0;
   const int nk = p.Cg / 16;
   if (p.Cg % 16 || (nk != 2 && nk != 4)) return 0;
   const int bn = p.Ng <= 32 ? 32 : 64, nf = bn / 32;
@@ -1132,8 +1128,6 @@ int dma_res_variant(const ConvParams& p, int TH, int TW) {
 // 1x1 layers with >= 192 output channels per group run as 256 x 256 GEMM tiles (8 waves) when that still leaves
 // enough units for the 256 CUs
 bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
-  static const int knob = std::getenv("DDX_DMA_WIDE") ? atoi(std::getenv("DDX_DMA_WIDE")) : -1;   // experiment knob: 0 never, 1 default rule
-  if (knob == 0) return false;
   return p.Ng >= 192 && pixel_tiles * ceil_div(p.Ng, 256) >= 128;
 }
 
@@ -1142,10 +1136,9 @@ bool dma_wide_1x1(const ConvParams& p, long pixel_tiles) {
 // 256 persistent workgroups: units = ceil(M / bm) * ceil(Ng / 256) * G run in ceil(units / 256) rounds of bm pixels each (the
 // 192-pixel unit reads 5 fragments per 6 MFMAs instead of 6 per 8: +5 %).  88064 pixels x 256 channels: 344 units of 256 pixels = 2
 // rounds (512 pixel-times) against 459 of 192 = 2 rounds (384); 22016 x 512: 172 units / 256 CUs against 230 / 256.
-// Returns the unit's pixel count (256 | 192 | 96; -96 = the 96-pixel x 512-channel pixel-norm unit) or 0 (2-D tiles).  DDX_DMA_FLAT=0 off, =256 | 192 forces a unit size.
+// Returns the unit's pixel count (256 | 192 | 96; -96 = the 96-pixel x 512-channel pixel-norm unit) or 0 (2-D tiles).
 int dma_flat_1x1_bm(const ConvParams& p) {
-  static const int knob = std::getenv("DDX_DMA_FLAT") ? atoi(std::getenv("DDX_DMA_FLAT")) : 1;
-  if (!knob || p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
+  if (p.resample != DDX_RESAMPLE_KEEP || p.reflect_w || p.swap1 || p.paired || p.res_up || p.layout) return 0;
   if (p.out_cs && p.B > 1) return 0;
   if (p.src0_alt && (p.src1 || p.pro_rows <= 0 || p.pro_rows % 256 || p.G != 1)) return 0;   // a unit's 256 channels read ONE source
   if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM && p.epilogue != DDX_EPI_PIXELNORM) return 0;
@@ -1156,14 +1149,13 @@ int dma_flat_1x1_bm(const ConvParams& p) {
   // pixel norm over 257 ... 512 channels: units of 96 pixels x 512 channels (eight waves of 64 channels each).  Every unit streams the
   // whole weight matrix for its 96 pixels: worth it from 512 input channels (level-1 512 -> 512: 52 -> 39 us with the norm; 256 -> 512
   // measured 36.9 us fused against 16.5 + 20 apart)
-  if (p.epilogue == DDX_EPI_PIXELNORM && p.Cout > 256) return (knob && p.Cg >= 512 && ceil_div(M, 96l) >= 48) ? -96 : 0;
+  if (p.epilogue == DDX_EPI_PIXELNORM && p.Cout > 256) return (p.Cg >= 512 && ceil_div(M, 96l) >= 48) ? -96 : 0;
   const long nn = (long)ceil_div(p.Ng, 256) * p.G;
   // (too few units for the persistent grid: register-staged kernel.  A fused pixel norm saves a launch and a round trip of the
   // tensor, which pays from 64 units; small-M layers with long K take 96-pixel units from 128 of them)
   const bool small_units = ceil_div(M, 256l) * nn < 128;
   if (small_units && p.epilogue == DDX_EPI_PIXELNORM) return ceil_div(M, 192l) * nn >= 64 ? 192 : 0;
-  if (small_units) return (knob == 1 && p.Cg >= 1024 && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0 && ceil_div(M, 96l) * nn >= 128) ? 96 : 0;
-  if (knob == 256 || knob == 192) return knob;
+  if (small_units) return (p.Cg >= 1024 && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0 && ceil_div(M, 96l) * nn >= 128) ? 96 : 0;
   const double c256 = (double)ceil_div(ceil_div(M, 256l) * nn, 256l) * 256.0;
   const double c192 = (double)ceil_div(ceil_div(M, 192l) * nn, 256l) * 192.0 * 1.05;
   return c192 < c256 ? 192 : 256;
@@ -1259,9 +1251,8 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   }
   // streaming producer / consumer mode (512-pixel units) for the conv_res0-type layers with more than 64 channels per group and
   // >= 640 units: measured -5 ... -11 % on those (same command); +6 ... +18 % with the LDS-patch epilogue of the residual + twin
-  // layers and slower at level 2 (384 units for 256 workgroups): not built for them.  DDX_DMA_PCS=0 switches the mode off.
-  static const int pcs_knob = std::getenv("DDX_DMA_PCS") ? atoi(std::getenv("DDX_DMA_PCS")) : 1;
-  if (ksize == 3 && pcs_knob && p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0 && p.Cg % 16 == 0) {
+  // layers and slower at level 2 (384 units for 256 workgroups): not built for them.
+  if (ksize == 3 && p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0 && p.Cg % 16 == 0) {
     using GEO = DmaGeom<3, 16, 2, 1, 8, 2>;
     int th = 0, tw = 0; double ut = 0;
     if (dma_tile(p, 3, &th, &tw, &ut, GEO::BM, GEO::AROWS) && ut >= 0.6) {
@@ -1278,12 +1269,11 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     }
   }
   // stationary weights where all K-stages of a channel tile fit beside two activation stages (Cg <= 32 with 64-channel tiles,
-  // Cg <= 64 with 32-channel tiles): -7 ... -15 % on those layers.  DDX_DMA_WS=0 off, 2 = also 32-channel tiles for
-  // Ng = 64 layers with Cg = 64 (experiment)
-  static const int ws_knob = std::getenv("DDX_DMA_WS") ? atoi(std::getenv("DDX_DMA_WS")) : 1;
-  if (ksize == 3 && ws_knob) {
+  // Cg <= 64 with 32-channel tiles): -7 ... -15 % on those layers (32-channel tiles for the Ng = 64 / Cg = 64 layers
+  // measured 3-6 % slower than streaming 64-channel tiles)
+  if (ksize == 3) {
     const int nk = p.Cg / 16;
-    const int bn = (p.Ng <= 32 || (ws_knob == 2 && p.Ng == 64 && nk == 4)) ? 32 : 64, combos = p.G * ceil_div(p.Ng, bn);
+    const int bn = p.Ng <= 32 ? 32 : 64, combos = p.G * ceil_div(p.Ng, bn);
     const long tiles = (long)p.B * p.tiles_h * p.tiles_w;
     if (combos <= 64 && 512 % (8 * combos) == 0 && tiles * combos >= 1024 && nk <= (bn == 32 ? 4 : 2))
       return bn == 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
@@ -1300,10 +1290,9 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     q.arows_alloc = bm;
     q.inv_TWP = 1.0f / (float)bm;
     // 64-channel stages where the layer allows (half as many stage hand-overs: these layers run 1 us per stage whatever its size)
-    static const int sk64_knob = std::getenv("DDX_DMA_SK64") ? atoi(std::getenv("DDX_DMA_SK64")) : 1;
     if (bm_code == -96) return launch_dma_t<1, 32, 2, 8, 0, 1, 3>(q, s);      // 96 pixels x 512 channels (pixel norm)
     if (bm == 96) return launch_dma_t<1, 64, 1, 8, 0, 1, 3>(q, s);       // 96 pixels x 256 channels, 64-channel stages (small-M, long K)
-    if (bm == 192 && sk64_knob && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0) return launch_dma_t<1, 64, 2, 4, 0, 2, 3>(q, s);
+    if (bm == 192 && p.Cg % 128 == 0 && p.C0 % 64 == 0 && p.C1 % 64 == 0 && p.CK % 64 == 0) return launch_dma_t<1, 64, 2, 4, 0, 2, 3>(q, s);
     return bm == 192 ? launch_dma_t<1, 32, 2, 4, 0, 2, 3>(q, s) : launch_dma_t<1, 32, 4, 2>(q, s);
   }
   const bool wide = dma_wide_1x1(p, (long)p.B * p.tiles_h * p.tiles_w * p.G);

@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_few_kernel(const ConvParams p, co
 
 // 3x3, one group, eight (zero-padded) input channels from ONE source, plain store (+ activated twin): the input convs
 bool conv_few_supported(const ConvParams& p, int ksize, int dtype) {
-  static const bool on = []() { const char* e = std::getenv("DDX_CONV_FEW"); return !e || e[0] != '0'; }();
-  if (!on || dtype != DDX_BF16 || ksize != 3 || p.G != 1 || p.C0 != 8 || p.src1 || p.Cin != 8) return false;
+  if (dtype != DDX_BF16 || ksize != 3 || p.G != 1 || p.C0 != 8 || p.src1 || p.Cin != 8) return false;
   if (p.resample != DDX_RESAMPLE_KEEP || p.prologue != DDX_PRO_NONE || p.epilogue != DDX_EPI_STORE || p.scale0 != 1.0f) return false;
   if (p.out_act || p.out_cs || p.clip > 0.f || p.reflect_w || p.swap1 || p.paired || p.layout || p.out2_linear || p.src0_alt) return false;
   if (p.Cout % 32 || p.Cout < 32 || p.Cout > 256 || p.CK != 32) return false;

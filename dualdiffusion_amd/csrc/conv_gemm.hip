@@ -220,20 +220,11 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   const double imb_n = (double)ceil_div(a.NT, 8) * 8 / a.NT, imb_m = (double)ceil_div(a.MT, 8) * 8 / a.MT;
   a.by_n = imb_n <= imb_m ? 1 : 0;
   const int grid = a.by_n ? a.MT * round_up(a.NT, 8) : a.NT * round_up(a.MT, 8);
-  // stage width / ring depth.  Measured (MI355X, tools/conv_bench.py --path gemm, DDX_GEMM_CFG=GK*10+NS): see DESIGN.md section 6d
-  static const int knob = std::getenv("DDX_GEMM_CFG") ? atoi(std::getenv("DDX_GEMM_CFG")) : 0;
-  const int cfg = knob ? knob : 642;
-  const int gk = cfg / 10;
-  if (gk != 32 && gk != 64) return set_error(DDX_ERR_ARG, "conv_gemm: DDX_GEMM_CFG");
-  if (p.C0 % gk || (p.src1 && p.C1 % gk) || p.CK % gk) return launch_cfg<32, 2>(p, a, grid, s);
-  switch (cfg) {
-    case 322: return launch_cfg<32, 2>(p, a, grid, s);
-    case 323: return launch_cfg<32, 3>(p, a, grid, s);
-    case 324: return launch_cfg<32, 4>(p, a, grid, s);
-    case 642: return launch_cfg<64, 2>(p, a, grid, s);
-    case 643: return launch_cfg<64, 3>(p, a, grid, s);
-    default: return set_error(DDX_ERR_ARG, "conv_gemm: DDX_GEMM_CFG");
-  }
+  // 64-channel stages (whole 128-byte lines) in a two-slot ring, two workgroups per CU; 32-channel stages where the layer's channel
+  // counts need them.  Measured (tools/conv_bench.py --path gemm, level-3 qkv): 32-channel stages with 2 / 3 / 4 slots 18.9 / 19.8 /
+  // 19.3 us, 64-channel with 2 slots 18.6, with 3 slots (one workgroup per CU) 26.7, rings of 6 / 8 slots 31.6 / 30.1 us.
+  if (p.C0 % 64 || (p.src1 && p.C1 % 64) || p.CK % 64) return launch_cfg<32, 2>(p, a, grid, s);
+  return launch_cfg<64, 2>(p, a, grid, s);
 }
 
 }  // namespace ddx

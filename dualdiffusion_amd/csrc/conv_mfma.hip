@@ -497,14 +497,13 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
   struct Cand { int BM, BN; };
   const Cand cands[4] = {{256, 64}, {256, 32}, {128, 64}, {128, 32}};
   Choice best{}; double best_score = -1;
-  // experiment knob: DDX_MFMA_FORCE="BM,BN,KSP" restricts the candidates (tools/conv_bench.py sweeps)
-  // p.force_cfg (ddx_conv_desc.force_direct >= 16, plan-time autotuning) does the same per call
+  // p.force_cfg (ddx_conv_desc.force_direct >= 16: plan-time autotuning, tools/conv_sweep.sh) restricts the candidates to one
   int fbm = 0, fbn = 0, fksp = 0;
   if (p.force_cfg > 0) {
     const int c = (p.force_cfg - 1) / 3, k = (p.force_cfg - 1) % 3;
     if (c > 3) return Choice{};
     fbm = cands[c].BM; fbn = cands[c].BN; fksp = 1 << k;
-  } else if (const char* e = std::getenv("DDX_MFMA_FORCE")) sscanf(e, "%d,%d,%d", &fbm, &fbn, &fksp);
+  }
   for (const Cand& c : cands) {
     const int BM = c.BM, BN = c.BN;
     int TH, TW; double um;

@@ -1,24 +1,28 @@
-// Magnitude-preserving conv2d forward for the SMALL-M layers of the UNet (level 4 of the default model: 86 pixels per image, 344 at
-// B = 4; reference src/modules/unets/unet_edm2_b4.py:110-158 at H x W = 2 x 43): implicit GEMMs built around latency, not around
-// tile throughput.
+// Magnitude-preserving 1x1 conv2d forward for the SMALL-M layers of the UNet (level 4 of the default model: 86 pixels per image, 344 at
+// B = 4; reference src/modules/unets/unet_edm2_b4.py:110-158 at H x W = 2 x 43: conv_skip, attn_proj): an implicit GEMM built around
+// latency, not around tile throughput.
 //
-// What bounds these layers is the number of SERIAL memory round trips inside a launch (2-3 us of roofline work took 12-20 us: a K
-// loop of dependent chunks on the register-staged kernel, a ring of four weight fragments per wave in the first version of this
+// What bounds these layers is the number of SERIAL memory round trips inside a launch (1-2 us of roofline work took 12-19 us: a K
+// loop of dependent chunks on the register-staged kernel, a ring of four weight fragments per wave in the round-2 version of this
 // file).  Round-4 structure: a workgroup is EIGHT waves that split K eight ways, and every byte the workgroup needs is requested in
 // ONE burst before anything waits:
+//   * epilogue operands (residual rows, channel scales) first: their latency hides behind everything else;
+//   * the pixel rows of the tile (whole 128-byte lines, all input channels of a K pass) go into LDS by LDS-DMA (buffer_load ... lds,
+//     zero padding by out-of-range offsets, rows padded by one 16-byte slot so that fragment reads are bank-conflict free, one
+//     all-zero row); layers with more than 80 sixteen-channel chunks per pixel tile run two or three K passes;
 //   * weights never touch LDS: prepared with 16-channel chunks (wp[g][c16][tap][NgP][16]) a 32-row x 16-channel MFMA A fragment is
-//     ONE contiguous 1 KiB block; a wave loads ALL fragments of its K share (<= NP steps) straight into the A operand registers;
-//   * 3x3 layers (conv_sm3): the halo tile of ALL channels of the group goes into LDS by LDS-DMA (buffer_load ... lds, zero padding
-//     by out-of-range offsets, rows padded by one 16-byte slot so that fragment reads are bank-conflict free);
-//   * 1x1 layers (conv_sm1): the pixel rows of the tile (whole 128-byte lines, all input channels of a K pass) go into LDS the same
-//     way; layers with more than 80 chunks per pixel tile run two K passes;
-//   * ONE wait + ONE barrier, then <= NP matrix steps per wave, then the eight partial tiles are summed through LDS inside the fused
-//     epilogue (fixed order: deterministic); residual rows and channel scales are requested before the reduction.
-// Operands are raw (producer-side activation); the one per-channel prologue of these levels, attn_qk reading
-// x * c, is served by a scaled twin written by the producing conv (`out2_linear`) and selected per output-channel tile (`src0_alt`).
+//     ONE contiguous 1 KiB block; a wave loads ALL fragments of its K share (<= 10 steps) straight into the A operand registers,
+//     BEHIND the rows in the memory queue -- a counted s_waitcnt + raw s_barrier release the matrix loop when the rows have
+//     landed, the weight fragments are waited for one by one;
+//   * the matrix loop is branch-free (steps past a wave's share multiply re-read weights with the zero row) with a ring of three
+//     fragment register sets; the eight partial tiles are summed through LDS inside the fused epilogue (fixed order: deterministic).
+// Measured (round 4, tools/sm_ablate.sh): an EMPTY launch of this shape (no loads, no MFMA, only the epilogue's dependent load ->
+// store chain) costs 4.6-6.4 us; the level-4 layers run 7.2-15.6 us.  A 3x3 variant of the same structure (slab of the whole image
+// in LDS, 23 weight fragments per wave) measured 8.3-23.7 us against 9.8-19.7 us on the register-staged kernel and lost 0.12 ms on the
+// whole step (it also moves the merged qkv conv here: 21-25 us against 19-22): removed, DESIGN.md section 6d.
+// Operands are raw (producer-side activation); `src0_alt` selects a second source per output-channel tile.
 // Workgroups that read the same weights are laid on the same XCD (observed block -> XCD map b % 8: speed only).
 #include <algorithm>
-#include <cstdio>
 #include <cstdlib>
 
 #include "conv_params.hpp"
@@ -40,14 +44,13 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, size_t bytes) {
 __device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 struct SmArgs {
-  int TH, TW, TWP, tiles_h, tiles_w, R;  // 3x3: pixel tile inside an image, staged rows (halo included)
-  int V, slots;                          // 16-byte slots per staged row (without the pad slot), slots of the staged slab
-  int SC, ppw;                           // K steps (3x3: 9 * Cg/16 pairs (tap, chunk); 1x1: chunks per pass), steps per wave
-  int npass, SCtot;                      // 1x1: K passes through LDS, chunks of the whole layer
-  int PT, WT, ntiles;                    // pixel tiles, weight tiles (= G * ntiles), channel tiles per group
+  int V, slots;                          // 16-byte slots per staged row (without the pad slot), slots of the staged rows
+  int SC, ppw;                           // 16-channel chunks per K pass, chunks per wave
+  int npass, SCtot;                      // K passes through LDS, chunks of the whole layer
+  int PT, WT;                            // pixel tiles, weight (channel) tiles
   int M, HW;                             // B*H*W, H*W
   int dbg;                               // DDX_SM_DBG ablation bits (timing experiments; wrong results): 1 no weight loads, 2 no operand DMA, 4 no MFMA, 8 no reduction
-  float inv_TW, inv_TWP, inv_V1, inv_ks16, inv_HW, inv_W;
+  float inv_V1, inv_HW, inv_W;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- epilogue
@@ -300,268 +303,94 @@ __global__ __launch_bounds__(kThreads, 2) void conv_sm1_kernel(const ConvParams 
   sm_epilogue<PF, NF>(p, a, acc, smem, q, pre);
 }
 
-// ---------------------------------------------------------------------------------------------------------------- 3x3
-// Tile = TH x TW pixels of one image (<= PF * 32) x NF * 32 output channels of one group; wave q owns the (tap, chunk) pairs
-// s = tap * Cg/16 + chunk in [q ppw, (q + 1) ppw).  Slab row R is the zero row (see conv_sm1_kernel).
-template <int PF, int NF, int NP>
-__global__ __launch_bounds__(kThreads, 2) void conv_sm3_kernel(const ConvParams p, const SmArgs a) {
-  constexpr int BN = NF * 32, EI = (PF * 32 * NF * 8 + kThreads - 1) / kThreads;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int khalf = lane >> 5, l31 = lane & 31;
-  int wt, px;
-  if (!sm_decode(a, &wt, &px)) return;
-  const int g = wt / a.ntiles, n0 = (wt - g * a.ntiles) * BN;
-  const int tx = px % a.tiles_w, ty = (px / a.tiles_w) % a.tiles_h, b = px / (a.tiles_w * a.tiles_h);
-  const int h0 = ty * a.TH, w0 = tx * a.TW;
-  const int TW = a.TW, TWP = a.TWP, MT = a.TH * TW;
-  const int ks16 = p.Cg >> 4, SC = a.SC;
-  const int s0 = q * a.ppw;
-
-  SmEpiPre<EI> pre;
-  sm_epilogue_prefetch<PF, NF>(p, a, g, n0, [&](int ml) {
-    const int th = fdiv(ml, a.inv_TW), tw = ml - th * TW;
-    const int h = h0 + th, w = w0 + tw;
-    return (ml < MT && h < p.H && w < p.W) ? (b * p.H + h) * p.W + w : -1;
-  }, pre);
-
-  // ---- activation slab by LDS-DMA: slot sidx = r * (V + 1) + v (v == V: pad slot), 64 consecutive slots per wave instruction
-  {
-    const rsrc_t rs0 = make_rsrc(p.src0, (size_t)p.B * p.sH * p.sW * p.C0 * 2);
-    const rsrc_t rs1 = p.src1 ? make_rsrc(p.src1, (size_t)p.B * p.sH * p.sW * p.C1 * 2) : rs0;
-    const int npieces = (a.slots + 63) >> 6;
-    const int cg0 = g * p.Cg;
-    const bool one_src = p.src1 == nullptr || cg0 + p.Cg <= p.C0 || cg0 >= p.C0;   // (workgroup-uniform)
-    const bool only1 = p.src1 != nullptr && cg0 >= p.C0;
-    for (int piece = q; piece < ((a.dbg & 2) ? 0 : npieces); piece += kWaves) {
-      const int sidx = piece * 64 + lane;
-      const int r = fdiv(sidx, a.inv_V1), v = sidx - r * (a.V + 1);
-      const int hh = fdiv(r, a.inv_TWP), ww = r - hh * TWP;
-      const int ih = h0 - 1 + hh, iw = w0 - 1 + ww;
-      const bool ok = r < a.R && v < a.V && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-      const int pix = (p.resample == DDX_RESAMPLE_UP) ? (b * p.sH + (ih >> 1)) * p.sW + (iw >> 1) : (b * p.sH + ih) * p.sW + iw;
-      stage_slot(p, rs0, rs1, ok, pix, cg0 + v * 8, smem + piece * 1024, one_src, only1);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- weights behind the slab (they come from HBM): all fragments of this wave's pairs
-  const bf16* wp = reinterpret_cast<const bf16*>(p.wp);
-  const bf16* wlane[NF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i) wlane[i] = wp + ((size_t)g * ks16 * 9 * p.NgP + min(n0 + i * 32 + l31, p.NgP - 1)) * 16 + khalf * 8;
-  bf16x8 wr[NP][NF];
-  if (!(a.dbg & 1)) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int s = min(s0 + i, SC - 1);
-      const int tap = fdiv(s, a.inv_ks16), c16 = s - tap * ks16;
-      const size_t off = ((size_t)c16 * 9 + tap) * p.NgP * 16;
-#pragma unroll
-      for (int n = 0; n < NF; ++n) wr[i][n] = *reinterpret_cast<const bf16x8*>(wlane[n] + off);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-#pragma unroll
-      for (int n = 0; n < NF; ++n)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wr[i][n][e] = (bf16)1.f;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-
-  int arow[PF];
-#pragma unroll
-  for (int j = 0; j < PF; ++j) {
-    const int ml = j * 32 + l31;
-    const int th = fdiv(ml, a.inv_TW);
-    arow[j] = (ml < MT) ? th * TWP + (ml - th * TW) : 0;
-  }
-  f32x16 acc[NF][PF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i)
-#pragma unroll
-    for (int j = 0; j < PF; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // the slab (issued first: memory returns in order) has landed when at most the weight loads are outstanding
-  // (raw barrier: __syncthreads() would drain vmcnt to 0 because LDS-DMA writes are pending LDS stores to the compiler's fence)
-  if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP * NF) : "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  const bf16* sA = reinterpret_cast<const bf16*>(smem);
-  const int rstride = (a.V + 1) * 8;  // elements
-  if (!(a.dbg & 4)) {
-    // fragments of step i + 2 are read while step i multiplies (ring of three register sets)
-    bf16x8 xf[3][PF];
-    auto read_x = [&](int i, int u) {
-      const int s = s0 + i;
-      const bool valid = i < a.ppw && s < SC;   // (wave-uniform)
-      const int sc = valid ? s : 0;
-      const int tap = fdiv(sc, a.inv_ks16), c16 = sc - tap * ks16;
-      const int t3 = tap / 3;
-      const int toff = t3 * TWP + (tap - 3 * t3);
-#pragma unroll
-      for (int j = 0; j < PF; ++j) xf[u][j] = *reinterpret_cast<const bf16x8*>(sA + (size_t)(valid ? arow[j] + toff : a.R) * rstride + c16 * 16 + khalf * 8);
-    };
-    read_x(0, 0);
-    read_x(1, 1);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (i + 2 < NP) read_x(i + 2, (i + 2) % 3);
-#pragma unroll
-      for (int n = 0; n < NF; ++n)
-#pragma unroll
-        for (int j = 0; j < PF; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[i][n], xf[i % 3][j], acc[n][j], 0, 0, 0);
-    }
-  }
-  sm_epilogue<PF, NF>(p, a, acc, smem, q, pre);
-}
-
 // ------------------------------------------------------------------------------------------- host side
 
-struct SmPlan { SmArgs a; int PF, NF, NP; size_t smem; long wgs; };
+struct SmPlan { SmArgs a; int PF, NF; size_t smem; long wgs; };
 constexpr size_t kLdsMax = 156 * 1024;
-constexpr int kNP1 = 10;   // 1x1: weight fragments per wave and K pass
-
-// pixel tile TH x TW <= BM of an H x W image: fewest tiles, then fewest staged rows
-void sm_tile(int H, int W, int BM, int* TH, int* TW) {
-  long best_tiles = -1; int best_rows = 0;
-  for (int tw = 1; tw <= W && tw <= BM; ++tw)
-    for (int th = 1; th <= H && th * tw <= BM; ++th) {
-      const long tiles = (long)ceil_div(H, th) * ceil_div(W, tw);
-      const int rows = (th + 2) * (tw + 2);
-      if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && rows < best_rows)) { best_tiles = tiles; best_rows = rows; *TH = th; *TW = tw; }
-    }
-}
+constexpr int kNP1 = 10;   // weight fragments per wave and K pass
 
 int env_int(const char* name) { const char* e = std::getenv(name); return e ? atoi(e) : 0; }
 
-bool sm_plan(const ConvParams& p, int ks, SmPlan* out) {
-  static const int force_pf = env_int("DDX_SM_PF"), force_nf = env_int("DDX_SM_NF"), dbg = env_int("DDX_SM_DBG");
+bool sm_plan(const ConvParams& p, SmPlan* out) {
+  static const int dbg = env_int("DDX_SM_DBG");   // timing ablations only (tools/sm_ablate.sh)
+  if (p.G != 1) return false;
   SmPlan best{}; double best_cost = 1e30; bool found = false;
-  for (int PF = 1; PF <= 3; ++PF) {
-    if (force_pf && PF != force_pf) continue;
+  for (int PF = 1; PF <= 2; ++PF) {
     for (int NF = 1; NF <= 2; ++NF) {
-      if (force_nf && NF != force_nf) continue;
-      if (ks == 3 && PF == 1) continue;   // built: 3x3 PF 2 | 3 (NF 2 only with <= 12 steps per wave); 1x1 PF 1 | 2
-      if (ks == 1 && PF == 3) continue;
       if (NF == 2 && p.Ng <= 32) continue;
       SmArgs a{};
       a.dbg = dbg;
       const int BM = PF * 32, BN = NF * 32;
       const size_t red = (size_t)kWaves * BM * (BN + 4) * sizeof(float);
-      size_t smem;
-      int NP;
-      double util;
       a.HW = p.H * p.W; a.M = p.B * a.HW;
       a.inv_HW = 1.0f / (float)a.HW; a.inv_W = 1.0f / (float)p.W;
-      a.ntiles = ceil_div(p.Ng, BN);
-      a.WT = p.G * a.ntiles;
-      if (ks == 1) {
-        if (p.G != 1) continue;
-        a.SCtot = p.Cin / 16;
-        // K passes: <= 8 * kNP1 chunks per pass, and the staged rows (one pad slot each) must fit LDS
-        const int max_chunks_lds = (int)((kLdsMax / ((size_t)(BM + 1) * 16) - 1) / 2);
-        const int max_chunks = std::min(kWaves * kNP1, max_chunks_lds);
-        if (max_chunks < 8) continue;
-        a.npass = ceil_div(a.SCtot, max_chunks);
-        a.SC = ceil_div(a.SCtot, a.npass);
-        a.ppw = ceil_div(a.SC, kWaves);
-        NP = kNP1;
-        a.V = a.SC * 2;
-        a.slots = (BM + 1) * (a.V + 1);   // + the zero row
-        a.inv_V1 = 1.0f / (float)(a.V + 1);
-        a.PT = ceil_div(a.M, BM);
-        util = (double)a.M / ((double)a.PT * BM);
-        smem = std::max(red, (size_t)round_up(a.slots, 64) * 16);
-      } else {
-        sm_tile(p.H, p.W, BM, &a.TH, &a.TW);
-        a.TWP = a.TW + 2;
-        a.tiles_h = ceil_div(p.H, a.TH); a.tiles_w = ceil_div(p.W, a.TW);
-        a.R = (a.TH + 2) * a.TWP;
-        a.V = p.Cg / 8;
-        a.slots = (a.R + 1) * (a.V + 1);   // + the zero row
-        a.SC = 9 * (p.Cg / 16); a.SCtot = a.SC; a.npass = 1;
-        a.ppw = ceil_div(a.SC, kWaves);
-        if (a.ppw > 24) continue;
-        NP = a.ppw <= 12 ? 12 : 24;
-        if (NF == 2 && NP != 12) continue;
-        a.PT = p.B * a.tiles_h * a.tiles_w;
-        a.inv_TW = 1.0f / (float)a.TW; a.inv_TWP = 1.0f / (float)a.TWP; a.inv_V1 = 1.0f / (float)(a.V + 1); a.inv_ks16 = 1.0f / (float)(p.Cg / 16);
-        smem = std::max(red, (size_t)round_up(a.slots, 64) * 16);
-        util = (double)p.H * p.W / ((double)a.tiles_h * a.tiles_w * BM);
-      }
+      a.WT = ceil_div(p.Ng, BN);
+      a.SCtot = p.Cin / 16;
+      // K passes: <= 8 * kNP1 chunks per pass, and the staged rows (one pad slot each) must fit LDS
+      const int max_chunks_lds = (int)((kLdsMax / ((size_t)(BM + 1) * 16) - 1) / 2);
+      const int max_chunks = std::min(kWaves * kNP1, max_chunks_lds);
+      if (max_chunks < 8) continue;
+      a.npass = ceil_div(a.SCtot, max_chunks);
+      a.SC = ceil_div(a.SCtot, a.npass);
+      a.ppw = ceil_div(a.SC, kWaves);
+      a.V = a.SC * 2;
+      a.slots = (BM + 1) * (a.V + 1);   // + the zero row
+      a.inv_V1 = 1.0f / (float)(a.V + 1);
+      a.PT = ceil_div(a.M, BM);
+      const double util = (double)a.M / ((double)a.PT * BM);
+      const size_t smem = std::max(red, (size_t)round_up(a.slots, 64) * 16);
       if (smem > kLdsMax) continue;
       const long wgs = (long)a.PT * a.WT;
       // relative cost (us): rounds of resident workgroups (one per CU) x (bytes a workgroup pulls at ~100 GB/s + matrix steps + fixed latency)
       const double rounds = std::ceil((double)wgs / 256.0);
-      const double kk = (double)p.Cg * ks * ks;
-      const double bytes = 2.0 * (BN * kk + (ks == 1 ? (double)BM * p.Cin : (double)a.R * p.Cg));
+      const double bytes = 2.0 * ((double)BN * p.Cin + (double)BM * p.Cin);
       const double mfma_us = (double)a.ppw * a.npass * PF * NF * 32.0 / 2100.0;
       double cost = rounds * (bytes / 100e3 + mfma_us + 3.0) / std::max(util, 0.1);
-      // measured (MI355X, tools/conv_bench.py --cases small --path sm, DDX_SM_PF / DDX_SM_NF): 1x1 layers with 64-pixel x 32-channel tiles
-      // beat the 32 x 64 ones of equal byte count (L4 proj 10.7 vs 14.4 us, skip over mp_cat 15.6 vs 21.7: 20 weight fragments per wave
-      // in flight are slower than 10 + a second operand pass)
-      if (ks == 1 && NF == 2) cost *= 1.3;
-      if (cost < best_cost) { best_cost = cost; best = SmPlan{a, PF, NF, NP, smem, wgs}; found = true; }
+      // measured (MI355X, tools/conv_bench.py --cases small --path sm with the tile forced): 64-pixel x 32-channel tiles beat the 32 x 64
+      // ones of equal byte count (level-4 proj 10.7 vs 14.4 us, skip over mp_cat 15.6 vs 21.7: 20 weight fragments per wave in flight
+      // are slower than 10 + a second operand pass)
+      if (NF == 2) cost *= 1.3;
+      if (cost < best_cost) { best_cost = cost; best = SmPlan{a, PF, NF, smem, wgs}; found = true; }
     }
   }
   if (found) *out = best;
-  static const int verbose = env_int("DDX_SM_VERBOSE");
-  if (found && verbose)
-    fprintf(stderr, "conv_sm ks=%d M=%d Cin=%d Cout=%d G=%d: PF=%d NF=%d NP=%d ppw=%d npass=%d wgs=%ld smem=%zu\n", ks, best.a.M, p.Cin, p.Cout, p.G, best.PF,
-            best.NF, best.NP, best.a.ppw, best.a.npass, best.wgs, best.smem);
   return found;
 }
 
-template <typename K>
-int launch_kernel(K kern, const ConvParams& p, const SmPlan& pl, hipStream_t s, bool* attr_done) {
-  if (!*attr_done) {
+template <int PF, int NF>
+int launch_sm(const ConvParams& p, const SmPlan& pl, hipStream_t s) {
+  static bool attr_done = false;
+  auto kern = conv_sm1_kernel<PF, NF, kNP1>;
+  if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(conv_sm)");
-    *attr_done = true;
+    attr_done = true;
   }
   const int grid = pl.a.PT * round_up(pl.a.WT, 8);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), pl.smem, s, p, pl.a);
   return check_launch("conv_sm");
 }
 
-template <int KS, int PF, int NF, int NP>
-int launch_sm(const ConvParams& p, const SmPlan& pl, hipStream_t s) {
-  static bool attr_done = false;
-  if constexpr (KS == 1) return launch_kernel(conv_sm1_kernel<PF, NF, NP>, p, pl, s, &attr_done);
-  else return launch_kernel(conv_sm3_kernel<PF, NF, NP>, p, pl, s, &attr_done);
-}
-
 }  // namespace
 
 bool conv_sm_supported(const ConvParams& p, int ksize, int dtype) {
-  if (dtype != DDX_BF16 || (ksize != 1 && ksize != 3) || p.CK != 16) return false;
+  if (dtype != DDX_BF16 || ksize != 1 || p.CK != 16) return false;
   if (p.resample == DDX_RESAMPLE_DOWN || p.reflect_w || p.swap1 || p.paired) return false;
   if (p.prologue != DDX_PRO_NONE || p.scale0 != 1.0f || (p.src1 && p.scale1 != 1.0f)) return false;   // raw operands only
   if (p.Cg % 16 || p.C0 % 16 || (p.src1 && p.C1 % 16)) return false;
   if (p.Ng % 4 || p.Cout % 4) return false;
   if (p.epilogue != DDX_EPI_STORE && p.epilogue != DDX_EPI_MPSUM) return false;
-  if (p.src0_alt && (ksize != 1 || p.pro_rows <= 0 || p.pro_rows % 64)) return false;
+  if (p.src0_alt && (p.pro_rows <= 0 || p.pro_rows % 64)) return false;
   if ((size_t)p.B * p.sH * p.sW * std::max(p.C0, p.C1) * 2 >= (size_t)0x7fffff00) return false;
   SmPlan pl;
-  return sm_plan(p, ksize, &pl);
+  return sm_plan(p, &pl);
 }
 
 int launch_conv_sm(const ConvParams& p, int ksize, hipStream_t s) {
   SmPlan pl;
-  if (!sm_plan(p, ksize, &pl)) return set_error(DDX_ERR_UNSUPPORTED, "conv_sm: no tile fits LDS");
-#define DDX_SM(KS_, PF_, NF_, NP_) \
-  if (ksize == KS_ && pl.PF == PF_ && pl.NF == NF_ && pl.NP == NP_) return launch_sm<KS_, PF_, NF_, NP_>(p, pl, s)
-  DDX_SM(3, 2, 1, 12); DDX_SM(3, 2, 1, 24); DDX_SM(3, 3, 1, 12); DDX_SM(3, 3, 1, 24); DDX_SM(3, 2, 2, 12); DDX_SM(3, 3, 2, 12);
-  DDX_SM(1, 1, 1, kNP1); DDX_SM(1, 1, 2, kNP1); DDX_SM(1, 2, 1, kNP1); DDX_SM(1, 2, 2, kNP1);
-#undef DDX_SM
-  return set_error(DDX_ERR_UNSUPPORTED, "conv_sm: configuration not built");
+  if (ksize != 1 || !sm_plan(p, &pl)) return set_error(DDX_ERR_UNSUPPORTED, "conv_sm: no tile fits LDS");
+  if (pl.PF == 1) return pl.NF == 1 ? launch_sm<1, 1>(p, pl, s) : launch_sm<1, 2>(p, pl, s);
+  return pl.NF == 1 ? launch_sm<2, 1>(p, pl, s) : launch_sm<2, 2>(p, pl, s);
 }
 
 }  // namespace ddx

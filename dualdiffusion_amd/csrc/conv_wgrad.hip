@@ -382,8 +382,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 int wgrad_ksplit(int G, int Ng, int Cg, int ks, int ntile_px, bool wide = false) {
   const int bcw = wide ? 128 : (ks == 3 ? 32 : 64);
   const long base = (long)G * ceil_div(Ng, wide ? 128 : 64) * ceil_div(Cg, bcw);
-  static const long want_units = std::getenv("DDX_WGRAD_WANT") ? atol(std::getenv("DDX_WGRAD_WANT")) : 512;      // experiment knobs
-  static const double cap_mb = std::getenv("DDX_WGRAD_CAP_MB") ? atof(std::getenv("DDX_WGRAD_CAP_MB")) : 48.0;
+  const long want_units = 512;      // (768 measured slower: more partial-sum traffic, same critical path)
+  const double cap_mb = 48.0;
   long want = std::max<long>(1, want_units / base);
   const double dw_mb = (double)G * Ng * Cg * ks * ks * 4.0 / 1e6;
   if (dw_mb * want > cap_mb) want = std::max<long>(1, (long)(cap_mb / dw_mb));
@@ -489,9 +489,8 @@ static int wgrad_fill(const ddx_wgrad_desc& d, WgradParams* pp) {
   p.resample = d.resample;
   if ((size_t)p.B * p.H * p.W * std::max(p.Cout, std::max(p.C0, p.C1)) * 2 >= (size_t)0x7fff0000)
     return set_error(DDX_ERR_UNSUPPORTED, "wgrad: tensor too large for 32-bit buffer offsets");
-  static const bool wide_enabled = []() { const char* e = std::getenv("DDX_WGRAD_WIDE"); return !e || e[0] != '0'; }();
   // (measured on MI355X: 1.4-1.65x faster from 5.5k pixels up, slower at 1.4k pixels where few, short units remain)
-  p.wide = wide_enabled && d.resample == DDX_RESAMPLE_KEEP && (long)p.B * p.H * p.W >= 4096 && wgrad1x1_wide_ok(d.ksize, p.Ng, p.Cg, p.C0, p.C1) ? 1 : 0;
+  p.wide = d.resample == DDX_RESAMPLE_KEEP && (long)p.B * p.H * p.W >= 4096 && wgrad1x1_wide_ok(d.ksize, p.Ng, p.Cg, p.C0, p.C1) ? 1 : 0;
   if (p.wide) {
     p.tiles_h = p.tiles_w = 0; p.ntile_px = ceil_div(p.B * p.H * p.W, Wg1::PX);
     p.n_tiles = p.Ng / 128; p.c_tiles = p.Cg / 128;

@@ -163,8 +163,6 @@ extern "C" int ddx_plan_include(const ddx_plan* src) {
 }
 
 static int plan_replay(ddx_plan* p, hipStream_t s, bool lanes) {
-  static const bool lanes_enabled = []() { const char* e = std::getenv("DDX_PLAN_LANES"); return !e || e[0] != '0'; }();
-  lanes = lanes && lanes_enabled;
   if (lanes && !p->side) {
     bool any = false;
     for (int k : p->kind) any = any || k == DDX_MARK_FORK;

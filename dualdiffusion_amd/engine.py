@@ -17,7 +17,7 @@ from typing import Callable, Optional
 import torch
 
 from . import ops
-from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan, check, lib, weights_epoch
+from ._lib import PRO_NONE, PRO_SCALE, PRO_SCALE_SILU, PRO_SILU, RESAMPLE_DOWN, RESAMPLE_KEEP, RESAMPLE_UP, Plan, weights_epoch
 
 _RESAMPLE = {"keep": RESAMPLE_KEEP, "up": RESAMPLE_UP, "down": RESAMPLE_DOWN}
 
@@ -28,11 +28,9 @@ def mp_cat_weights(na: int, nb: int, t: float) -> tuple:
     return c / math.sqrt(na) * (1 - t), c / math.sqrt(nb) * t
 
 
-MERGE_QKV = os.environ.get("DDX_MERGE_QKV", "1") != "0"     # attn_qk | attn_v as one conv (engine.PlanBuilder.block)
-# batched emb_linear on the plan's side lane (PlanBuilder.finalize).  Measured (MI355X, hipGraph, default UNet B=4): 5.14 ms per
-# step with the lane vs 5.055 ms without -- the 130 MB weight stream slows the HBM-bound L0 convs it runs beside by more than
-# the 55 us it hides -> off by default.
-EMB_LANE = os.environ.get("DDX_EMB_LANE", "0") != "0"
+# (Measured and removed: attn_qk / attn_v as two convs -- the merged conv saves 15 small-M launches, 5.23 -> 5.07 ms per step in round 1;
+# the batched emb_linear launch on a side lane of the plan -- 5.14 vs 5.055 ms, the 130 MB weight stream slows the HBM-bound level-0 convs it
+# runs beside by more than the 55 us it hides.)
 # plan-time kernel selection by measurement (ops.tuning): every conv of an inference plan times its kernel candidates once.
 # Measured (default UNet, hipGraph): B=1 2.77 -> 2.66 ms, B=4 4.99 -> 4.98 ms, B=8 8.44 -> 8.40 ms -- the built-in heuristics were
 # tuned at B=4/8 and leave little there, so it is opt-in (adds ~1-2 s to the first call, run-to-run choices may differ).
@@ -41,23 +39,24 @@ AUTOTUNE = os.environ.get("DDX_AUTOTUNE", "0") != "0"
 # (conv_sm.hip): their weights are prepared with 16-channel chunks, the layout that kernel streams straight into the MFMA operand
 # registers.  Measured on MI355X (tools/conv_bench.py --cases small, graph-chained launches, B=4): level-4 1x1 layers (344 pixels)
 # 7.0-12.9 us against 9.1-17.2 us on the register-staged split-K kernel; level-3 1x1 layers (1376 pixels) 13-31 us against 12-26 us,
-# and the 3x3 variant (DDX_SM_3X3=1) 10-33 us against 9-28 us -> the default covers what is faster.  0 switches it off.
+# (round 4, eight-wave one-burst kernels: level-4 1x1 layers 7.2-15.6 us; a 3x3 variant of the same structure measured 8.3-23.7 us against
+# 9.8-19.7 us on the register-staged kernel and 4.42 vs 4.30 ms on the whole step -- removed).  DDX_SM_MAX_PIXELS=0 switches the path off.
 # Channel-blocked [B, C/16, H, W, 16] storage of the tensors that only 3x3 LDS-DMA convs read (conv_res0's output, the activated
 # twins written by conv_res1): a K-stage of the consumer is then one contiguous plane slice instead of 32-byte granules a pixel
 # stride apart.  Measured on MI355X (tools/conv_bench.py --epi real --path dma+dma16, B=4): conv_res1 at level 0 63.2 -> 49.3 us
 # (512 -> 256 channels) and 166.6 -> 151.2 us (1024 -> 512), level 1 42.9 -> 38.7 us; conv_res0 layers 3-8 %; bit-identical results.
 C16 = os.environ.get("DDX_C16", "1") != "0"
 SM_MAX_PIXELS = int(os.environ.get("DDX_SM_MAX_PIXELS", "512"))
-SM_3X3 = os.environ.get("DDX_SM_3X3", "0") != "0"
 # The residual branch of an up block is conv_skip(upsample(x)): a 1x1 conv commutes with the nearest resample exactly, so the
 # skip conv runs at the SOURCE size (a quarter of the matrix work and output bytes) and conv_res1 gathers the half-size
-# residual in its epilogue (ddx_conv_desc::residual_up).  Inference plans; DDX_RES_UP=0 restores the full-size skip conv.
-RES_UP = os.environ.get("DDX_RES_UP", "1") != "0"
+# residual in its epilogue (ddx_conv_desc::residual_up).  Inference plans (4.735 -> 4.63-4.66 ms per step in round 3; tests flip the constant).
+RES_UP = True
 # encoder blocks: normalize(conv_skip(x)) and its activated twin from the skip conv's epilogue where one unit holds all channels of a pixel
-FUSE_PIXELNORM = os.environ.get("DDX_FUSE_PIXELNORM", "1") != "0"
+# (five pixelnorm launches less: 4.65 -> 4.60, 4.53 -> 4.49-4.51 ms in round 3)
+FUSE_PIXELNORM = True
 # attention blocks outside the small-M regime: x * c_qk as a materialised twin (written by conv_res1 where it runs on the register-staged
 # kernel) + the merged qkv conv on the 1x1 GEMM kernel / the wide 1x1 units of the LDS-DMA kernel (0 = never)
-QKV_TWIN_MIN_PIXELS = int(os.environ.get("DDX_QKV_TWIN_MIN_PIXELS", "1024"))
+QKV_TWIN_MIN_PIXELS = 1024
 PIXELNORM_EPS = 1e-4     # eps of normalize() (mp_tools.py:42-49), the default of ops.pixelnorm
 
 
@@ -69,7 +68,6 @@ class PlanBuilder:
         self.gains: list = []       # 0-d gain parameters, mirrored into one fp32 vector read by the kernels
         self.convs: list = []       # weight-preparation specs
         self.padded: list = []      # (conv, zero-row-padded weight copy) for convs prepared with cout_pad
-        self.first_cvec_step: Optional[int] = None   # index of the first step that reads a modulation vector (see finalize)
         self.lin_jobs: list = []    # (weight holder, gain slot, out tensor, groups, add_const)
         self.steps: list = []       # closures executed while recording the forward plan
         self.wplan, self.fplan = Plan(), Plan()
@@ -90,7 +88,7 @@ class PlanBuilder:
     def pick_ck(self, Cg: int, ks: int, npix: int) -> int:
         # (1x1 layers: a wave of the small-M kernel owns a quarter of the channels in whole 64-channel lines, four steps in flight)
         if (not self.training and self.dt == torch.bfloat16 and 0 < npix <= SM_MAX_PIXELS and Cg >= 32 and
-                ((SM_3X3 and Cg % 16 == 0 and Cg <= 336) if ks == 3 else Cg % 256 == 0)):
+                ks == 1 and Cg % 256 == 0):
             return 16
         return ops.pick_ck(Cg, ks, self.dt, npix)
 
@@ -174,10 +172,6 @@ class PlanBuilder:
         tw_res1 = dict(out2=twin, out2_scale=twin_scale) if (twin is not None and not attn) else {}
         if attn:
             c_qk, c_v = self.cvec(blk.emb_linear_qk, blk.emb_gain_qk), self.cvec(blk.emb_linear_v, blk.emb_gain_v)
-            if pw_res1.CK == 16:
-                # small-M kernels take raw operands: conv_res1 also writes the scaled twin x * c_qk that attn_qk reads
-                xs = self.act(h, w, cout)
-                tw_res1 = dict(out2=xs, out2_chan_scale=c_qk)
         S = self.step
         if blk.flavor == "enc":
             pw_skip = self.prep(blk.conv_skip, npix=npix) if blk.conv_skip is not None else None
@@ -203,25 +197,16 @@ class PlanBuilder:
                 S(lambda: ops.pixelnorm(x1, out=x1, out_act=x1a))
             else:
                 S(lambda: ops.pixelnorm(src0, out=x1, out_act=x1a))
-            if self.first_cvec_step is None:
-                self.first_cvec_step = len(self.steps)     # conv_res0 is the first reader of a modulation vector
             kw0 = dict(out_act=True, out_scale=c_emb, out=y0)
             kw1 = dict(residual=x1, res_t=res_balance, clip=last_clip, out=xo, **tw_res1)
             self._block_layouts(None, None, x1a, pw_res0, kw0, y0, pw_res1, kw1, twin if not attn else None)
             S(lambda: ops.conv2d(x1a, pw_res0, **kw0))
             S(lambda: ops.conv2d(y0, pw_res1, **kw1))
         else:
-            if self.first_cvec_step is None:
-                self.first_cvec_step = len(self.steps)
             kw0 = None
             if act0 is not None and (src1 is None or act1 is not None):
                 kw0 = dict(out_hw=(h, w), src1=act1, resample=rs, out_act=True, out_scale=c_emb, out=y0)
                 S(lambda: ops.conv2d(act0, pw_res0, **kw0))
-            elif pw_res0.CK == 16 and src1 is None:
-                # small-M kernel (raw operands only): one element-wise pass makes the activated operand the producer did not write
-                a0 = self.act(src0.shape[1], src0.shape[2], src0.shape[3])
-                S(lambda: ops.silu_scale_fwd(src0, None, s0, out=a0))
-                S(lambda: ops.conv2d(a0, pw_res0, out_hw=(h, w), resample=rs, out_act=True, out_scale=c_emb, out=y0))
             else:   # no twins available: fused prologue on the raw inputs
                 S(lambda: ops.conv2d(src0, pw_res0, out_hw=(h, w), src1=src1, scale0=s0, scale1=s1, resample=rs, prologue=PRO_SILU,
                                      out_act=True, out_scale=c_emb, out=y0))
@@ -237,17 +222,12 @@ class PlanBuilder:
                 else:
                     sk = src0
             elif blk.conv_skip is not None:
-                # the skip conv only depends on the block input: it runs on the plan's side lane, next to conv_res0
+                # (the skip conv only depends on the block input: queued ahead of conv_res0.  Running the two on parallel branches of the
+                # graph measured 2.5 % slower -- every fork / join pair costs more cross-queue synchronisation than the overlapped 15-20 us
+                # kernels save; round 4: two half-batch chains on two branches 525 vs 457 us for the full batch on one, tools/lane_probe.py)
                 pw_skip = self.prep(blk.conv_skip, npix=npix, in_split=src0.shape[3] if src1 is not None else 0, in_scale0=s0, in_scale1=s1)
                 sk = self.act(h, w, cout)
-                # (only where the kernels leave CUs idle: large layers fill the chip on their own and lose from sharing it)
-                two_lanes = npix <= self.LANE_MAX_PIXELS
-                if two_lanes:
-                    self.steps.insert(len(self.steps) - 1, self._fork)
                 self.steps.insert(len(self.steps) - 1, lambda: ops.conv2d(src0, pw_skip, out_hw=(h, w), src1=src1, resample=rs, out=sk))
-                if two_lanes:
-                    self.steps.insert(len(self.steps) - 1, self._main)
-                    S(self._join)
             elif rs != RESAMPLE_KEEP:
                 sk = self.act(h, w, cout)      # no skip conv: the residual is the (resampled) block input itself
                 S(lambda: ops.resample2d(src0, sk, rs))
@@ -260,45 +240,37 @@ class PlanBuilder:
         if not attn:
             return xo, twin
         heads = blk.num_heads
-        sm_qk = pw_res1.CK == 16
         # attn_qk and attn_v read the same tensor: ONE conv over the row-concatenated weights writes [q|k (2C) | v (C)]; the
         # channel-scale prologue (x * c_qk) only applies to the q|k output tiles (one 15 us small-M launch less per block)
         pw_proj = self.prep(blk.attn_proj, npix=npix)
         ao, xa = self.act(h, w, cout), self.act(h, w, cout)
         tw_proj = dict(out2=twin, out2_scale=twin_scale) if twin is not None else {}
-        if MERGE_QKV:
-            pw_qkv = self.prep_merged([(blk.attn_qk, cout // heads), (blk.attn_v, 0)], npix=npix, allow_sm=sm_qk)
-            qkv = self.act(h, w, 3 * cout)
-            qk, vv = qkv[..., :2 * cout], qkv[..., 2 * cout:]
-            if pw_qkv.CK == 16:
-                S(lambda: ops.conv2d(xo, pw_qkv, src0_alt=xs, prologue_rows=2 * cout, out=qkv))
-            elif self._qkv_twin_ok(xo, pw_qkv, cout, qkv, npix):
-                # large batches: x * c_qk is written once (one element-wise pass) and the q|k output tiles of the merged conv read it through
-                # src0_alt, so the conv takes raw operands and runs on the wide 1x1 units of the LDS-DMA kernel (B=32: 430 -> 700+ TFLOP/s)
-                xs2 = self.act(h, w, cout)
-                try:    # conv_res1 on the register-staged kernel writes the twin itself (kw1 is read when the queued step runs)
-                    twin_in_conv = ops.conv2d(y0, pw_res1, query=True, **dict(kw1, out2=xs2, out2_chan_scale=c_qk)) == 2
-                except Exception:
-                    twin_in_conv = False
-                if twin_in_conv:
-                    kw1.update(out2=xs2, out2_chan_scale=c_qk)
-                else:
-                    S(lambda: ops.silu_scale_fwd(xo, c_qk, 1.0, act=False, out=xs2))
-                S(lambda: ops.conv2d(xo, pw_qkv, src0_alt=xs2, prologue_rows=2 * cout, out=qkv))
+        pw_qkv = self.prep_merged([(blk.attn_qk, cout // heads), (blk.attn_v, 0)], npix=npix, allow_sm=False)
+        qkv = self.act(h, w, 3 * cout)
+        qk, vv = qkv[..., :2 * cout], qkv[..., 2 * cout:]
+        if self._qkv_twin_ok(xo, pw_qkv, cout, qkv, npix):
+            # from QKV_TWIN_MIN_PIXELS pixels: x * c_qk is a materialised twin and the q|k output tiles of the merged conv read it through
+            # src0_alt, so the conv takes raw operands and runs on the 1x1 GEMM kernel (level 3 at B=4: 35 -> 21-24 us) or the wide 1x1
+            # units of the LDS-DMA kernel (B=32: 430 -> 700+ TFLOP/s)
+            xs2 = self.act(h, w, cout)
+            try:    # conv_res1 on the register-staged kernel writes the twin itself (kw1 is read when the queued step runs)
+                twin_in_conv = ops.conv2d(y0, pw_res1, query=True, **dict(kw1, out2=xs2, out2_chan_scale=c_qk)) == 2
+            except Exception:
+                twin_in_conv = False
+            if twin_in_conv:
+                kw1.update(out2=xs2, out2_chan_scale=c_qk)
             else:
-                S(lambda: ops.conv2d(xo, pw_qkv, prologue=PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * cout, out=qkv))
+                S(lambda: ops.silu_scale_fwd(xo, c_qk, 1.0, act=False, out=xs2))
+            S(lambda: ops.conv2d(xo, pw_qkv, src0_alt=xs2, prologue_rows=2 * cout, out=qkv))
         else:
-            pw_qk, pw_v = self.prep(blk.attn_qk, qk_head_dim=cout // heads, npix=npix, allow_sm=False), self.prep(blk.attn_v, npix=npix)
-            qk, vv = self.act(h, w, 2 * cout), self.act(h, w, cout)
-            S(lambda: ops.conv2d(xo, pw_v, out=vv))
-            S(lambda: ops.conv2d(xo, pw_qk, prologue=PRO_SCALE, chan_scale=c_qk, out=qk))
+            S(lambda: ops.conv2d(xo, pw_qkv, prologue=PRO_SCALE, chan_scale=c_qk, prologue_rows=2 * cout, out=qkv))
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
 
     def _qkv_twin_ok(self, xo, pw_qkv, cout, qkv, npix) -> bool:
-        """Merged attn_qk | attn_v conv on the LDS-DMA kernel with a materialised x * c_qk twin (src0_alt)?  From QKV_TWIN_MIN_PIXELS
-        pixels: at the benchmark batch (1376 pixels at level 3) the extra pass costs what the faster conv gains (4.60 vs 4.59 ms)."""
+        """Merged attn_qk | attn_v conv on raw operands with a materialised x * c_qk twin (src0_alt)?  From QKV_TWIN_MIN_PIXELS pixels
+        (level 3 at B=4; below that -- 344 pixels at level 4 -- neither the GEMM kernel nor the LDS-DMA units have enough tiles)."""
         if self.training or self.dt != torch.bfloat16 or QKV_TWIN_MIN_PIXELS <= 0 or npix < QKV_TWIN_MIN_PIXELS:
             return False
         try:
@@ -307,7 +279,7 @@ class PlanBuilder:
             return False
 
     def _fused_pixelnorm(self, src0, pw_skip, x1, x1a) -> bool:
-        """Does the library run this encoder skip conv with DDX_EPI_PIXELNORM (bf16 inference plans; DDX_FUSE_PIXELNORM=0: never)?"""
+        """Does the library run this encoder skip conv with DDX_EPI_PIXELNORM (bf16 inference plans)?"""
         if not FUSE_PIXELNORM or self.training or self.dt != torch.bfloat16:
             return False
         try:
@@ -334,24 +306,6 @@ class PlanBuilder:
             ops.mark_c16(y0)
         if twin is not None and q1 == 3 and twin.shape[3] % 16 == 0 and kw1.get("out2") is twin:
             ops.mark_c16(twin)
-
-    # B*H*W up to which independent convs of a block (skip conv || conv_res0, attn_v || attn_qk) are put on two lanes of
-    # the plan.  Measured on MI355X (hipGraph): every fork/join pair costs more cross-queue synchronisation than the
-    # overlapped 15-20 us kernels save (5.30 vs 5.16 ms per step with 30 forks at L3/L4) -> off by default.
-    LANE_MAX_PIXELS = 0
-
-    # two-lane plan markers (no-ops outside a recording)
-    @staticmethod
-    def _fork() -> None:
-        check(lib().ddx_plan_fork(), "plan_fork")
-
-    @staticmethod
-    def _main() -> None:
-        check(lib().ddx_plan_main(), "plan_main")
-
-    @staticmethod
-    def _join() -> None:
-        check(lib().ddx_plan_join(), "plan_join")
 
     # ------------------------------------------------------------------------------------------ finalize / run
     def gain_ptr(self, slot: Optional[int]):
@@ -384,24 +338,15 @@ class PlanBuilder:
                 if self.lin_jobs:
                     ops.linear_small(self.emb_table, n_jobs, max_o, emb, self.B, wdt, x_stride=emb_stride)
                 for st in self.steps:
-                    if st not in (self._fork, self._main, self._join):
-                        st()
+                    st()
             torch.cuda.current_stream().synchronize()
         with self.fplan.record():
             if pre_steps is not None:
                 pre_steps()
-            # the batched emb_linear launch streams every block's modulation weights (~130 MB for the default UNet, ~55 us);
-            # optionally (EMB_LANE) on the plan's side lane next to the front of the network, joined before the first conv_res0
-            lane = EMB_LANE and bool(self.lin_jobs) and self.first_cvec_step is not None and self.first_cvec_step > 0
-            if lane:
-                self._fork()
+            # the batched emb_linear launch streams every block's modulation weights (~130 MB for the default UNet, ~55 us)
             if self.lin_jobs:
                 ops.linear_small(self.emb_table, n_jobs, max_o, emb, self.B, wdt, x_stride=emb_stride)
-            if lane:
-                self._main()
-            for i, st in enumerate(self.steps):
-                if lane and i == self.first_cvec_step:
-                    self._join()
+            for st in self.steps:
                 st()
 
     def refresh_weights(self, params) -> None:
