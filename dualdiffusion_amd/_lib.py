@@ -308,9 +308,11 @@ class Plan:
                 if not h:
                     raise DDXError("ddx_plan_begin failed: " + lib().ddx_last_error().decode())
                 plan._h = h
+                plan._recording = True
                 return plan
 
             def __exit__(self_inner, et, ev, tb):
+                plan._recording = False
                 check(lib().ddx_plan_end(plan._h), "plan_end")
                 return False
 
@@ -332,6 +334,8 @@ class Plan:
 
     def include(self, other: "Plan") -> None:
         """While THIS plan is being recorded: append the launches of the finished plan `other`."""
+        if not getattr(self, "_recording", False):     # (ddx_plan_include appends to whichever plan is recording: it must be this one)
+            raise DDXError("Plan.include: this plan is not the one being recorded")
         check(lib().ddx_plan_include(other._h), "plan_include")
         self.keepalive.append(other)
 

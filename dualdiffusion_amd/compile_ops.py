@@ -15,30 +15,41 @@ of dualdiffusion_amd.autograd is a torch.autograd.Function, which Dynamo already
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
 
-# handle -> object.  A plain dict with id() keys: Dynamo traces `handle_of` itself (id() and a global dict store are supported), so the
-# registration happens while the caller is being compiled.  Entries are strong references: a module that was part of a compiled
-# graph stays alive as long as the process (the compiled graph holds its handle as a constant).
+from ._lib import DDXError
+
+# handle -> weak reference (strong where the type has no weak references).  Dynamo traces `handle_of` itself (id() and a global dict
+# store are supported), but the store is a DEFERRED side effect: while the caller is being traced the fake implementations see the
+# handle before the registry does.  `_get` then looks the id up among the live, GC-tracked objects (the traced caller holds the
+# object, so it is there) -- never by casting the integer to a pointer: a stale or foreign handle raises instead of being dereferenced.
 _OBJECTS: dict = {}
 
 
 def handle_of(obj) -> int:
     """Integer handle of a module / format object."""
     h = id(obj)
-    _OBJECTS[h] = obj
+    try:
+        _OBJECTS[h] = weakref.ref(obj)
+    except TypeError:
+        _OBJECTS[h] = lambda o=obj: o
     return h
 
 
 def _get(h: int):
-    obj = _OBJECTS.get(h, None)
+    ref = _OBJECTS.get(h, None)
+    obj = ref() if ref is not None else None
     if obj is None:
-        # while Dynamo traces, the dict store of `handle_of` is a deferred side effect: the fake implementations see the handle before
-        # the registry does.  The object is alive (the traced caller holds it), so its id() can be turned back into a reference.
-        import ctypes
-        obj = ctypes.cast(h, ctypes.py_object).value
+        _OBJECTS.pop(h, None)
+        import gc
+        obj = next((o for o in gc.get_objects() if id(o) == h), None)
+        if obj is None:
+            raise DDXError(f"dualdiffusion_amd custom op: unknown or expired module handle {h} (the module a compiled graph was traced "
+                           "with must stay alive, and handles come from compile_ops.handle_of)")
+        handle_of(obj)
     return obj
 
 

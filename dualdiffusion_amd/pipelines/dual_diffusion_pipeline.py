@@ -293,7 +293,7 @@ class DualDiffusionPipeline(torch.nn.Module):
 
         if p.seamless_loop:
             return self._decode_seamless(p, steps, sig_table, sample, ref_in, unet, fmt, emb, B, np_gen, draw)
-        if self.step_graph and emb is not None and hasattr(unet, "_engine_for") and not unet.training:
+        if self.step_graph and emb is not None and hasattr(unet, "_engine_for") and not unet.training and self._step_graph_ok(steps, sample, nb):
             return self._decode_step_graph(p, steps, sig_table, sample, ref_in, unet, fmt, emb, B, nb, draw)
         for i, (s_curr, t_hat, t, noise_gain) in enumerate(steps):
             guided(sample, sig_table[i, 0], cfg)
@@ -310,50 +310,76 @@ class DualDiffusionPipeline(torch.nn.Module):
     # the whole CFG + Heun step as ONE hipGraph; False: the eager step loop (UNet plan + lincomb launches per step)
     step_graph = os.environ.get("DDX_STEP_GRAPH", "1") != "0"
 
+    # ddx_sampler_load serves at most 256 UNet rows; the per-step noise is staged up front (steps x sample fp32): beyond this budget the
+    # eager loop (one draw per step) runs instead
+    STEP_GRAPH_MAX_ROWS = 256
+    STEP_GRAPH_NOISE_BYTES = 2 << 30
+    STEP_PLAN_CACHE = 4
+
+    def _step_graph_ok(self, steps, sample, nb) -> bool:
+        any_noise = any(ng > 0 for (_s, _th, _t, ng) in steps)
+        return nb <= self.STEP_GRAPH_MAX_ROWS and (not any_noise or len(steps) * sample.numel() * 4 <= self.STEP_GRAPH_NOISE_BYTES)
+
     def _decode_step_graph(self, p, steps, sig_table, sample, ref_in, unet, fmt, emb, B, nb, draw) -> torch.Tensor:
         """The sampler loop with one graph launch per step: [copy-in + sigma row, UNet forward, CFG lerp, Heun lerp, copy-in, UNet forward,
         CFG lerp, average, update (+ ancestral noise), step counter] recorded once over static buffers (the UNet engine's own launch
         plan is included twice); the per-step scalars (sigma rows, lerp weights, noise gain) and the step's noise tensor are read on
         the device through a step counter, so nothing runs on the host -- or in ATen -- between two UNet forwards.  Same kernels,
-        same arithmetic and the same generator draws, in the same order, as the eager loop."""
+        same arithmetic and the same generator draws, in the same order, as the eager loop.  The recorded plan and its hipGraph are
+        kept per (engine, steps, Heun, noise, cfg scale) and reused by later calls: only the tables and the sample are refreshed."""
         from .._lib import Plan
         dev = sample.device
         eng = unet._engine_for(nb, sample.shape[2], sample.shape[3], ref_in is not None)
         eng.prepare(fmt, emb, ref_in)
         n = len(steps)
-        coef = torch.tensor([[1.0 - th, th, 1.0 - t, t, ng] for (_s, th, t, ng) in steps], dtype=torch.float32).to(dev)
+        coef = torch.tensor([[1.0 - th, th, 1.0 - t, t, ng] for (_s, th, t, ng) in steps], dtype=torch.float32)
         any_noise = any(ng > 0 for (_s, _th, _t, ng) in steps)
-        noise_buf = None
-        if any_noise:   # drawn up front, in the eager loop's order (steps x sample: 0.56 GB at B = 16, 100 steps)
-            noise_buf = torch.zeros((n,) + tuple(sample.shape), device=dev, dtype=torch.float32)
+        cache = self.__dict__.setdefault("_step_plans", {})
+        key = (id(eng), n, bool(p.use_heun), any_noise, float(p.cfg_scale), tuple(sample.shape))
+        st = cache.get(key)
+        if st is not None and st["eng"] is not eng:      # (an id() recycled by a new engine)
+            st = None
+        if st is None:
+            st = dict(eng=eng, sample=torch.empty_like(sample), coef=torch.empty(n, 5, dtype=torch.float32, device=dev),
+                      sig_table=torch.empty_like(sig_table), stepc=torch.zeros(1, dtype=torch.int32, device=dev),
+                      # drawn up front, in the eager loop's order (steps x sample: 0.56 GB at B = 16, 100 steps)
+                      noise_buf=torch.zeros((n,) + tuple(sample.shape), device=dev, dtype=torch.float32) if any_noise else None)
+            cfg, cfg_hat, x_hat = (torch.empty_like(sample) for _ in range(3))
+            s_buf, c_buf, t_buf, stepc, noise_buf = st["sample"], st["coef"], st["sig_table"], st["stepc"], st["noise_buf"]
+            eng.pb.launch(False)        # one eager pass of the UNet plan outside any capture (kernel attributes of a first launch)
+            plan = Plan()
+            with plan.record():
+                ops.sampler_load(s_buf, eng.x_in, eng.x_pre, eng.sigma, t_buf, stepc, 0)
+                plan.include(eng.fplan)
+                ops.lincomb3(cfg, eng.out[:B], p.cfg_scale, eng.out[B:], 1.0 - p.cfg_scale)            # uncond.lerp(cond, cfg_scale)
+                if p.use_heun:
+                    ops.lincomb3_dev(x_hat, c_buf, stepc, cfg, 0, s_buf, 1)                            # lerp(cfg, sample, t_hat)
+                    ops.sampler_load(x_hat, eng.x_in, eng.x_pre, eng.sigma, t_buf, stepc, 1)
+                    plan.include(eng.fplan)
+                    ops.lincomb3(cfg_hat, eng.out[:B], p.cfg_scale, eng.out[B:], 1.0 - p.cfg_scale)
+                    ops.lincomb3(cfg, cfg, 0.5, cfg_hat, 0.5)
+                ops.lincomb3_dev(s_buf, c_buf, stepc, cfg, 2, s_buf, 3, noise_buf, 4 if any_noise else -1, z_step_stride=s_buf.numel())
+                ops.step_advance(stepc)
+            plan.keepalive += [c_buf, noise_buf, stepc, cfg, cfg_hat, x_hat, t_buf, s_buf, eng]
+            torch.cuda.current_stream().synchronize()
+            cap = torch.cuda.Stream(device=dev)          # the legacy default stream cannot be captured
+            plan.graph_build(cap.cuda_stream)
+            cap.synchronize()
+            st["plan"] = plan
+            while len(cache) >= self.STEP_PLAN_CACHE:
+                cache.pop(next(iter(cache)))
+            cache[key] = st
+        st["sample"].copy_(sample)
+        st["coef"].copy_(coef)
+        st["sig_table"].copy_(sig_table)
+        st["stepc"].zero_()
+        if any_noise:
             for i, (_s, _th, _t, ng) in enumerate(steps):
                 if ng > 0:
-                    noise_buf[i].copy_(draw(1 + i))
-        stepc = torch.zeros(1, dtype=torch.int32, device=dev)
-        cfg, cfg_hat, x_hat = (torch.empty_like(sample) for _ in range(3))
-        eng.pb.launch(False)        # one eager pass of the UNet plan outside any capture (kernel attributes of a first launch)
-        plan = Plan()
-        with plan.record():
-            ops.sampler_load(sample, eng.x_in, eng.x_pre, eng.sigma, sig_table, stepc, 0)
-            plan.include(eng.fplan)
-            ops.lincomb3(cfg, eng.out[:B], p.cfg_scale, eng.out[B:], 1.0 - p.cfg_scale)            # uncond.lerp(cond, cfg_scale)
-            if p.use_heun:
-                ops.lincomb3_dev(x_hat, coef, stepc, cfg, 0, sample, 1)                            # lerp(cfg, sample, t_hat)
-                ops.sampler_load(x_hat, eng.x_in, eng.x_pre, eng.sigma, sig_table, stepc, 1)
-                plan.include(eng.fplan)
-                ops.lincomb3(cfg_hat, eng.out[:B], p.cfg_scale, eng.out[B:], 1.0 - p.cfg_scale)
-                ops.lincomb3(cfg, cfg, 0.5, cfg_hat, 0.5)
-            ops.lincomb3_dev(sample, coef, stepc, cfg, 2, sample, 3, noise_buf, 4 if any_noise else -1, z_step_stride=sample.numel())
-            ops.step_advance(stepc)
-        plan.keepalive += [coef, noise_buf, stepc, cfg, cfg_hat, x_hat, sig_table, sample, eng]
-        torch.cuda.current_stream().synchronize()
-        cap = torch.cuda.Stream(device=dev)          # the legacy default stream cannot be captured
-        plan.graph_build(cap.cuda_stream)
-        cap.synchronize()
+                    st["noise_buf"][i].copy_(draw(1 + i))
         for _ in range(n):
-            plan.graph_launch()
-        torch.cuda.current_stream().synchronize()    # the plan's buffers go out of scope with this frame
-        return sample
+            st["plan"].graph_launch()
+        return st["sample"].clone()
 
     def _decode_seamless(self, p, steps, sig_table, sample, ref_in, unet, fmt, emb, B, np_gen, draw) -> torch.Tensor:
         """seamless_loop (reference :651-658, :729-732): every step rolls the sample (and the reference input) by a random shift

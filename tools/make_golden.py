@@ -309,7 +309,14 @@ def gen_unet_default() -> None:
     coll = {}
     ours = O.unet_forward(sd, cfg, x_in, sigma, emb, collect=coll)
     check("default forward", ours, out, 1e-5)
-    t = {"x_in": x_in, "sigma": sigma, "clap": clap, "mask": mask.to(torch.uint8), "embeddings": emb, "out": out}
+    # the reference's OWN bfloat16 forward of the same model (module.half() is .to(bfloat16), modules/module.py:133-134; weights and
+    # activations in bf16 on the CPU): the yardstick the HIP bf16 path is judged against at the benchmarked size
+    unet_bf = unet.half()
+    with torch.no_grad():
+        out_bf = unet_bf(x_in, sigma, fmt, unet_bf.get_embeddings(clap, mask)).float()
+    ref_bf16_err = float((out_bf.double() - out.double()).norm() / out.double().norm())
+    print(f"  reference bf16 vs reference fp32 (default UNet, B=1): rel-L2 {ref_bf16_err:.3e}")
+    t = {"x_in": x_in, "sigma": sigma, "clap": clap, "mask": mask.to(torch.uint8), "embeddings": emb, "out": out, "out_ref_bf16": out_bf}
     STRIDE = 389
     for k, v in got.items():
         check(f"stage {k}", coll[k], v, 1e-5)
@@ -836,6 +843,62 @@ def gen_vae_default() -> None:
                                  stage_stride=STRIDE, recon_stride=7, freq_range=[20.0, 16000.0], weights="oracle.random_vae_state(cfg, seed)"))
 
 
+def gen_config5_b16() -> None:
+    """BASELINE.json configs[4] at its real batch, through ONE sample: the reference's diffusion_decode (default 293 M UNet, CFG + Heun, 2
+    steps, no ancestral noise) on the first sample of a batch-16 noise draw, then the default VAE's decode of that latent.  Samples of a
+    batch are independent in both stages, so sample 0 of the HIP pipeline at B = 16 (UNet batch 32) must reproduce this
+    (tests/test_gpu_fullsize.py::test_config5_real_batch_sample0_vs_reference)."""
+    print("config 5 at B=16, sample 0 (default UNet sampler 2 steps -> default VAE decode)")
+    import types
+    from pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams
+    ref_import.install_old_vae()
+    from modules.old.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config
+    from modules.formats.frequency_scale import FrequencyScale
+    ucfg = O.unet_cfg(channel_mult_noise=1, channel_mult_emb=3)
+    unet = make_ref_unet(ucfg)
+    unet.load_state_dict(O.random_unet_state(ucfg, 5))
+    SEED, STEPS, B = 4242, 2, 16
+    shape1 = (1, 4, 32, 688)
+    n1 = 4 * 32 * 688
+    # sample 0 of a batch-16 draw IS the batch-1 draw of the same CPU generator (the fill is sequential in blocks of 16 values)
+    big = torch.randn((B,) + shape1[1:], generator=torch.Generator().manual_seed(SEED))
+    one = torch.randn(shape1, generator=torch.Generator().manual_seed(SEED))
+    assert torch.equal(big[:1], one) and n1 % 16 == 0
+    g = torch.Generator().manual_seed(SEED + 1)
+    clap = torch.randn(1, 512, generator=g)
+    params = SampleParams(seed=SEED, num_steps=STEPS, batch_size=1, length=1, sigma_max=80.0, sigma_min=0.05, sigma_data=1.0, rho=7.0,
+                          schedule="edm2", use_heun=True, cfg_scale=1.5, input_perturbation=0.0)
+    fake = types.SimpleNamespace(format=FakeFormat())
+    with torch.no_grad():
+        lat = DualDiffusionPipeline.diffusion_decode(fake, params, quiet=True, audio_embedding=clap.repeat(2, 1), sample_shape=shape1, module=unet)
+    del unet
+    over = dict(model_channels=96, channel_mult=(1, 2, 3, 5), num_layers_per_block=3, label_dim=1612, target_snr=31.984371183438952,
+                mlp_multiplier=1, mlp_groups=1, channel_mult_emb=None)
+    vcfg = O.vae_cfg(**over)
+    vae = AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**{k: (list(v) if isinstance(v, tuple) else v) for k, v in vcfg.items()}))
+    vae = vae.requires_grad_(False).train(False)
+    vsd = O.random_vae_state(vcfg, seed=31)
+    vae.load_state_dict(vsd)
+
+    class Fmt:
+        fs = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+        def get_ln_freqs(self, x):
+            ln = self.fs.get_unscaled(x.shape[2] + 2, device=x.device)[1:-1].log2()
+            ln = ln.view(1, 1, -1, 1).repeat(x.shape[0], 1, 1, x.shape[3])
+            return ((ln - ln.mean()) / ln.std()).to(x.dtype)
+
+    labels_like = torch.randn(1, vcfg["label_dim"], generator=g)
+    with torch.no_grad():
+        vemb = R_silu(vae.emb_label(R_normalize(labels_like)))
+        rec = vae.decode(lat, vemb, Fmt())
+    check("config5 vae decode of the sampled latent", O.vae_decode(vsd, vcfg, lat, vemb), rec, 1e-5)
+    t = {"clap": clap, "labels_like": labels_like, "latents": lat, "recon_sub": _sub(rec, 7)}
+    save("config5_b16", t, dict(seed=SEED, num_steps=STEPS, B=B, shape=list(shape1), sigma_max=80.0, sigma_min=0.05, cfg_scale=1.5, unet_seed=5,
+                                vae_seed=31, vae_cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in over.items()}, recon_stride=7,
+                                freq_range=[20.0, 16000.0]))
+
+
 def gen_ddec_default() -> None:
     """DDec_MCLT_UNet_B1 with its default config (32 x (1,2,3,4), 3 layers per block, 4096 PSD bins) on a (1, 2, 256, 344) input."""
     print("ddec default (real widths, B=1, 256 x 344)")
@@ -953,7 +1016,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default, "loader": gen_loader}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default, "loader": gen_loader, "config5_b16": gen_config5_b16}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
