@@ -118,7 +118,8 @@ class WPathJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wp_t", C.c_void_p), ("row_scale", C.c_void_p), ("gain_ptr", C.c_void_p),
                 ("dwp", C.c_void_p), ("dw", C.c_void_p), ("dgain", C.c_void_p), ("gain", C.c_float),
                 ("Cout", C.c_int32), ("Cg", C.c_int32), ("ksize", C.c_int32), ("groups", C.c_int32), ("CK", C.c_int32), ("CK_t", C.c_int32),
-                ("normalize", C.c_int32), ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float)]
+                ("normalize", C.c_int32), ("qk_head_dim", C.c_int32), ("in_split", C.c_int32), ("in_scale0", C.c_float), ("in_scale1", C.c_float),
+                ("dwp_parts", C.c_int32), ("reserved", C.c_int32)]
 
 
 WPATH_NORMALIZE, WPATH_PREP, WPATH_ROWSCALE, WPATH_TRANSPOSED, WPATH_BWD = range(5)
@@ -180,6 +181,8 @@ PROTOTYPES = {
                                     C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ddx_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ddx_mpconv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "ddx_wgrad_parts": (C.c_int32, [C.POINTER(WgradDesc)]),
+    "ddx_wgrad_parts_max": (C.c_int32, [C.c_int32] * 4),
     "ddx_silu_scale_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_void_p]),
     "ddx_silu_scale_bwd_ex": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

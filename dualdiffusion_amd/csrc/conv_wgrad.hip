@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // split-K factor: enough units to fill the chip (512 workgroup slots; 768 measured 4-5 % slower on the train step: more
 // partial-sum traffic for no shorter critical path), but never more partial-sum traffic than ~4x the
 // gradient itself (small-M layers have large weights and few pixel tiles: they run unsplit and write dW directly)
-int wgrad_ksplit(int G, int Ng, int Cg, int ks, int ntile_px, bool wide = false) {
+int wgrad_ksplit(int G, int Ng, int Cg, int ks, long ntile_px, bool wide = false) {
   const int bcw = wide ? 128 : (ks == 3 ? 32 : 64);
   const long base = (long)G * ceil_div(Ng, wide ? 128 : 64) * ceil_div(Cg, bcw);
   const long want_units = 512;      // (768 measured slower: more partial-sum traffic, same critical path)
@@ -517,6 +517,28 @@ extern "C" size_t ddx_wgrad_workspace_bytes(const ddx_wgrad_desc* dp) {
   return (size_t)p.ksplit * p.Cout * p.Cg * d.ksize * d.ksize * sizeof(float);
 }
 
+extern "C" int32_t ddx_wgrad_parts(const ddx_wgrad_desc* dp) {
+  if (!dp || dp->dtype != DDX_BF16) return 0;
+  WgradParams p{};
+  ddx_wgrad_desc d = *dp;
+  static float dummy;
+  if (!d.dw) d.dw = &dummy;
+  if (!d.dy) d.dy = &dummy;
+  if (!d.x0) d.x0 = &dummy;
+  if (d.C1 > 0 && !d.x1) d.x1 = &dummy;
+  if (wgrad_fill(d, &p) != 0) return 0;
+  return p.ksplit;
+}
+
+extern "C" int32_t ddx_wgrad_parts_max(int32_t Cout, int32_t Cg, int32_t groups, int32_t ksize) {
+  if (Cout <= 0 || Cg <= 0 || groups <= 0 || Cout % groups || (ksize != 1 && ksize != 3)) return 0;
+  const int Ng = Cout / groups;
+  // (the two tilings of a 1x1 layer have different unit counts: the bound covers both)
+  const int a = wgrad_ksplit(groups, Ng, Cg, ksize, 1l << 40, false);
+  const int b = ksize == 1 && Ng % 128 == 0 && Cg % 128 == 0 ? wgrad_ksplit(groups, Ng, Cg, ksize, 1l << 40, true) : 1;
+  return std::max(a, b);
+}
+
 extern "C" int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* dp, ddx_stream stream) {
   if (!dp) return set_error(DDX_ERR_ARG, "wgrad: null descriptor");
   const ddx_wgrad_desc d = *dp;
@@ -530,7 +552,10 @@ extern "C" int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* dp, ddx_stream stream) {
   const int accumulate = d.accumulate;
   const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
   const double bytes = 2.0 * ((double)p.B * p.H * p.W * p.Cout + (double)p.B * p.sH * p.sW * p.Cin) + 4.0 * n;
+  if (accumulate < 0 || accumulate > 2) return set_error(DDX_ERR_ARG, "wgrad: accumulate");
   return dispatch([p, ks, n, dw, accumulate](hipStream_t s) -> int {
+    if (accumulate == 2)   // the split-K slices stay in the workspace: the consumer adds them (ddx_wpath_job.dwp_parts)
+      return p.wide ? launch_wgrad1x1_wide(p, s) : (ks == 3 ? launch_wgrad<3>(p, s) : launch_wgrad<1>(p, s));
     if (p.ksplit == 1 && !accumulate) {  // unsplit: the kernel writes the gradient itself
       WgradParams q = p;
       q.ws = dw;

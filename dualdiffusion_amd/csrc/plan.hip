@@ -90,7 +90,7 @@ extern "C" int64_t ddx_abi_offsetof_tail(int32_t which) {
     case 2: return offsetof(ddx_dgrad_act_desc, scale1);
     case 3: return offsetof(ddx_wgrad_desc, accumulate);
     case 4: return offsetof(ddx_linear_bwd_job, groups);
-    case 5: return offsetof(ddx_wpath_job, in_scale1);
+    case 5: return offsetof(ddx_wpath_job, reserved);
     case 6: return offsetof(ddx_linear_job, normalize);
     case 7: return offsetof(ddx_melstft_desc, scale);
     case 8: return offsetof(ddx_msmel_desc, offset);

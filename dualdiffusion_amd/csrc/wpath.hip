@@ -36,8 +36,13 @@ __global__ __launch_bounds__(256) void wpath_multi_kernel(const ddx_wpath_job* _
     wprep_transposed_row_w<TP>(w, reinterpret_cast<TP*>(J.wp_t), J.row_scale, J.Cout, J.Cg, taps, J.groups, J.CK_t, J.qk_head_dim, J.in_split,
                                J.in_scale0, J.in_scale1, row, lane);
   } else {
-    wprep_bwd_row_w(J.dwp, w, J.gain_ptr, J.gain, J.dw, J.dgain, J.Cout, J.Cg, taps, J.groups, J.normalize, J.qk_head_dim, eps, J.in_split,
-                    J.in_scale0, J.in_scale1, row, lane);
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][kWpathRowBuf];
+    if (J.dwp_parts > 1)
+      wprep_bwd_row_parts_w(J.dwp, J.dwp_parts, w, J.gain_ptr, J.gain, J.dw, J.dgain, J.Cout, J.Cg, taps, J.groups, J.normalize, J.qk_head_dim, eps,
+                            J.in_split, J.in_scale0, J.in_scale1, row, lane, rowbuf[threadIdx.x >> 6]);
+    else
+      wprep_bwd_row_w(J.dwp, w, J.gain_ptr, J.gain, J.dw, J.dgain, J.Cout, J.Cg, taps, J.groups, J.normalize, J.qk_head_dim, eps, J.in_split,
+                      J.in_scale0, J.in_scale1, row, lane);
   }
 }
 

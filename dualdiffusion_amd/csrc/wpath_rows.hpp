@@ -214,6 +214,93 @@ __device__ __forceinline__ void wprep_transposed_row_w(const float* __restrict__
   }
 }
 
+// The same with the prepared-weight gradient given as `parts` split-K slices [parts][Cout][fan] (ddx_wpath_job.dwp_parts): the slices are
+// added in slice order while the row is read (once: the summed row waits in `rowbuf`, fan <= kWpathRowBuf floats of LDS per wave, for the
+// second pass; longer rows read the slices twice).
+constexpr int kWpathRowBuf = 3072;
+__device__ __forceinline__ void wprep_bwd_row_parts_w(const float* __restrict__ dwp, int parts, const float* __restrict__ w, const float* gain_ptr,
+                                                      float gain, float* __restrict__ dw, float* __restrict__ dgain, int Cout, int Cg, int taps, int G,
+                                                      int normalize, int qk_d, float eps, int in_split, float in_s0, float in_s1, int od, int lane,
+                                                      float* rowbuf) {
+  const int Ng = Cout / G;
+  const int g = od / Ng;
+  const int os = wpath_src_row(od, qk_d);
+  const int fan = Cg * taps;
+  const size_t pstride = (size_t)Cout * fan;
+  const float* wr = w + (size_t)os * fan;
+  const float* gr = dwp + (size_t)od * fan;
+  auto cat_scale = [&](int i) { return in_split > 0 ? ((g * Cg + i / taps < in_split) ? in_s0 : in_s1) : 1.0f; };
+  float* dr = dw + (size_t)os * fan;
+  const bool keep = fan <= kWpathRowBuf;
+  auto grad_at = [&](int i) {
+    float s = gr[i];
+    for (int k = 1; k < parts; ++k) s += gr[(size_t)k * pstride + i];
+    return s;
+  };
+  float ss = 0.f, su = 0.f;
+  if ((fan & 3) == 0 && aligned16(wr) && aligned16(gr) && aligned16(dr) && (pstride & 3) == 0) {
+    const f32x4* pw = reinterpret_cast<const f32x4*>(wr);
+    const f32x4* pg = reinterpret_cast<const f32x4*>(gr);
+    const size_t ps4 = pstride >> 2;
+    // (eight slices in flight per lane: the slices of a short row -- 288 floats at level 0, up to 128 slices -- are otherwise one dependent
+    // round trip each; four running sums, combined in a fixed order: deterministic)
+    auto grad4 = [&](int i) {
+      f32x4 s0 = pg[i], s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+      int k = 1;
+      for (; k + 7 < parts; k += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pg[(size_t)(k + u) * ps4 + i];
+        s0 += t[0]; s1 += t[1]; s2 += t[2]; s3 += t[3];
+        s0 += t[4]; s1 += t[5]; s2 += t[6]; s3 += t[7];
+      }
+      for (; k < parts; ++k) s0 += pg[(size_t)k * ps4 + i];
+      return (s0 + s1) + (s2 + s3);
+    };
+    for (int i = lane; i < (fan >> 2); i += 64) {
+      const f32x4 x = pw[i], gv = grad4(i);
+      if (keep) reinterpret_cast<f32x4*>(rowbuf)[i] = gv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ss += x[e] * x[e]; su += gv[e] * cat_scale(4 * i + e) * x[e]; }
+    }
+    ss = wave_sum(ss);
+    su = wave_sum(su);
+    const float rfan = sqrtf(1.0f / (float)fan);
+    const float n = sqrtf(ss);
+    const float nu = normalize ? eps + n * rfan : 1.0f;
+    float gn = gain;
+    if (gain_ptr) gn *= *gain_ptr;
+    const float s = gn * rfan;
+    const float k = (normalize && n > 0.f) ? su * rfan / (nu * n) : 0.f;
+    f32x4* pd = reinterpret_cast<f32x4*>(dr);
+    for (int i = lane; i < (fan >> 2); i += 64) {
+      const f32x4 x = pw[i], gv = keep ? reinterpret_cast<const f32x4*>(rowbuf)[i] : grad4(i);   // (a lane re-reads what it wrote)
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (s / nu) * (gv[e] * cat_scale(4 * i + e) - x[e] * k);
+      pd[i] = v;
+    }
+    if (dgain && lane == 0) atomicAdd(dgain, gain * su * rfan / nu);
+    return;
+  }
+  for (int i = lane; i < fan; i += 64) {
+    const float x = wr[i], gv = grad_at(i);
+    if (keep) rowbuf[i] = gv;
+    ss += x * x; su += gv * cat_scale(i) * x;
+  }
+  ss = wave_sum(ss);
+  su = wave_sum(su);
+  const float rfan = sqrtf(1.0f / (float)fan);
+  const float n = sqrtf(ss);
+  const float nu = normalize ? eps + n * rfan : 1.0f;
+  float gn = gain;
+  if (gain_ptr) gn *= *gain_ptr;
+  const float s = gn * rfan;
+  const float k = (normalize && n > 0.f) ? su * rfan / (nu * n) : 0.f;
+  for (int i = lane; i < fan; i += 64) dr[i] = (s / nu) * ((keep ? rowbuf[i] : grad_at(i)) * cat_scale(i) - wr[i] * k);
+  if (dgain && lane == 0) atomicAdd(dgain, gain * su * rfan / nu);
+}
+
 __device__ __forceinline__ void wprep_bwd_row_w(const float* __restrict__ dwp, const float* __restrict__ w, const float* gain_ptr, float gain,
                                                 float* __restrict__ dw, float* __restrict__ dgain, int Cout, int Cg, int taps, int G, int normalize,
                                                 int qk_d, float eps, int in_split, float in_s0, float in_s1, int od, int lane) {

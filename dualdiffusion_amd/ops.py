@@ -286,6 +286,24 @@ def conv2d_wgrad(dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, *,
     return out
 
 
+def conv2d_wgrad_parts(dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, parts: torch.Tensor, *, x1: Optional[torch.Tensor] = None,
+                       resample: int = L.RESAMPLE_KEEP) -> int:
+    """Weight gradient as split-K partial sums: `parts` [P, Cout, Cin/groups, k, k] fp32 receives the launch's slices in its first
+    ddx_wgrad_parts() entries (returned), no reduction launch -- the consumer adds them (training.weight_bank: the weight-path backward
+    reads `dwp_parts` slices per row).  Entries beyond the returned count are NOT touched: the caller keeps them zero."""
+    B, H, W, Cout = dy.shape
+    C0 = x0.shape[3]
+    C1 = x1.shape[3] if x1 is not None else 0
+    assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.shape[1:] == (Cout, (C0 + C1) // groups, ksize, ksize)
+    d = L.WgradDesc(dy=ptr(dy), x0=ptr(x0), x1=ptr(x1), dw=ptr(parts), workspace=ptr(parts), B=B, H=H, W=W, C0=C0, C1=C1, Cout=Cout,
+                    groups=groups, ksize=ksize, resample=resample, dtype=dtype_code(dy.dtype), accumulate=2)
+    n = int(lib().ddx_wgrad_parts(C.byref(d)))
+    if n <= 0 or n > parts.shape[0]:
+        raise L.DDXError(f"conv2d_wgrad_parts: the launch writes {n} slices, the buffer holds {parts.shape[0]}")
+    check(lib().ddx_mpconv2d_wgrad(C.byref(d), current_stream()), "mpconv2d_wgrad(parts)")
+    return n
+
+
 def _chan_view(t: torch.Tensor, Cn: int):
     """(data pointer, row stride) of an NHWC tensor or of a channel slice `t[..., c0:c0+Cn]` of one."""
     assert t.shape[-1] == Cn and t.stride(-1) == 1

@@ -103,7 +103,7 @@ def _wgrad(w: BlockWeightsT, key: str, pw, dy: torch.Tensor, x0: torch.Tensor, g
     filled by bank.backward())."""
     if w.bank is not None:
         name = f"{w.prefix}.{key}.weight"
-        ops.conv2d_wgrad(dy, x0, groups, ksize, x1=x1, out=w.bank.dwp[name])
+        w.bank.wgrad(name, dy, x0, groups, ksize, x1=x1)
         return w.bank.dw[name]
     return ops.wprep_bwd(pw, ops.conv2d_wgrad(dy, x0, groups, ksize, x1=x1))
 

@@ -53,6 +53,9 @@ class WeightBank:
         backward("early") / backward("late") run the weight-path backward for the two parts separately, so that the first
         gradient bucket can be all-reduced while the rest of the backward pass runs."""
         self.entries, self.dtype = entries, dtype
+        self.split_parts = dtype == torch.bfloat16      # (the fp32 parity GEMM writes finished gradients)
+        self.dwp_parts: dict = {}                       # conv layers: [parts, *weight.shape] views of the split-K slices
+        self._parts_used: dict = {}                     # slices the last launch of a layer wrote (stale ones are zeroed when it shrinks)
         dev = entries[0].weight.device
         self.dev = dev
         geo = []
@@ -73,7 +76,11 @@ class WeightBank:
             wp_bytes += nb
             wpt_bytes += nbt
             rs_floats += _align(Cout, 64) if (e.transpose or e.grad) else 0
-            dwp_floats += _align(w.numel(), 64) if e.grad else 0
+            # conv layers: the weight-gradient GEMM leaves its split-K slices here and the weight-path backward adds them while it reads
+            # the row (no reduction launch per layer: 106 launches / ~1 ms per B=8 step); the bound only depends on the weight's shape
+            parts = max(1, int(lib().ddx_wgrad_parts_max(Cout, Cg, e.groups, ks))) if (e.grad and e.prep and self.split_parts) else 1
+            geo[-1]["parts"] = parts
+            dwp_floats += _align(w.numel() * parts, 64) if e.grad else 0
         # zero-initialised: the padding rows / channels of the prepared layouts are never written afterwards
         self.wp_flat = torch.zeros(max(wp_bytes, 1), dtype=torch.uint8, device=dev)
         self.wpt_flat = torch.zeros(max(wpt_bytes, 1), dtype=torch.uint8, device=dev)
@@ -96,6 +103,8 @@ class WeightBank:
             gain_ptr = e.gain.reshape(1) if e.gain is not None else None
             if e.grad:
                 self.dwp[e.name] = self.dwp_flat[g["dwp_off"]:g["dwp_off"] + w.numel()].view(w.shape)
+                if g["parts"] > 1:
+                    self.dwp_parts[e.name] = self.dwp_flat[g["dwp_off"]:g["dwp_off"] + w.numel() * g["parts"]].view((g["parts"],) + tuple(w.shape))
                 self.dw[e.name] = grad_views[e.name]
                 if self.dw[e.name].numel() != w.numel() or self.dw[e.name].dtype != torch.float32:
                     raise L.DDXError(f"WeightBank: gradient view of {e.name} does not match the weight")
@@ -109,7 +118,7 @@ class WeightBank:
                                  dgain=ptr(self.dgain[e.name]) if e.name in self.dgain else None, gain=1.0,
                                  Cout=g["Cout"], Cg=g["Cg"], ksize=g["ks"], groups=e.groups, CK=g["CK"], CK_t=g["CKt"],
                                  normalize=int(e.normalize), qk_head_dim=e.qk_head_dim, in_split=e.in_split, in_scale0=e.in_scale0,
-                                 in_scale1=e.in_scale1)
+                                 in_scale1=e.in_scale1, dwp_parts=g["parts"], reserved=0)
             part = {L.WPATH_NORMALIZE: g["Cout"] if e.normalize else 0, L.WPATH_PREP: g["Cout"] if e.prep else 0,
                     # (PREP writes the row scales of the entries it prepares: the ROWSCALE phase only serves the others)
                     L.WPATH_ROWSCALE: g["Cout"] if (e.name in self.rs and not e.prep) else 0, L.WPATH_TRANSPOSED: g["Cin"] if e.transpose else 0,
@@ -129,6 +138,18 @@ class WeightBank:
                     r.append(r[-1] + (g["Cout"] if (e.grad and ((e.name in early) == want)) else 0))
                 self.part_prefix[part] = torch.tensor(r, dtype=torch.int32).to(dev)
                 self.part_total[part] = r[-1]
+
+    def wgrad(self, name: str, dy: torch.Tensor, x0: torch.Tensor, groups: int, ksize: int, x1: Optional[torch.Tensor] = None) -> None:
+        """Weight-gradient GEMM of conv layer `name` into the bank: split-K slices for backward() to add, or the finished gradient."""
+        parts = self.dwp_parts.get(name)
+        if parts is None:
+            ops.conv2d_wgrad(dy, x0, groups, ksize, x1=x1, out=self.dwp[name])
+            return
+        n = ops.conv2d_wgrad_parts(dy, x0, groups, ksize, parts, x1=x1)
+        prev = self._parts_used.get(name, 0)
+        if prev > n:            # a smaller batch / image than last time: the slices it no longer writes must read as zero
+            parts[n:prev].zero_()
+        self._parts_used[name] = n
 
     def _run(self, phase: int) -> None:
         check(lib().ddx_wpath_multi(ptr(self.jobs), ptr(self.prefix[phase]), self.njobs, self.total[phase], phase, dtype_code(self.dtype),

@@ -225,10 +225,16 @@ typedef struct {
   int32_t C0, C1, Cout, groups, ksize;
   int32_t resample;         /* DDX_RESAMPLE_KEEP | DDX_RESAMPLE_UP */
   int32_t dtype;            /* DDX_BF16 (matrix cores) | DDX_F32 (scalar parity kernel, no workspace needed) */
-  int32_t accumulate;
+  int32_t accumulate;       /* 0: dw = gradient; 1: dw += gradient; 2: leave the split-K partial sums [parts][Cout][Cg][ks][ks] in `workspace`
+                             * (parts = ddx_wgrad_parts(d)), no reduction, `dw` is not touched -- the consumer adds the slices
+                             * (ddx_wpath_job.dwp_parts) */
 } ddx_wgrad_desc;
 
 size_t ddx_wgrad_workspace_bytes(const ddx_wgrad_desc* d);
+/* split-K slices the launch described by `d` writes (0 when the descriptor is not served), and a bound that only depends on the
+ * weight's shape (for sizing a per-layer partial-sum buffer once): ddx_wgrad_parts(d) <= ddx_wgrad_parts_max(Cout, Cg, groups, ksize) */
+int32_t ddx_wgrad_parts(const ddx_wgrad_desc* d);
+int32_t ddx_wgrad_parts_max(int32_t Cout, int32_t Cg, int32_t groups, int32_t ksize);
 int ddx_mpconv2d_wgrad(const ddx_wgrad_desc* d, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -307,6 +313,10 @@ typedef struct {
   float gain;
   int32_t Cout, Cg, ksize, groups, CK, CK_t, normalize, qk_head_dim, in_split;
   float in_scale0, in_scale1;
+  /* BWD: dwp holds dwp_parts partial sums, [dwp_parts][Cout][Cg][k][k] (the split-K slices of ddx_mpconv2d_wgrad with accumulate = 2,
+   * unused slices zero), which the pass adds in slice order while it reads them -- the weight-gradient GEMMs need no reduction
+   * launch of their own.  0 or 1: dwp is the finished gradient. */
+  int32_t dwp_parts, reserved;
 } ddx_wpath_job;
 
 int ddx_wpath_multi(const ddx_wpath_job* jobs_dev, const int32_t* row_prefix_dev, int32_t njobs, int32_t total_rows, int32_t phase,
