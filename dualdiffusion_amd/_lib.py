@@ -204,6 +204,7 @@ PROTOTYPES = {
     "ddx_edm2_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int64, C.c_void_p]),
     "ddx_multi_grad_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "ddx_clip_coef": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "ddx_multi_adamw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int32, C.c_float, C.c_void_p]),
     "ddx_multi_adamw_ema_wn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -222,6 +222,14 @@ extern "C" int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs,
   }, stream, "grad_norm");
 }
 
+extern "C" int ddx_clip_coef(float* workspace3, float grad_scale, float max_norm, ddx_stream stream) {
+  if (!workspace3) return set_error(DDX_ERR_ARG, "clip_coef: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, (const float*)workspace3, grad_scale, max_norm, workspace3 + 1);
+    return check_launch("clip_coef");
+  }, stream, "grad_norm");
+}
+
 extern "C" int ddx_multi_adamw(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, const float* clip_coef, float grad_scale, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int32_t step, float ema_beta, ddx_stream stream) {
   if (!jobs_dev || njobs <= 0 || max_n <= 0 || step <= 0) return set_error(DDX_ERR_ARG, "multi_adamw: bad args");

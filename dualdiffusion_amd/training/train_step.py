@@ -147,12 +147,43 @@ class GradientExchange:
         self._pending = None
 
 
+class ShardedExchange:
+    """GradientExchange's interface over training.sharded.ShardedAdamW: the two bucket segments are reduce-scattered (the decoder's early,
+    asynchronously), the parameter pass then runs on this rank's shard and the updated parameters are all-gathered (ShardedAdamW.step)."""
+
+    def __init__(self, opt, flat: torch.Tensor, early_numel: int, accum: Optional[torch.Tensor] = None) -> None:
+        self.opt, self.flat, self.early_numel, self.accum = opt, flat, early_numel, accum
+        self.bucket = accum if accum is not None else flat
+        self._early_sent = False
+
+    def _send(self, i: int, async_op: bool) -> None:
+        s, n = (0, self.early_numel) if i == 0 else (self.early_numel, self.flat.numel() - self.early_numel)
+        if n == 0:
+            return
+        if self.accum is not None:
+            self.accum[s:s + n].add_(self.flat[s:s + n])
+        self.opt.reduce_segment(i, async_op=async_op, bucket=self.bucket)
+
+    def start_early(self) -> None:
+        if self._early_sent:
+            raise RuntimeError("ShardedExchange: start_early twice in one step")
+        self._send(0, True)
+        self._early_sent = True
+
+    def finish(self) -> None:
+        if not self._early_sent:
+            self._send(0, False)
+        self._send(1, False)
+        self._early_sent = False
+
+
 class UNetTrainStep:
 
     def __init__(self, unet, format, optimizer: OptimizerConfig = OptimizerConfig(), lr_schedule: LRScheduleConfig = LRScheduleConfig(),
                  ema: Optional[dict] = None, ema_beta: float = 0.0, input_perturbation: float = 0.0, use_graph: bool = False,
                  gradient_accumulation_steps: int = 1, sigma_sampler=None, conditioning_dropout: float = 0.1,
-                 emas: Optional[list] = None, fused_weight_norm: bool = False, trainer=None, optimizer_impl=None) -> None:
+                 emas: Optional[list] = None, fused_weight_norm: bool = False, trainer=None, optimizer_impl=None,
+                 grad_exchange: Optional[str] = None) -> None:
         """use_graph: capture the whole train batch (forward, loss, backward: ~1900 launches) into one hipGraph on first use and
         replay it afterwards (static input buffers).  The eager loop needs ~20 ms of host time per step and every host hiccup of
         a shared machine lands in the step time; the replay needs the host for the input copies, one graph launch, the
@@ -172,7 +203,30 @@ class UNetTrainStep:
             wn_rows = {k + ".weight": m.weight.shape[0] for k, m in unet.named_modules()
                        if hasattr(m, "disable_weight_norm") and hasattr(m, "weight") and not m.disable_weight_norm}
         self.fused_weight_norm = wn_rows is not None
-        self.opt = optimizer_impl if optimizer_impl is not None else FusedAdamW(self.params, optimizer, ema, ema_beta, emas=emas, wn_rows=wn_rows)
+        # grad_exchange = "sharded" (DDX_GRAD_EXCHANGE=sharded): ZeRO-1 style -- reduce-scatter, parameter pass on this rank's shard of one
+        # flat parameter buffer, all-gather, weight norm (training.sharded); also at world size 1, where it is the same arithmetic
+        self.grad_exchange = grad_exchange or os.environ.get("DDX_GRAD_EXCHANGE", "all_reduce")
+        self.sharded = None
+        if self.grad_exchange == "sharded" and optimizer_impl is None:
+            from .sharded import ShardedAdamW
+            tr = self.trainer
+            if ema is not None:
+                raise ValueError("UNetTrainStep: the sharded pass takes `emas` (EMASpec list), not the single fixed-beta `ema`")
+            total = tr.grad_flat.numel()
+
+            def _normalize():
+                if getattr(tr, "bank", None) is not None:
+                    tr.bank.normalize()
+                else:
+                    self.unet.normalize_weights()
+            self.sharded = ShardedAdamW(list(unet.named_parameters()), tr.grad_flat, tr.grad_views, [(0, tr.early_numel), (tr.early_numel, total - tr.early_numel)],
+                                        optimizer, emas=emas, normalize=_normalize)
+            self.params = {k: p.data for k, p in unet.named_parameters()}     # (now views of the flat parameter buffer)
+            if getattr(tr, "bank", None) is not None:                          # its job table holds the old storage
+                tr.bank, tr._bank_key = None, None
+            self.fused_weight_norm = True                                     # (the normalisation runs inside ShardedAdamW.step)
+        self.opt = optimizer_impl if optimizer_impl is not None else (self.sharded if self.sharded is not None else
+                                                                      FusedAdamW(self.params, optimizer, ema, ema_beta, emas=emas, wn_rows=wn_rows))
         self.emas = list(emas or [])
         self.input_perturbation = input_perturbation
         self.accum_steps = int(gradient_accumulation_steps)
@@ -263,7 +317,10 @@ class UNetTrainStep:
         lr = self.lr_cfg.learning_rate * lr_multiplier(self.lr_cfg, self.global_step)
         total_batch = device_batch * n_micro * world
         betas = [e.effective_beta(self.global_step, self.total_samples_processed, total_batch) for e in self.emas] if self.emas else None
-        grad_norm = self.opt.step(grads, lr, self.opt.cfg.loss_scale / (world * n_micro), ema_betas=betas)
+        if self.sharded is not None:
+            grad_norm = self.sharded.step(lr, self.sharded.cfg.loss_scale / (world * n_micro), ema_betas=betas)
+        else:
+            grad_norm = self.opt.step(grads, lr, self.opt.cfg.loss_scale / (world * n_micro), ema_betas=betas)
         # trainer.py:1105-1108: forced weight normalisation after every optimizer step (inside the fused launch, or one launch over
         # the weight bank)
         if not self.fused_weight_norm:
@@ -281,7 +338,10 @@ class UNetTrainStep:
         exchange = world > 1 or (os.environ.get("DDX_DDP_BUCKETS", "0") == "1" and _dist_ready())
         if n_micro > 1 and (self._accum is None or self._accum.shape != tr.grad_flat.shape):
             self._accum = torch.zeros_like(tr.grad_flat)
-        return GradientExchange(tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None) if exchange else None
+        if self.sharded is not None:
+            return ShardedExchange(self.sharded, tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None)
+        mode = self.grad_exchange if self.grad_exchange in ("all_reduce", "rs_ag") else "all_reduce"
+        return GradientExchange(tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None, mode=mode) if exchange else None
 
     def step(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
              conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:

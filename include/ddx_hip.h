@@ -608,6 +608,9 @@ typedef struct {
 
 int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, float grad_scale, float max_norm,
                         float* workspace3, ddx_stream stream);
+/* workspace3[1], [2] from workspace3[0] alone (a sharded pass sums |g|^2 of the local shard with ddx_multi_grad_norm, all-reduces the
+ * one float over the ranks and then asks for the clip coefficient of the global norm) */
+int ddx_clip_coef(float* workspace3, float grad_scale, float max_norm, ddx_stream stream);
 int ddx_multi_adamw(const ddx_optim_job* jobs_dev, int32_t njobs, int64_t max_n, const float* clip_coef, float grad_scale, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float ema_beta, ddx_stream stream);
 

@@ -219,6 +219,81 @@ def test_train_step_control_flow_world2_gloo(tmp_path):
     assert os.path.isfile(tmp_path / "train_ok0") and os.path.isfile(tmp_path / "train_ok1")
 
 
+def _sharded_worker(rank: int, ws: int, port: int, out_dir: str):
+    """training.sharded.ShardedAdamW over gloo (torch backend of the local pass): three steps on three toy parameters with a plain and a
+    feedback EMA, gradients that differ per rank, against the unsharded arithmetic on the summed gradients."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from dualdiffusion_amd.training.optimizer import EMASpec, OptimizerConfig
+    from dualdiffusion_amd.training.sharded import ShardedAdamW
+    torch.manual_seed(0)
+    shapes = {"dec.w": (8, 4, 3, 3), "enc.lin": (16, 10), "enc.gain": ()}
+    order = ["dec.w", "enc.lin", "enc.gain"]
+    params = {k: torch.nn.Parameter(torch.randn(shapes[k])) for k in order}
+    start = {k: p.detach().clone() for k, p in params.items()}
+    total = sum(p.numel() for p in params.values())
+    flat = torch.zeros(total)
+    views, off = {}, 0
+    for k in order:
+        n = params[k].numel()
+        views[k] = flat[off:off + n].view(shapes[k])
+        off += n
+    early = params["dec.w"].numel()
+    cfg = OptimizerConfig(dynamic_max_grad_norm_z=None)
+    emas = [EMASpec(name="a", tensors={k: p.detach().clone() for k, p in params.items()}, beta=0.99),
+            EMASpec(name="b", tensors={k: p.detach().clone() for k, p in params.items()}, beta=0.95, feedback_beta=0.9)]
+    calls = []
+    opt = ShardedAdamW([(k, params[k]) for k in order], flat, views, [(0, early), (early, total - early)], cfg, emas=emas,
+                       normalize=lambda: calls.append(1), use_hip=False)
+    assert opt.shards[0][1] == 128 and opt.tails[0] == (256, 288) and opt.shards[1][1] == 64      # 288 = 2 x 128 + 32, 161 = 2 x 64 + 33
+    # reference: plain tensors, the same update on the SUM of both ranks' gradients
+    rp = {k: v.clone() for k, v in start.items()}
+    rm = {k: torch.zeros_like(v) for k, v in rp.items()}
+    rv = {k: torch.zeros_like(v) for k, v in rp.items()}
+    re0 = {k: v.clone() for k, v in rp.items()}
+    re1 = {k: v.clone() for k, v in rp.items()}
+    betas = [0.99, 0.95]
+    import math
+    for step in range(1, 4):
+        gsum = {}
+        for k in order:
+            gs_ = [torch.randn(shapes[k], generator=torch.Generator().manual_seed(1000 * step + 10 * r + len(k))) for r in range(ws)]
+            views[k].copy_(gs_[rank])
+            gsum[k] = sum(gs_)
+        opt.reduce_segment(0, async_op=True)
+        opt.reduce_segment(1)
+        lr, gscale = 1e-2, 0.5
+        norm = opt.step(lr, gscale, ema_betas=betas)
+        ref_norm = math.sqrt(sum(float((g.double() ** 2).sum()) for g in gsum.values())) * gscale
+        assert abs(norm - ref_norm) < 1e-4 * ref_norm
+        coef = min(1.0, cfg.max_grad_norm / (ref_norm + 1e-6))
+        b1, b2 = 1 - cfg.adam_beta1 ** step, 1 - cfg.adam_beta2 ** step
+        for k in order:
+            g = gsum[k] * (gscale * coef)
+            rm[k].mul_(cfg.adam_beta1).add_(g, alpha=1 - cfg.adam_beta1)
+            rv[k].mul_(cfg.adam_beta2).addcmul_(g, g, value=1 - cfg.adam_beta2)
+            rp[k].mul_(1 - lr * cfg.adam_weight_decay)
+            rp[k].addcdiv_(rm[k], rv[k].sqrt() / math.sqrt(b2) + cfg.adam_epsilon, value=-lr / b1)
+            re0[k].lerp_(rp[k], 1 - betas[0])
+            re1[k].lerp_(rp[k], 1 - betas[1])
+            rp[k].lerp_(re1[k], 1 - 0.9)
+        for k in order:
+            assert torch.allclose(params[k].data, rp[k], rtol=1e-5, atol=1e-6), (step, k)
+            assert params[k].data.data_ptr() == opt.param_flat[opt.offsets[k][0]:].data_ptr()     # the parameter IS the flat buffer's view
+    assert len(calls) == 3
+    opt.gather_emas()
+    for k in order:
+        assert torch.allclose(emas[0].tensors[k], re0[k], rtol=1e-5, atol=1e-6) and torch.allclose(emas[1].tensors[k], re1[k], rtol=1e-5, atol=1e-6), k
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"sharded_ok_{rank}"), "w").write("ok")
+
+
+def test_sharded_optimizer_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), f"sharded_ok_{r}")) for r in range(2))
+
+
 def test_single_process_fallbacks():
     from dualdiffusion_amd import distributed as D
     assert D.replica_throughput(7, 0.5) == (7.0, 0.5)

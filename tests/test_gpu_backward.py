@@ -329,6 +329,55 @@ def test_fused_adamw_matches_torch():
         assert rel_l2(ema_hip[k], ema_ref[k]) < 2e-6, k
 
 
+def test_sharded_adamw_hip_matches_fused():
+    """training.sharded.ShardedAdamW on the HIP kernels (world of one: the shard is everything but the < 64-element tails) against
+    FusedAdamW on the same gradients: four steps, a classic and a feedback EMA, dynamic clip threshold; the parameters are views of the
+    flat buffer afterwards.  (The N > 1 arithmetic is covered by the world-2 gloo test on the torch backend.)"""
+    from dualdiffusion_amd.training.optimizer import EMASpec, FusedAdamW, OptimizerConfig
+    from dualdiffusion_amd.training.sharded import ShardedAdamW
+    g = torch.Generator().manual_seed(4)
+    shapes = {"dec.a": (300, 17), "dec.c": (64, 8, 3, 3), "enc.w": (96, 40), "enc.b": (5,), "enc.d": ()}
+    order = list(shapes)
+    init = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+    cfg = OptimizerConfig(adam_weight_decay=0.01, loss_scale=250.0, max_grad_norm=1.0, dynamic_max_grad_norm_z=3)
+    # fused reference
+    p_f = {k: v.clone().cuda() for k, v in init.items()}
+    em_f = [EMASpec(name="a", tensors={k: v.clone().cuda() for k, v in init.items()}, beta=0.99),
+            EMASpec(name="b", tensors={k: v.clone().cuda() for k, v in init.items()}, beta=0.9, feedback_beta=0.95)]
+    fused = FusedAdamW(p_f, cfg, emas=em_f)
+    # sharded: parameters + one flat gradient bucket with views, two segments
+    params = {k: torch.nn.Parameter(v.clone().cuda(), requires_grad=False) for k, v in init.items()}
+    total = sum(v.numel() for v in init.values())
+    flat = torch.zeros(total, device="cuda")
+    views, off = {}, 0
+    for k in order:
+        n = init[k].numel()
+        views[k] = flat[off:off + n].view(shapes[k])
+        off += n
+    early = init["dec.a"].numel() + init["dec.c"].numel()
+    em_s = [EMASpec(name="a", tensors={k: v.clone().cuda() for k, v in init.items()}, beta=0.99),
+            EMASpec(name="b", tensors={k: v.clone().cuda() for k, v in init.items()}, beta=0.9, feedback_beta=0.95)]
+    calls = []
+    sh = ShardedAdamW([(k, params[k]) for k in order], flat, views, [(0, early), (early, total - early)], cfg, emas=em_s, normalize=lambda: calls.append(1))
+    assert sh.use_hip and sh.tails[0][1] - sh.tails[0][0] == early % 64
+    for step in range(4):
+        grads = {k: torch.randn(s, generator=g) * (0.002 if step % 2 else 0.02) for k, s in shapes.items()}
+        betas = [0.99, 0.9]
+        n_f = fused.step({k: v.cuda() for k, v in grads.items()}, 3e-3, ema_betas=betas)
+        for k in order:
+            views[k].copy_(grads[k])
+        sh.reduce_segment(0, async_op=True)
+        sh.reduce_segment(1)
+        n_s = sh.step(3e-3, ema_betas=betas)
+        assert abs(n_s - n_f) < 1e-5 * n_f and abs(sh.get_max_grad_norm() - fused.get_max_grad_norm()) < 1e-6
+    assert len(calls) == 4
+    for k in order:
+        assert rel_l2(params[k].data, p_f[k]) < 2e-6, k
+        assert params[k].data.data_ptr() == sh.param_flat[sh.offsets[k][0]:].data_ptr()
+        for j in range(2):
+            assert rel_l2(em_s[j].tensors[k], em_f[j].tensors[k]) < 2e-6, (k, j)
+
+
 def test_unet_train_steps_reduce_loss():
     """Six full optimizer steps (train batch -> all-reduce (single rank) -> clip + AdamW -> forced weight norm) on a fixed batch:
     the loss goes down and every MPConv weight row is unit-RMS again after each step."""
@@ -419,7 +468,7 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
     s.close()
     res = {}
     try:
-        for bucketed in (False, True, "graph", "rs_ag"):
+        for bucketed in (False, True, "graph", "rs_ag", "sharded", "sharded_graph"):
             if bucketed is True:
                 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
                 monkeypatch.setenv("DDX_DDP_BUCKETS", "1")
@@ -428,8 +477,11 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
             unet = UNet(UNetConfig(**over)).requires_grad_(False)
             unet.load_state_dict(sd, strict=True)
             unet = unet.to(device="cuda", dtype=torch.float32).train(True)
+            # "sharded": reduce-scatter, the parameter pass on this rank's shard of the flat parameter buffer, all-gather (training.sharded)
             ts = UNetTrainStep(unet, _Fmt(), OptimizerConfig(), LRScheduleConfig(learning_rate=5e-4, lr_warmup_steps=1, lr_reference_steps=1000),
-                               use_graph=bucketed == "graph")
+                               use_graph=bucketed in ("graph", "sharded_graph"), grad_exchange="sharded" if str(bucketed).startswith("sharded") else None)
+            if str(bucketed).startswith("sharded"):
+                assert ts.sharded is not None and unet.dec["block0_layer0"].conv_res0.weight.data.data_ptr() >= ts.sharded.param_flat.data_ptr()
             ts.global_step = 1
             tr = ts.trainer
             assert 0 < tr.early_numel < tr.grad_flat.numel()
@@ -449,11 +501,11 @@ def test_unet_train_step_bucketed_exchange_world1_rccl(monkeypatch):
             dist.destroy_process_group()
     # "graph": the train batch captured as two hipGraphs cut at the bucket hook, the early collective between the two replays
     assert res["graph_tail"], "graph mode with an exchange must capture the batch in two halves"
-    for variant in (True, "graph", "rs_ag"):
+    for variant in (True, "graph", "rs_ag", "sharded", "sharded_graph"):
         for (l0, n0), (l1, n1) in zip(res[False][0], res[variant][0]):
             assert rel_l2(l1, l0) < 5e-4 and abs(n1 - n0) <= 2e-3 * abs(n0)   # (two runs differ by bf16 rounding flips: float atomics)
         e_dec, e_enc = rel_l2(res[variant][1], res[False][1]), rel_l2(res[variant][2], res[False][2])
-        print(f"bucketed exchange (world 1, rccl, {'two hipGraphs' if variant == 'graph' else ('reduce-scatter + all-gather' if variant == 'rs_ag' else 'eager')}) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
+        print(f"bucketed exchange (world 1, rccl, {variant}) vs plain: weights after 3 steps rel-L2 dec {e_dec:.2e} enc {e_enc:.2e}")
         assert e_dec < 2e-3 and e_enc < 2e-3
 
 
