@@ -7,9 +7,12 @@
 // ~45 GB/s per CU).  Here:
 //   * 128 pixels x 128 channels per workgroup (4 waves, 64 x 64 each: 4 fragment reads per 4 MFMAs), two workgroups per CU,
 //     one unit per workgroup (grid = units: 264 for the level-3 qkv conv, 258 for the level-2 skip over mp_cat);
-//   * 32-channel K stages by LDS-DMA into a ring of FOUR slots, THREE stages in flight per workgroup (counted vmcnt, raw
-//     barrier: a __syncthreads() would drain the queue), one barrier per stage;
-//   * rows are 64 bytes, 16-byte slots XOR-swizzled on the SOURCE address (conv_dma.hip's scheme) -- conflict-free ds_read_b128;
+//   * 64-channel K stages by LDS-DMA into a ring of TWO slots (32-channel stages where the channel counts need them), the next
+//     stage in flight while this one multiplies (counted vmcnt, raw barrier: a __syncthreads() would drain the queue), one
+//     barrier per stage.  Measured on the level-3 qkv conv: (32,2) 18.9, (32,3) 19.8, (32,4) 19.3, (64,2) 18.6, (64,3) 26.7 us,
+//     6 / 8 slots ~30 us -- deeper rings lose (occupancy 2 -> 1 workgroup per CU costs more than the extra stages buy);
+//   * rows are 64 / 128 bytes, 16-byte slots XOR-swizzled on the SOURCE address (conv_dma.hip's scheme) -- conflict-free
+//     ds_read_b128;
 //   * raw operands only (two sources of an mp_cat with the scales folded into the weights, `src0_alt` per channel tile), plain
 //     store (+ clip) epilogue through an LDS transpose (the layers served need nothing else).
 #include <algorithm>
