@@ -411,7 +411,7 @@ extern "C" int ddx_edm2_loss(const float* denoised, const float* target, const f
                              float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream) {
   if (!denoised || !target || !sigma || !loss || !workspace || B <= 0 || n_per_sample <= 0) return set_error(DDX_ERR_ARG, "edm2_loss: bad args");
   return dispatch([=](hipStream_t s) -> int {
-    if (hipMemsetAsync(workspace, 0, sizeof(float) * B, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "edm2_loss: memset");
+    if (int rc = zero_bytes(workspace, sizeof(float) * B, s)) return rc;   // (a kernel, not a memset node: common.hpp)
     dim3 grid((unsigned)std::min<int64_t>((n_per_sample + 255) / 256, 512), (unsigned)B);
     hipLaunchKernelGGL(edm2_loss_grad_kernel, grid, dim3(256), 0, s, denoised, target, sigma, logvar, sigma_data, d_denoised, workspace, B, (size_t)n_per_sample);
     hipLaunchKernelGGL(edm2_loss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)workspace, sigma, logvar, sigma_data, loss, d_logvar, B,

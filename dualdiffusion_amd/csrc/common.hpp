@@ -22,6 +22,10 @@ using LaunchFn = std::function<int(hipStream_t)>;
 int dispatch(LaunchFn&& fn, ddx_stream stream, const char* tag = "op", double flops = 0.0, double bytes = 0.0);
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
+// Zero `bytes` bytes (a multiple of 2) at a 4-byte aligned address with a KERNEL.  Not hipMemsetAsync: a memset node of a captured hipGraph
+// was seen to leave the low word of every 8 bytes untouched on replay (32-byte workspace of the loss, round 4) -- stale sums of squares, garbage
+// loss and logvar gradient from the second replay on, depending on which tensor had owned the block before.
+int zero_bytes(void* p, size_t bytes, hipStream_t s);
 
 // ---- scalar helpers
 // mp_silu(x) = x * sigmoid(x) / 0.596 with v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence:

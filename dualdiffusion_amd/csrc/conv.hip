@@ -72,7 +72,7 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
       const int taps = d.ksize * d.ksize, Ng = d.Cout / d.groups, Cin = d.Cg * d.groups, fan = d.Cg * taps;
       const size_t bytes = ddx_wprep_bytes(Cin, Ng, d.ksize, d.groups, d.CK, d.wp_dtype);
       if (round_up(d.Cg, 32) != d.Cg || Ng % d.CK) {
-        if (hipMemsetAsync(d.wp, 0, bytes, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "wprep: memset");
+        if (int rc = zero_bytes(d.wp, bytes, s)) return rc;
       }
 #define DDX_WPREP_T(TWT, TPT)                                                                                              \
   do {                                                                                                                     \
@@ -96,7 +96,7 @@ extern "C" int ddx_mpconv_wprep(const ddx_wprep_desc* dp, ddx_stream stream) {
     const int Ng = d.Cout / d.groups;
     const size_t bytes = ddx_wprep_bytes(d.Cout, d.Cg, d.ksize, d.groups, d.CK, d.wp_dtype);
     if (d.rows_total == 0 && (round_up(Ng, 32) != Ng || d.Cg % d.CK)) {  // (merged matrices are zero-filled by their owner)
-      if (hipMemsetAsync(d.wp, 0, bytes, s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "wprep: memset");
+      if (int rc = zero_bytes(d.wp, bytes, s)) return rc;
     }
 #define DDX_WPREP(TWT, TPT)                                                                                         \
   hipLaunchKernelGGL((wprep_kernel<TWT, TPT>), dim3(d.Cout), dim3(256), 0, s, (const TWT*)d.w, (TPT*)d.wp, d.gain_ptr, \
@@ -287,6 +287,9 @@ static int dgrad_act_fill(const ddx_dgrad_act_desc& d, ConvParams* pp) {
   return 0;
 }
 
+// DDX_EPI_SILU_BWD on the register-staged kernel: 4-channel items must lie in one part
+static bool dgrad_act_on_mfma(const ConvParams& p) { return p.bwd_split % 4 == 0 && p.Ng % 4 == 0 && p.CK != 16; }
+
 extern "C" size_t ddx_mpconv2d_dgrad_act_workspace_bytes(const ddx_dgrad_act_desc* dp) {
   if (!dp) return 0;
   ConvParams p{};
@@ -299,7 +302,9 @@ extern "C" size_t ddx_mpconv2d_dgrad_act_workspace_bytes(const ddx_dgrad_act_des
   if (d.split > 0 && !d.y1) d.y1 = &dummy;
   if (d.split > 0 && !d.out1) d.out1 = &dummy;
   if (dgrad_act_fill(d, &p) != 0) return 0;
-  if (d.conv.dtype != DDX_BF16 || !conv_mfma_supported(p, d.conv.ksize, d.conv.dtype) || !conv_dma_supported(p, d.conv.ksize, d.conv.dtype, false)) return 0;
+  if (d.conv.dtype != DDX_BF16 || !conv_mfma_supported(p, d.conv.ksize, d.conv.dtype)) return 0;
+  if (!conv_dma_supported(p, d.conv.ksize, d.conv.dtype, false))
+    return dgrad_act_on_mfma(p) ? 16 : 0;   // register-staged kernel: no workspace (per-wave atomics into dchan_scale), a token size says "fused"
   return conv_dma_bwd_ws_bytes(p, d.conv.ksize);
 }
 
@@ -309,10 +314,15 @@ extern "C" int ddx_mpconv2d_dgrad_act(const ddx_dgrad_act_desc* dp, ddx_stream s
   ConvParams p{};
   if (int rc = dgrad_act_fill(d, &p)) return rc;
   const int ks = d.conv.ksize;
+  const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
+  const double bytes = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.add ? 3.0 : 2.0) + (double)p.Cout * p.Cg * ks * ks);
+  if (d.conv.dtype == DDX_BF16 && conv_mfma_supported(p, ks, d.conv.dtype) && !conv_dma_supported(p, ks, d.conv.dtype, false) && dgrad_act_on_mfma(p)) {
+    // the small layers (levels 3 / 4) that the forward dispatch gives to the register-staged kernel: same kernel, activation backward in its epilogue
+    const int dt = d.conv.dtype;
+    return dispatch([p, ks, dt](hipStream_t s) -> int { return launch_conv_mfma(p, ks, dt, s); }, stream, ks == 3 ? "conv3x3_mfma_bwd" : "conv1x1_mfma_bwd", flops, bytes);
+  }
   if (d.conv.dtype != DDX_BF16 || !conv_dma_supported(p, ks, d.conv.dtype, /*any_size=*/true))
     return set_error(DDX_ERR_UNSUPPORTED, "dgrad_act: layer does not qualify for the LDS-DMA kernel (run the conv and ddx_silu_scale_bwd)");
   if (d.dchan_scale && !d.workspace) return set_error(DDX_ERR_ARG, "dgrad_act: workspace missing");
-  const double flops = 2.0 * p.B * p.H * p.W * (double)p.Cout * p.Cg * ks * ks;
-  const double bytes = 2.0 * ((double)p.B * p.sH * p.sW * p.Cin + (double)p.B * p.H * p.W * p.Cout * (d.add ? 3.0 : 2.0) + (double)p.Cout * p.Cg * ks * ks);
   return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_dma(p, ks, s); }, stream, ks == 3 ? "conv3x3_dma_bwd" : "conv1x1_dma_bwd", flops, bytes);
 }

@@ -396,6 +396,76 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
       rres[it] = *reinterpret_cast<const V4*>(res + (ok ? roff : 0));
     }
   }
+  if (p.epilogue == DDX_EPI_SILU_BWD) {
+    // data gradient through the producer-side activation a = mp_silu(y * c * s) (ddx_mpconv2d_dgrad_act, the LDS-DMA kernel's EB
+    // epilogue on this kernel's item map): dz = g * silu'(y c s), out = dz * c * s (+ add), dc[b][ch] += s * sum_pixels dz * y.
+    // The output channels may belong to two tensors (the two mp_cat sources): a 4-channel item lies in one of them (split % 4 == 0).
+    // NT % G4 == 0: every item of a thread has the same 4 channels, so the dc partial sums live in four registers.
+    const int ch = g * p.Ng + n0 + (tid_all % G4) * 4;
+    const bool second = p.bwd_split > 0 && ch >= p.bwd_split;
+    const int ld_u = p.bwd_split > 0 ? (second ? p.Cout - p.bwd_split : p.bwd_split) : p.Cout;
+    const int cu = second ? ch - p.bwd_split : ch;
+    const T* y_u = second ? reinterpret_cast<const T*>(p.bwd_y1) : res;
+    T* out_u = second ? reinterpret_cast<T*>(p.bwd_out1) : out;
+    const T* addp = reinterpret_cast<const T*>(p.bwd_add);
+    const float sc_u = second ? p.bwd_s1 : p.bwd_s0;
+    const bool ch_ok = n0 + (tid_all % G4) * 4 < p.Ng;
+    float s4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s4[e] = sc_u;
+    if (p.out_cs && ch_ok) {
+      const f32x4 c4v = *reinterpret_cast<const f32x4*>(p.out_cs + (size_t)b * p.Cout + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s4[e] *= c4v[e];
+    }
+    long uoff[EI];
+    V4 ry[EI], ra[EI];
+#pragma unroll
+    for (int it = 0; it < EI; ++it) {
+      const long pix = eoff[it] < 0 ? 0 : (eoff[it] - ch) / p.Cout;      // NHWC pixel index of the item (eoff = pix * Cout + ch)
+      uoff[it] = eoff[it] < 0 ? -1 : pix * ld_u + cu;
+      ry[it] = *reinterpret_cast<const V4*>(y_u + (uoff[it] < 0 ? 0 : uoff[it]));
+      if (addp) ra[it] = *reinterpret_cast<const V4*>(addp + (eoff[it] < 0 ? 0 : eoff[it]));
+    }
+    float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < EI; ++it) {
+      const int idx = min(tid_all + it * NT, BM * G4 - 1);
+      const int ml = idx / G4, c4 = idx % G4;
+      const f32x4 y4 = *reinterpret_cast<const f32x4*>(sE + (size_t)ml * ES + c4 * 4);
+      if (uoff[it] < 0) continue;
+      Vec4<T> yv, av, ov;
+      yv.v = ry[it];
+      if (addp) av.v = ra[it];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yy = yv.get(e);
+        float dz = y4[e];
+        if (p.bwd_act) {
+          const float z = yy * s4[e];
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+          dz *= sg * (1.0f + z * (1.0f - sg)) * kMpSiluInv;
+        }
+        dcs[e] += dz * yy;
+        ov.set(e, dz * s4[e] + (addp ? av.get(e) : 0.f));
+      }
+      *reinterpret_cast<V4*>(out_u + uoff[it]) = ov.v;
+    }
+    if (p.bwd_dc) {   // lanes l, l + G4, ... of a wave hold the same channels: one atomic per (wave, channel)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sacc = dcs[e];
+#pragma unroll
+        for (int m = G4; m < 64; m <<= 1) sacc += __shfl_xor(sacc, m, 64);
+        dcs[e] = sacc;
+      }
+      if ((tid_all & 63) < G4 && ch_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(p.bwd_dc + (size_t)b * p.Cout + ch + e, dcs[e] * p.bwd_s0);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < EI; ++it) {
     const int idx = min(tid_all + it * NT, BM * G4 - 1);

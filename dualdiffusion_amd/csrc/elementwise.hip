@@ -1,6 +1,7 @@
 // HBM-bound glue kernels of the UNet forward: pixel-norm, input/output preconditioning, layout conversion, the
 // noise-embedding front end and the small-M linear layers.  All are bandwidth- or latency-bound: coalesced 16-byte
 // accesses, wave shuffles for the reductions, no LDS staging needed.
+#include <algorithm>
 #include "common.hpp"
 
 namespace ddx {
@@ -353,6 +354,24 @@ __global__ __launch_bounds__(256) void lincomb3_kernel(const float* __restrict__
 }
 
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
+
+// ---- zero_bytes (see common.hpp)
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, size_t n16, size_t nwords, int tail2) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) reinterpret_cast<u32x4*>(p)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (size_t i = n16 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = 0u;
+  if (tail2 && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<uint16_t*>(p + nwords)[0] = 0;
+}
+int zero_bytes(void* p, size_t bytes, hipStream_t s) {
+  if (!p || bytes == 0) return DDX_OK;
+  if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 1)) return set_error(DDX_ERR_ARG, "zero_bytes: alignment");
+  const size_t nwords = bytes / 4;
+  const size_t n16 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : nwords / 4;
+  const int blocks = (int)std::min<size_t>((std::max<size_t>(n16, nwords - n16 * 4) + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), n16, nwords, (int)((bytes & 2) != 0));
+  return check_launch("zero_bytes");
+}
 
 }  // namespace ddx
 

@@ -212,7 +212,7 @@ extern "C" int ddx_multi_grad_norm(const ddx_optim_job* jobs_dev, int32_t njobs,
                                    float* workspace3, ddx_stream stream) {
   if (!jobs_dev || njobs <= 0 || max_n <= 0 || !workspace3) return set_error(DDX_ERR_ARG, "multi_grad_norm: bad args");
   return dispatch([=](hipStream_t s) -> int {
-    if (hipMemsetAsync(workspace3, 0, sizeof(float), s) != hipSuccess) return set_error(DDX_ERR_LAUNCH, "multi_grad_norm: memset");
+    if (int rc = zero_bytes(workspace3, sizeof(float), s)) return rc;
     // (every workgroup ends in ONE atomicAdd on the same float: few, long-running workgroups -- 64 per tensor, four 16-byte loads in
     // flight per thread -- instead of 256 per tensor whose atomics serialise behind each other)
     dim3 grid((unsigned)std::min<int64_t>((max_n + kChunk - 1) / kChunk, 64), (unsigned)njobs);

@@ -186,8 +186,11 @@ int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t n
  *     dz = dA * mp_silu'(y * s) | dA;     out = dz * s (+ add);     dchan_scale[b][c] += scale * sum_pixels dz * y.
  * The output channels may be split after `split` channels over two tensors with their own y and scalar scale (the two
  * sources of an mp_cat: conv.out / y0 / scale0 hold channels [0, split), out1 / y1 / scale1 the rest; split % 64 == 0).
- * LDS-DMA kernel only: ddx_mpconv2d_dgrad_act_workspace_bytes() returns 0 when the layer does not qualify -- run
- * ddx_mpconv2d_fwd + ddx_silu_scale_bwd_ex then.  conv.epilogue / residual / out2 / out_act / out_scale are ignored.
+ * Served by the kernel the forward dispatch would pick for the conv: the LDS-DMA kernel (per-unit channel sums in the workspace + a
+ * reduction launch) or, for the small layers it leaves to the register-staged kernel (levels 3 / 4 of the default UNet; split % 4 == 0),
+ * that kernel with the same epilogue (per-wave atomics into dchan_scale; no workspace is used, the size query returns a 16-byte token).
+ * ddx_mpconv2d_dgrad_act_workspace_bytes() returns 0 when the layer does not qualify for either -- run ddx_mpconv2d_fwd +
+ * ddx_silu_scale_bwd_ex then.  conv.epilogue / residual / out2 / out_act / out_scale are ignored.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   ddx_conv_desc conv;

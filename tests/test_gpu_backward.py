@@ -541,3 +541,29 @@ def test_run_batch_graph_with_accumulation_reports_every_micro_step_loss():
     assert not torch.allclose(l_e[:Bd], l_e[Bd:]), "the two micro-steps must have different losses for this test to mean anything"
     assert rel_l2(l_g, l_e) < 5e-4, (l_g, l_e)
     assert abs(res[True][1] - res[False][1]) <= 2e-3 * abs(res[False][1])
+
+
+def test_edm2_loss_in_a_replayed_graph_zeroes_its_workspace():
+    """The loss op clears its per-sample sum-of-squares workspace with a KERNEL (csrc/common.hpp: zero_bytes).  With a captured
+    hipMemsetAsync node the second replay of a train-batch graph read stale words from whichever tensor had reused the 32-byte
+    block (round 4: garbage loss / logvar gradient on replays >= 1, depending on the allocator's layout).  Here the block the
+    workspace is freed into is handed to a tensor the graph fills with 3e30 right after the loss: every replay must still give
+    the eager result."""
+    from dualdiffusion_amd import ops
+    torch.manual_seed(4)
+    B = 8
+    den, tgt = torch.randn(B, 4, 32, 64, device="cuda"), torch.randn(B, 4, 32, 64, device="cuda")
+    sigma, logvar = torch.rand(B, device="cuda") + 0.3, torch.randn(B, device="cuda") * 0.1
+    loss_e, dd_e, dlv_e = ops.edm2_loss(den, tgt, sigma, logvar, 0.5)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss_g, dd_g, dlv_g = ops.edm2_loss(den, tgt, sigma, logvar, 0.5)
+        junk = [torch.empty(B, device="cuda") for _ in range(4)]     # the allocator hands the freed workspace block to one of these
+        for j in junk:
+            j.fill_(3e30)
+    for rep in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(loss_g, loss_e, rtol=1e-5, atol=1e-6), f"replay {rep}: {loss_g.tolist()} vs {loss_e.tolist()}"
+        assert torch.allclose(dlv_g, dlv_e, rtol=1e-5, atol=1e-6) and torch.equal(dd_g, dd_e)

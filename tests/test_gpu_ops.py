@@ -640,7 +640,8 @@ def test_cat2_act(dtype):
     assert rel_l2(act.float(), ref_act) < (5e-3 if dtype == torch.bfloat16 else 1e-6)
 
 
-@pytest.mark.parametrize("case", ["chan_scale", "two_parts_add", "two_parts_ng96", "scale_only"])
+@pytest.mark.parametrize("case", ["chan_scale", "two_parts_add", "two_parts_ng96", "scale_only",
+                                  "small_chan_scale", "small_two_parts_add", "small_scale_only", "small_1x1_chan_scale_add"])
 def test_conv_dgrad_act_fused_matches_unfused(case):
     """ddx_mpconv2d_dgrad_act (activation backward in the data-gradient conv's epilogue, LDS-DMA kernel) against the conv
     followed by ddx_silu_scale_bwd.  The fused form differentiates the fp32 accumulator instead of the bf16-rounded conv
@@ -649,9 +650,17 @@ def test_conv_dgrad_act_fused_matches_unfused(case):
     dt, dev = torch.bfloat16, "cuda"
     torch.manual_seed(3)
     B, H, W, Cin_f, Cout_f, G = 2, 32, 256, 512, 256, 8
+    ks = 3
     if case == "two_parts_ng96":     # 96 channels per group: the part boundary (512) only falls on a 32-channel tile start
         Cin_f, Cout_f = 768, 512
-    w = torch.randn(Cout_f, Cin_f // G, 3, 3, device=dev)
+    if case.startswith("small"):     # levels 3 / 4 of the UNet: the forward dispatch gives these to the register-staged kernel, and so does the
+        H, W = 4, 86                 # fused launch (same epilogue on that kernel's item map, per-wave atomics into dchan_scale)
+        case = case[len("small_"):]
+        if case.startswith("1x1"):
+            ks, G, Cin_f, Cout_f, case = 1, 1, 1024, 2048, "scale_only_act"
+        else:
+            Cin_f, Cout_f = 2048, 1024
+    w = torch.randn(Cout_f, Cin_f // G, ks, ks, device=dev)
     pw_t = ops.wprep(w, G, dt, normalize=True, transpose=True)
     dy = (torch.randn(B, H, W, Cout_f, device=dev) * 0.5).to(dt)
     kw, y1 = {}, None
@@ -659,13 +668,13 @@ def test_conv_dgrad_act_fused_matches_unfused(case):
         y0 = torch.randn(B, H, W, Cin_f, device=dev).to(dt)
         kw = dict(chan_scale=torch.rand(B, Cin_f, device=dev) + 0.5)
     elif case.startswith("two_parts"):
-        c0 = 320 if case == "two_parts_add" else 512
+        c0 = (320 if case == "two_parts_add" else 512) * (Cin_f // 512 if H == 4 else 1)
         y0 = torch.randn(B, H, W, c0, device=dev).to(dt)
         y1 = torch.randn(B, H, W, Cin_f - c0, device=dev).to(dt)
         kw = dict(scale0=0.8, scale1=1.3, add=torch.randn(B, H, W, Cin_f, device=dev).to(dt))
     else:
         y0 = torch.randn(B, H, W, Cin_f, device=dev).to(dt)
-        kw = dict(chan_scale=torch.rand(B, Cin_f, device=dev) + 0.5, add=torch.randn(B, H, W, Cin_f, device=dev).to(dt), act=False)
+        kw = dict(chan_scale=torch.rand(B, Cin_f, device=dev) + 0.5, add=torch.randn(B, H, W, Cin_f, device=dev).to(dt), act=case.endswith("_act"))
     res = {}
     n_fused = ops._dgrad_act_fused_calls
     for fused in (True, False):
