@@ -70,6 +70,14 @@ class DgradActDesc(C.Structure):
                 ("split", C.c_int32), ("act", C.c_int32), ("scale0", C.c_float), ("scale1", C.c_float)]
 
 
+class ConvPairDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("wp0", C.c_void_p), ("wp1", C.c_void_p), ("chan_scale", C.c_void_p), ("residual", C.c_void_p),
+                ("out", C.c_void_p), ("out2", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("groups", C.c_int32),
+                ("CK0", C.c_int32), ("CK1", C.c_int32), ("dtype", C.c_int32),
+                ("res_t", C.c_float), ("clip", C.c_float), ("out2_scale", C.c_float)]
+
+
 class MelStftDesc(C.Structure):
     _fields_ = [("audio", C.c_void_p), ("window", C.c_void_p), ("twiddle", C.c_void_p), ("band_start", C.c_void_p),
                 ("band_len", C.c_void_p), ("band_w", C.c_void_p), ("out", C.c_void_p),
@@ -143,7 +151,7 @@ _lib: Optional[C.CDLL] = None
 # name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
 # ctypes mirrors in the order of ddx_abi_sizeof() (include/ddx_hip.h); tests/test_abi.py compares sizes and tail offsets with the library
 ABI_MIRRORS = [WPrepDesc, ConvDesc, DgradActDesc, WgradDesc, LinearBwdJob, WPathJob, LinearJob, MelStftDesc, MsMelDesc, BgemmDesc, MssDesc,
-               OptimJob, OptimJobEx]
+               OptimJob, OptimJobEx, ConvPairDesc]
 
 PROTOTYPES = {
     "ddx_version": (C.c_char_p, []),
@@ -225,6 +233,8 @@ PROTOTYPES = {
     "ddx_linear_small_bwd_batched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_mpconv2d_dgrad_act_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "ddx_mpconv2d_dgrad_act": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ddx_mpconv_pair_supported": (C.c_int, [C.c_int32] * 5),
+    "ddx_mpconv_pair_fwd": (C.c_int, [C.POINTER(ConvPairDesc), C.c_void_p]),
     "ddx_attn_act_fwd_ld": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_attn_fold_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

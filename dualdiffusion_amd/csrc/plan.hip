@@ -80,6 +80,7 @@ extern "C" int64_t ddx_abi_sizeof(int32_t which) {
     case 10: return sizeof(ddx_mss_desc);
     case 11: return sizeof(ddx_optim_job);
     case 12: return sizeof(ddx_optim_job_ex);
+    case 13: return sizeof(ddx_conv_pair_desc);
     default: return -1;
   }
 }
@@ -98,6 +99,7 @@ extern "C" int64_t ddx_abi_offsetof_tail(int32_t which) {
     case 10: return offsetof(ddx_mss_desc, loss_scale);
     case 11: return offsetof(ddx_optim_job, n);
     case 12: return offsetof(ddx_optim_job_ex, reserved);
+    case 13: return offsetof(ddx_conv_pair_desc, out2_scale);
     default: return -1;
   }
 }

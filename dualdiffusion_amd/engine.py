@@ -57,6 +57,8 @@ FUSE_PIXELNORM = True
 # attention blocks outside the small-M regime: x * c_qk as a materialised twin (written by conv_res1 where it runs on the register-staged
 # kernel) + the merged qkv conv on the 1x1 GEMM kernel / the wide 1x1 units of the LDS-DMA kernel (0 = never)
 QKV_TWIN_MIN_PIXELS = 1024
+# level-0 encoder blocks: conv_res0 -> conv_res1 as one launch with the hidden tensor in LDS (csrc/conv_pair.hip); DDX_CONV_PAIR=0 for the A/B
+CONV_PAIR = os.environ.get("DDX_CONV_PAIR", "1") != "0"
 PIXELNORM_EPS = 1e-4     # eps of normalize() (mp_tools.py:42-49), the default of ops.pixelnorm
 
 
@@ -199,9 +201,16 @@ class PlanBuilder:
                 S(lambda: ops.pixelnorm(src0, out=x1, out_act=x1a))
             kw0 = dict(out_act=True, out_scale=c_emb, out=y0)
             kw1 = dict(residual=x1, res_t=res_balance, clip=last_clip, out=xo, **tw_res1)
-            self._block_layouts(None, None, x1a, pw_res0, kw0, y0, pw_res1, kw1, twin if not attn else None)
-            S(lambda: ops.conv2d(x1a, pw_res0, **kw0))
-            S(lambda: ops.conv2d(y0, pw_res1, **kw1))
+            if self._pair_ok(blk, cout, mm, pw_res0, pw_res1, attn):
+                # level 0 (32 -> 64 -> 32 channels per group): conv_res0 -> mp_silu(y * c) -> conv_res1 -> mp_sum as ONE launch, the hidden
+                # tensor stays in LDS (csrc/conv_pair.hip; 115 -> 88 us per block at B = 4, 950 -> 700 us at B = 32)
+                self.keep = [t for t in self.keep if t is not y0]      # (the hidden tensor is never materialised)
+                S(lambda: ops.conv_pair(x1a, pw_res0, pw_res1, c_emb, x1, res_balance, clip=last_clip, out=xo,
+                                        out2=tw_res1.get("out2"), out2_scale=tw_res1.get("out2_scale", 1.0)))
+            else:
+                self._block_layouts(None, None, x1a, pw_res0, kw0, y0, pw_res1, kw1, twin if not attn else None)
+                S(lambda: ops.conv2d(x1a, pw_res0, **kw0))
+                S(lambda: ops.conv2d(y0, pw_res1, **kw1))
         else:
             kw0 = None
             if act0 is not None and (src1 is None or act1 is not None):
@@ -267,6 +276,12 @@ class PlanBuilder:
         S(lambda: ops.attention(qk, vv, heads, out=ao, out_scale=c_v))
         S(lambda: ops.conv2d(ao, pw_proj, residual=xo, res_t=attn_balance, clip=clip, out=xa, **tw_proj))
         return xa, twin
+
+    def _pair_ok(self, blk, cout, mm, pw_res0, pw_res1, attn) -> bool:
+        """Fused conv_res0 -> conv_res1 launch for this encoder block (bf16 inference, 32 -> 64 -> 32 channels per group, no attention)?"""
+        if not CONV_PAIR or self.training or self.dt != torch.bfloat16 or attn or pw_res0.CK != 32 or pw_res1.CK != 32:
+            return False
+        return ops.conv_pair_supported(self.B, cout, blk.conv_res0.groups, cout * mm, self.dt)
 
     def _qkv_twin_ok(self, xo, pw_qkv, cout, qkv, npix) -> bool:
         """Merged attn_qk | attn_v conv on raw operands with a materialised x * c_qk twin (src0_alt)?  From QKV_TWIN_MIN_PIXELS pixels

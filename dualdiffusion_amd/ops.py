@@ -226,6 +226,28 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     return out
 
 
+def conv_pair_supported(B: int, C: int, groups: int, hidden: int, dtype: torch.dtype) -> bool:
+    """Does the fused conv_res0 -> conv_res1 launch (ddx_mpconv_pair_fwd, csrc/conv_pair.hip) serve this block shape?"""
+    return bool(lib().ddx_mpconv_pair_supported(B, C, groups, hidden, dtype_code(dtype)))
+
+
+def conv_pair(src: torch.Tensor, pw0: PreparedWeight, pw1: PreparedWeight, chan_scale: torch.Tensor, residual: torch.Tensor, res_t: float, *,
+              clip: float = 0.0, out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0) -> torch.Tensor:
+    """out = clip(mp_sum(residual, conv_res1(mp_silu(conv_res0(src) * chan_scale)), res_t)) (+ out2 = mp_silu(out2_scale * out)) in ONE launch:
+    the hidden tensor stays in LDS (include/ddx_hip.h: ddx_conv_pair_desc; reference unet_edm2_b4.py:121-135).  `src` is the activated input."""
+    B, H, W, Cn = src.shape
+    assert pw0.ksize == 3 and pw1.ksize == 3 and pw0.groups == pw1.groups and pw1.Cout == Cn and pw0.Cout == pw1.Cg * pw1.groups
+    if residual.shape != src.shape or chan_scale.shape != (B, pw0.Cout):
+        raise L.DDXError("conv_pair: residual / chan_scale shape")
+    if out is None:
+        out = torch.empty_like(src)
+    d = L.ConvPairDesc(src=ptr(src), wp0=ptr(pw0.wp), wp1=ptr(pw1.wp), chan_scale=ptr(chan_scale), residual=ptr(residual), out=ptr(out), out2=ptr(out2),
+                       B=B, H=H, W=W, C=Cn, hidden=pw0.Cout, groups=pw0.groups, CK0=pw0.CK, CK1=pw1.CK, dtype=dtype_code(src.dtype),
+                       res_t=float(res_t), clip=float(clip), out2_scale=float(out2_scale))
+    check(lib().ddx_mpconv_pair_fwd(C.byref(d), current_stream()), "mpconv_pair_fwd")
+    return out
+
+
 def conv2d_dgrad_act(dy: torch.Tensor, pw_t: PreparedWeight, y0: torch.Tensor, *, y1: Optional[torch.Tensor] = None, scale0: float = 1.0,
                      scale1: float = 1.0, chan_scale: Optional[torch.Tensor] = None, dchan_scale: Optional[torch.Tensor] = None,
                      add: Optional[torch.Tensor] = None, act: bool = True):

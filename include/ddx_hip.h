@@ -179,6 +179,31 @@ int ddx_mpconv2d_path(const ddx_conv_desc* d);
 int32_t ddx_mpconv2d_pick_ck(int32_t Cg, int32_t ksize, int32_t dtype, int64_t npix);
 
 /* ------------------------------------------------------------------------------------------------
+ * One EDM2 block body as ONE launch (inference, bf16): reference src/modules/unets/unet_edm2_b4.py:121-135
+ *     y = conv_res0(src);  y = mp_silu(y * chan_scale[b][:]);  y = conv_res1(y);  out = clip(mp_sum(residual, y, res_t));
+ *     out2 = mp_silu(out2_scale * out)   (optional)
+ * with `src` the already activated block input (the producer-side twin mp_silu(x)), both convs 3x3, zero padded, grouped alike.  The hidden
+ * tensor (conv_res0's output, `hidden` channels) never reaches HBM: csrc/conv_pair.hip.  Served for 32 -> 64 -> 32 channels per group
+ * (C = 32 * groups, hidden = 64 * groups: the level-0 encoder blocks of the default UNet), NHWC bf16 tensors, weights prepared by
+ * ddx_mpconv_wprep with CK = 32; ddx_mpconv_pair_supported() says whether a shape qualifies -- otherwise run the two ddx_mpconv2d_fwd launches,
+ * which compute the same thing (equal up to the fp32 summation order inside a conv).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* src;           /* NHWC [B][H][W][C] bf16: activated input of conv_res0 */
+  const void* wp0;           /* prepared conv_res0 weights [hidden][C/groups][3][3], CK0 = 32 */
+  const void* wp1;           /* prepared conv_res1 weights [C][hidden/groups][3][3], CK1 = 32 */
+  const float* chan_scale;   /* [B][hidden] fp32: c = emb_linear(emb) * gain + 1 */
+  const void* residual;      /* NHWC [B][H][W][C] bf16 */
+  void* out;                 /* NHWC [B][H][W][C] bf16 */
+  void* out2;                /* NHWC [B][H][W][C] bf16 or NULL */
+  int32_t B, H, W, C, hidden, groups, CK0, CK1, dtype;
+  float res_t, clip, out2_scale;
+} ddx_conv_pair_desc;
+
+int ddx_mpconv_pair_supported(int32_t B, int32_t C, int32_t groups, int32_t hidden, int32_t dtype);
+int ddx_mpconv_pair_fwd(const ddx_conv_pair_desc* d, ddx_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Data-gradient conv fused with the backward of the producer-side activation it feeds (training).
  * The forward stored a = mp_silu(y * s) (act = 1) or a = y * s (act = 0), s[b][c] = chan_scale[b][c] * scale, as the operand
  * of the conv described by `conv` (unet_edm2_b4.py:119-122, :139).  With dA = conv (src0 = dY, wp = the transposed
@@ -668,7 +693,7 @@ void ddx_plan_destroy(ddx_plan* p);
 /* sizeof() of the descriptor structs of this header as the library was compiled, so that a binding can check its mirrors against
  * the binary instead of against hand-counted bytes (tests/test_abi.py does): which = 0 ddx_wprep_desc, 1 ddx_conv_desc,
  * 2 ddx_dgrad_act_desc, 3 ddx_wgrad_desc, 4 ddx_linear_bwd_job, 5 ddx_wpath_job, 6 ddx_linear_job, 7 ddx_melstft_desc, 8 ddx_msmel_desc,
- * 9 ddx_bgemm_desc, 10 ddx_mss_desc, 11 ddx_optim_job, 12 ddx_optim_job_ex; -1 for any other code.  ddx_abi_offsetof_tail(which) is the
+ * 9 ddx_bgemm_desc, 10 ddx_mss_desc, 11 ddx_optim_job, 12 ddx_optim_job_ex, 13 ddx_conv_pair_desc; -1 for any other code.  ddx_abi_offsetof_tail(which) is the
  * offset of the LAST field of the same struct (catches a mirror that is one trailing field short inside the tail padding). */
 int64_t ddx_abi_sizeof(int32_t which);
 int64_t ddx_abi_offsetof_tail(int32_t which);

@@ -1117,3 +1117,41 @@ def test_conv_residual_up(path, dtype, shape):
     assert torch.equal(out, out_full)
     with pytest.raises(Exception):
         ops.conv2d(to_nhwc(x, dtype), pw, residual_up=True, path=path)     # no residual: argument error
+
+
+@pytest.mark.parametrize("case", ["b2_twin", "b1_ragged", "b4_clip"])
+def test_conv_pair_matches_the_two_convs(case):
+    """ddx_mpconv_pair_fwd (csrc/conv_pair.hip: conv_res0 -> mp_silu(y * c) -> conv_res1 -> mp_sum / clip / twin with the hidden tensor in LDS)
+    against the same block as two ddx_mpconv2d_fwd launches (unet_edm2_b4.py:121-135).  Same bf16 operands, same bf16 rounding of the hidden
+    activations; the fp32 summation order inside a conv differs (all taps of a 16-channel k-step vs chunk-major): outputs agree to a bf16
+    rounding flip here and there (rel-L2 <= 3e-3, max |diff| <= 2 bf16 ulps of the largest value)."""
+    ops = _ops()
+    dt, dev = torch.bfloat16, "cuda"
+    torch.manual_seed(11)
+    B, H, W = {"b2_twin": (2, 16, 96), "b1_ragged": (1, 13, 75), "b4_clip": (4, 32, 64)}[case]
+    G, Cn = 8, 256
+    x = torch.randn(B, H, W, Cn, device=dev).to(dt)
+    xa = (torch.nn.functional.silu(x.float()) / 0.596).to(dt)
+    w0 = torch.randn(2 * Cn, Cn // G, 3, 3, device=dev)
+    w1 = torch.randn(Cn, 2 * Cn // G, 3, 3, device=dev)
+    pw0, pw1 = ops.wprep(w0, G, dt, normalize=True), ops.wprep(w1, G, dt, normalize=True)
+    c = torch.rand(B, 2 * Cn, device=dev) + 0.5
+    clip = 1.5 if case == "b4_clip" else 256.0
+    twin = case == "b2_twin"
+    assert ops.conv_pair_supported(B, Cn, G, 2 * Cn, dt)
+    # two launches
+    y0 = ops.conv2d(xa, pw0, out_act=True, out_scale=c)
+    ref2 = torch.empty_like(x) if twin else None
+    ref = ops.conv2d(y0, pw1, residual=x, res_t=0.3, clip=clip, **(dict(out2=ref2, out2_scale=0.8) if twin else {}))
+    # one launch
+    out2 = torch.empty_like(x) if twin else None
+    out = ops.conv_pair(xa, pw0, pw1, c, x, 0.3, clip=clip, out2=out2, out2_scale=0.8)
+    torch.cuda.synchronize()
+    e = rel_l2(out.float(), ref.float())
+    md = (out.float() - ref.float()).abs().max().item()
+    print(f"conv_pair {case}: rel-L2 {e:.2e}, max |diff| {md:.3e} (max |ref| {ref.float().abs().max().item():.2f})")
+    assert e <= 3e-3 and md <= 2 * 2 ** -8 * ref.float().abs().max().item()
+    if twin:
+        assert rel_l2(out2.float(), ref2.float()) <= 3e-3
+    if clip < 256:
+        assert out.float().abs().max().item() <= clip
