@@ -29,6 +29,12 @@
 // wait for the load on the spot; loop-invariant per-lane address terms are hoisted into 20-60 registers and spilled (an opaque copy of the lane
 // index per tile stops that); a spill reload inside the tile loop waits on vmcnt behind the staging loads.
 //
+// Also built and measured: conv_res0 one 32-channel half at a time (18 dependent MFMAs) with the mp_silu epilogue of the half before it issued in
+// the MFMA shadow of the same wave -- the tile time behaves as the SUM of the two pipes' work per SIMD (removing the 4 200 VALU cycles of the
+// conv_res0 epilogue shortens a tile by exactly that), so the interleave inside one wave is the lever -- but with 144 weight registers, two
+// accumulator halves, the fragment ring and the staging registers the allocator spills 22-48 registers and the kernel lands at 114-146 us.
+// Not kept; the budget of 256 registers at two waves per SIMD is what this structure runs into.
+//
 // Measured (tools/pair_bench.py, graph replay, MI355X): B = 4: 115 us in two launches -> 88 us; B = 32: 854 -> 637 us (with the activated twin
 // 952 -> 698).  Counters (tools/pmc_pair.sh): MFMA busy 30 % of the SIMD cycles, VALU 32 % (2 M of the 12.5 M VALU instructions are the
 // quarter-rate v_exp_f32 / v_rcp_f32 of mp_silu), LDS 23 % with 30 % bank-conflict cycles, waves waiting 37 % of their time.
