@@ -69,7 +69,7 @@ struct PairArgs {
   bf16* out; bf16* out2;
   int B, H, W, C, G, tiles_h, tiles_w, units, wgs_per_group;
   float res_a, res_b, clip, out2_scale;
-  int dbg;   // DDX_PAIR_DBG timing ablations: 1 no conv_res0 matrix loop, 2 no conv_res1 matrix loop, 4 no tile DMA, 8 no output stores, 16 no hidden writes
+  int dbg;   // DDX_ABLATE timing ablations: 1 no conv_res0 matrix loop, 2 no conv_res1 matrix loop, 4 no staging loads, 8 no output stores, 16 no hidden writes
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -394,7 +394,7 @@ extern "C" int ddx_mpconv_pair_fwd(const ddx_conv_pair_desc* dp, ddx_stream stre
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   a.wgs_per_group = std::max(1, std::min(cus / d.groups, a.units));
   const float t = d.res_t, nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
-  a.dbg = std::getenv("DDX_PAIR_DBG") ? std::atoi(std::getenv("DDX_PAIR_DBG")) : 0;
+  a.dbg = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;
   a.res_a = (1.f - t) / nrm; a.res_b = t / nrm; a.clip = d.clip; a.out2_scale = d.out2_scale;
   const int smem = IN_BYTES + 2 * HID_BYTES + d.B * CH * 8;
   const double px = (double)d.B * d.H * d.W;

@@ -49,7 +49,7 @@ struct SmArgs {
   int npass, SCtot;                      // K passes through LDS, chunks of the whole layer
   int PT, WT;                            // pixel tiles, weight (channel) tiles
   int M, HW;                             // B*H*W, H*W
-  int dbg;                               // DDX_SM_DBG ablation bits (timing experiments; wrong results): 1 no weight loads, 2 no operand DMA, 4 no MFMA, 8 no reduction
+  int dbg;                               // DDX_ABLATE ablation bits (timing experiments; wrong results): 1 no weight loads, 2 no operand DMA, 4 no MFMA, 8 no reduction
   float inv_V1, inv_HW, inv_W;
 };
 
@@ -312,7 +312,7 @@ constexpr int kNP1 = 10;   // weight fragments per wave and K pass
 int env_int(const char* name) { const char* e = std::getenv(name); return e ? atoi(e) : 0; }
 
 bool sm_plan(const ConvParams& p, SmPlan* out) {
-  static const int dbg = env_int("DDX_SM_DBG");   // timing ablations only (tools/sm_ablate.sh)
+  static const int dbg = env_int("DDX_ABLATE");   // timing ablations only (tools/sm_ablate.sh)
   if (p.G != 1) return false;
   SmPlan best{}; double best_cost = 1e30; bool found = false;
   for (int PF = 1; PF <= 2; ++PF) {

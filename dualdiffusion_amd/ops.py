@@ -284,7 +284,7 @@ def conv2d_dgrad_act(dy: torch.Tensor, pw_t: PreparedWeight, y0: torch.Tensor, *
             silu_scale_bwd(da[..., Cs:], y1, None, scale1, add=add[..., Cs:] if add is not None else None, act=act))
 
 
-_FUSE_DGRAD_ACT = os.environ.get("DDX_FUSE_DGRAD_ACT", "1") != "0"
+_FUSE_DGRAD_ACT = True       # (tests flip it to compare against conv + silu_scale_bwd)
 _dgrad_act_fused_calls = 0      # how often the fused launch was taken (tests check that a qualifying layer really used it)
 
 
