@@ -29,11 +29,18 @@
 // wait for the load on the spot; loop-invariant per-lane address terms are hoisted into 20-60 registers and spilled (an opaque copy of the lane
 // index per tile stops that); a spill reload inside the tile loop waits on vmcnt behind the staging loads.
 //
-// Also built and measured: conv_res0 one 32-channel half at a time (18 dependent MFMAs) with the mp_silu epilogue of the half before it issued in
-// the MFMA shadow of the same wave -- the tile time behaves as the SUM of the two pipes' work per SIMD (removing the 4 200 VALU cycles of the
-// conv_res0 epilogue shortens a tile by exactly that), so the interleave inside one wave is the lever -- but with 144 weight registers, two
-// accumulator halves, the fragment ring and the staging registers the allocator spills 22-48 registers and the kernel lands at 114-146 us.
-// Not kept; the budget of 256 registers at two waves per SIMD is what this structure runs into.
+// Also built and measured (round 4), not kept:
+//   * conv_res0 one 32-channel half at a time (18 dependent MFMAs) with the mp_silu epilogue of the half before it issued between the MFMAs of
+//     the same wave, all 144 weight registers resident: the allocator spills 22-48 registers, 114-146 us;
+//   * the same with every conv_res0 wave owning ONE half (72 weight registers, fragments alternating between two accumulators, the scaled
+//     copies of c in 32 registers, all staging on these waves, two taps of conv_res1's weights parked in LDS so that nothing spills): the
+//     instruction stream is as intended (MFMA, ~12 VALU, MFMA, ...) and a fragment still takes ~1 500 cycles = its 576 MFMA cycles PLUS its
+//     ~800 VALU cycles: 106 us.  Matrix and vector work of a SIMD add up here whether they come from two waves or are interleaved inside
+//     one; what shortens a tile is fewer VALU cycles (the packed mp_silu: 130 -> 91 us) or fewer MFMA cycles, not their arrangement.
+//   * Two smaller traps of those variants: a value declared outside the role branch but defined inside it is merged with an undefined value at
+//     the join and occupies registers on the other role's path (28 staging registers cost the conv_res1 waves 128 spilled weight registers);
+//     a register read by a store still in flight cannot be overwritten (the compiler waits for the store), so output stores issued right
+//     before the next tile's accumulators are zeroed cost the store latency per tile.
 //
 // Measured (tools/pair_bench.py, graph replay, MI355X): B = 4: 115 us in two launches -> 88 us; B = 32: 854 -> 637 us (with the activated twin
 // 952 -> 698).  Counters (tools/pmc_pair.sh): MFMA busy 30 % of the SIMD cycles, VALU 32 % (2 M of the 12.5 M VALU instructions are the
