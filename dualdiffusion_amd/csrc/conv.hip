@@ -281,7 +281,7 @@ static int dgrad_act_fill(const ddx_dgrad_act_desc& d, ConvParams* pp) {
   if (d.dchan_scale && (!d.chan_scale || d.split > 0)) return set_error(DDX_ERR_ARG, "dgrad_act: dchan_scale needs chan_scale and one part");
   p.epilogue = DDX_EPI_SILU_BWD;
   p.res = d.y0; p.bwd_y1 = d.y1; p.bwd_out1 = d.out1; p.bwd_add = d.add; p.out_cs = d.chan_scale;
-  p.bwd_dc = d.dchan_scale; p.bwd_ws = d.dchan_scale ? d.workspace : nullptr;
+  p.bwd_dc = d.dchan_scale; p.bwd_ws = nullptr;
   p.bwd_split = d.split; p.bwd_act = d.act; p.bwd_s0 = d.scale0; p.bwd_s1 = d.scale1;
   *pp = p;
   return 0;
@@ -323,6 +323,5 @@ extern "C" int ddx_mpconv2d_dgrad_act(const ddx_dgrad_act_desc* dp, ddx_stream s
   }
   if (d.conv.dtype != DDX_BF16 || !conv_dma_supported(p, ks, d.conv.dtype, /*any_size=*/true))
     return set_error(DDX_ERR_UNSUPPORTED, "dgrad_act: layer does not qualify for the LDS-DMA kernel (run the conv and ddx_silu_scale_bwd)");
-  if (d.dchan_scale && !d.workspace) return set_error(DDX_ERR_ARG, "dgrad_act: workspace missing");
   return dispatch([p, ks](hipStream_t s) -> int { return launch_conv_dma(p, ks, s); }, stream, ks == 3 ? "conv3x3_dma_bwd" : "conv1x1_dma_bwd", flops, bytes);
 }

@@ -948,7 +948,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     }
     DDX_TR(4);
     if constexpr (EB) {
-      if (p.bwd_ws) {
+      if (p.bwd_dc) {
         // channel sums of this wave's 64 pixels: the 16 lanes that share (lane & 3) hold the same 8*NF channels.  Transposing
         // all-reduce: every step halves the values a lane is responsible for and adds the partner's half, so 8*NF - 1 (+1)
         // shuffles leave ONE finished channel sum per lane instead of 4 * 8 * NF shuffles for a plain butterfly.
@@ -976,7 +976,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
         if constexpr (NV == 16) step(std::integral_constant<int, 1>{}, 4);
         else v[0] += __shfl_xor(v[0], 4, 64);  // NF = 1: the last step is a plain pair sum (both lanes hold it)
         const bool writer = NV == 16 || (lane & 4) == 0;
-        if (writer) p.bwd_ws[((size_t)u * NW + wave) * (NF * 32) + (vid >> 3) * 32 + (lane & 3) * 8 + (vid & 7)] = v[0];
+        // one atomic per (wave, channel) straight into the [B][Cout] gradient (round 4: the per-unit workspace + reduction launch it replaces
+        // cost 20 launches / 0.33 ms of a B=8 training step; a few hundred adds per address spread over the kernel's life are absorbed by L2)
+        const int chn = t.n0 + (vid >> 3) * 32 + (lane & 3) * 8 + (vid & 7);
+        if (writer && chn < p.Ng) atomicAdd(p.bwd_dc + (size_t)t.b * p.Cout + t.g * p.Ng + chn, v[0] * p.bwd_s0);
       }
     }
   }
@@ -1008,24 +1011,6 @@ static void dma_trace_report(long total) {
 
 // dc[b][c] += scale * sum over the (pixel tile, wave) partial rows of image b written by the EB epilogue.
 // Row index = unit * NW + wave with unit = (g * ntile_n + nt) * ntile_px + b * tiles_per_image + tile.
-__global__ __launch_bounds__(256) void conv_dc_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dc, int rows_per_image, int rows_per_gn,
-                                                             int BN, int ntile_n, int Ng, int Cout, float scale) {
-  __shared__ float red[256];
-  const int gn = blockIdx.x, b = blockIdx.y;
-  const int g = gn / ntile_n, nt = gn - g * ntile_n;
-  const int ch = threadIdx.x % BN, sub = threadIdx.x / BN, nsub = 256 / BN;
-  const float* base = ws + ((size_t)gn * rows_per_gn + (size_t)b * rows_per_image) * BN;
-  float s = 0.f;
-  for (int r = sub; r < rows_per_image; r += nsub) s += base[(size_t)r * BN + ch];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (sub == 0) {
-    for (int k = 1; k < nsub; ++k) s += red[k * BN + ch];
-    const int c = nt * BN + ch;
-    if (c < Ng) dc[(size_t)b * Cout + g * Ng + c] += s * scale;
-  }
-}
-
 template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int WS = 0>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
@@ -1054,11 +1039,6 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
     per_xcd = (int)((total + 7) / 8);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GEO::NW), SMEM_BYTES, s, p, (int)total, ntile_n, per_xcd);
-  if (EB && p.bwd_ws && p.bwd_dc) {
-    const int tpi = p.tiles_h * p.tiles_w;
-    hipLaunchKernelGGL(conv_dc_reduce_kernel, dim3(p.G * ntile_n, p.B), dim3(256), 0, s, (const float*)p.bwd_ws, p.bwd_dc, tpi * GEO::NW,
-                       p.B * tpi * GEO::NW, GEO::BN, ntile_n, p.Ng, p.Cout, p.bwd_s0);
-  }
   dma_trace_report(total);
   return check_launch("conv_dma");
 }
@@ -1215,13 +1195,12 @@ bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size
   return tiles * ceil_div(p.Ng, p.Ng <= 32 ? 32 : 64) >= (ksize == 3 ? 384 : 512);
 }
 
+// does the DDX_EPI_SILU_BWD epilogue serve this layer (every channel tile inside one part)?  Returns a 16-byte token: the channel-scale
+// gradient is accumulated with per-wave atomics, no workspace is used any more (the name is the ABI's)
 size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize) {
   int TH = 0, TW = 0; double util;
   if (!dma_tile(p, ksize, &TH, &TW, &util)) return 0;
-  const int BN = dma_bwd_bn(p);
-  if (BN == 0) return 0;
-  const size_t units = (size_t)p.B * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.Ng, BN) * p.G;
-  return units * 4 * BN * sizeof(float);
+  return dma_bwd_bn(p) == 0 ? 0 : 16;
 }
 
 int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {

@@ -38,8 +38,8 @@ struct ConvParams {
   const void* bwd_y1;   // y of the second channel part (or null)
   void* bwd_out1;       // output of the second channel part
   const void* bwd_add;  // [B][H][W][Cout] gradient added to the result (or null)
-  float* bwd_ws;        // per (unit, wave) channel sums of dz * y for the dc reduction (or null)
-  float* bwd_dc;        // [B][Cout] accumulated chan_scale gradient (with bwd_ws)
+  float* bwd_ws;        // (unused since round 4: the channel sums go to bwd_dc with per-wave atomics)
+  float* bwd_dc;        // [B][Cout] accumulated chan_scale gradient
   int bwd_split, bwd_act;
   float bwd_s0, bwd_s1;
   // spatial tiling (MFMA kernel)
@@ -66,6 +66,6 @@ bool conv_few_supported(const ConvParams& p, int ksize, int dtype);  // conv_few
 int launch_conv_few(const ConvParams& p, hipStream_t s);
 bool conv_gemm_supported(const ConvParams& p, int ksize, int dtype, bool auto_pick);  // conv_gemm.hip (mid-size raw 1x1 layers: 128 x 128 GEMM tiles, deep LDS-DMA ring)
 int launch_conv_gemm(const ConvParams& p, hipStream_t s);
-size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize);  // per (unit, wave) channel sums of the DDX_EPI_SILU_BWD epilogue
+size_t conv_dma_bwd_ws_bytes(const ConvParams& p, int ksize);  // 16 when the DDX_EPI_SILU_BWD epilogue serves the layer, else 0
 
 }  // namespace ddx

@@ -211,9 +211,9 @@ int ddx_mpconv_pair_fwd(const ddx_conv_pair_desc* d, ddx_stream stream);
  *     dz = dA * mp_silu'(y * s) | dA;     out = dz * s (+ add);     dchan_scale[b][c] += scale * sum_pixels dz * y.
  * The output channels may be split after `split` channels over two tensors with their own y and scalar scale (the two
  * sources of an mp_cat: conv.out / y0 / scale0 hold channels [0, split), out1 / y1 / scale1 the rest; split % 64 == 0).
- * Served by the kernel the forward dispatch would pick for the conv: the LDS-DMA kernel (per-unit channel sums in the workspace + a
- * reduction launch) or, for the small layers it leaves to the register-staged kernel (levels 3 / 4 of the default UNet; split % 4 == 0),
- * that kernel with the same epilogue (per-wave atomics into dchan_scale; no workspace is used, the size query returns a 16-byte token).
+ * Served by the kernel the forward dispatch would pick for the conv: the LDS-DMA kernel or, for the small layers it leaves to the
+ * register-staged kernel (levels 3 / 4 of the default UNet; split % 4 == 0), that kernel with the same epilogue.  Either way dchan_scale is
+ * accumulated with one atomic per (wave, channel); `workspace` is not used any more (round 4) and the size query returns a 16-byte token.
  * ddx_mpconv2d_dgrad_act_workspace_bytes() returns 0 when the layer does not qualify for either -- run ddx_mpconv2d_fwd +
  * ddx_silu_scale_bwd_ex then.  conv.epilogue / residual / out2 / out_act / out_scale are ignored.
  * ------------------------------------------------------------------------------------------------ */
@@ -225,7 +225,7 @@ typedef struct {
   const void* add;           /* NHWC [B][H][W][Cout] or NULL */
   const float* chan_scale;   /* [B][Cout] fp32 or NULL */
   float* dchan_scale;        /* [B][Cout] fp32, accumulated, or NULL (needs chan_scale, split = 0) */
-  float* workspace;          /* ddx_mpconv2d_dgrad_act_workspace_bytes() bytes (only used with dchan_scale) */
+  float* workspace;          /* unused (kept for the ABI); may be NULL */
   int32_t split, act;
   float scale0, scale1;
 } ddx_dgrad_act_desc;
