@@ -17,8 +17,39 @@
 
 namespace ddx {
 
+// -DDDX_FGLA_TRACE (tools/fgla_trace.sh): thread 0 of every workgroup times its three phases -- operands into LDS (global loads + math),
+// the in-LDS FFT-6400, results out (global stores issued) -- with s_memtime, plus the workgroup's start / end on the constant 100 MHz clock;
+// the host prints per-phase cycles per workgroup and how many workgroups were in flight per CU on average (sum of workgroup lifetimes /
+// kernel span / 256).  A barrier is added after the first phase so that the phases are the whole workgroup's, not thread 0's.
+#ifdef DDX_FGLA_TRACE
+#include <cstdio>
+#include <vector>
+constexpr int kFtMax = 1 << 16;
+__device__ unsigned long long g_ftrace[kFtMax][6];   // per workgroup: load, fft, store cycles; start, end (100 MHz ticks); valid -- plain stores, no contention
+#define DDX_FT_BEGIN() long long ft_t0 = clock64(), ft_t1 = 0, ft_t2 = 0; const unsigned long long ft_w0 = wall_clock64()
+#define DDX_FT_LOADED() do { __syncthreads(); ft_t1 = clock64(); } while (0)
+#define DDX_FT_FFT() do { __syncthreads(); ft_t2 = clock64(); } while (0)
+#define DDX_FT_END(k) do { if (threadIdx.x == 0) { const long long t3 = clock64(); const unsigned long long w1 = wall_clock64(); \
+    const int wgid = blockIdx.y * gridDim.x + blockIdx.x; if (wgid < kFtMax) { unsigned long long* r = g_ftrace[wgid]; \
+    r[0] = ft_t1 - ft_t0; r[1] = ft_t2 - ft_t1; r[2] = t3 - ft_t2; r[3] = ft_w0; r[4] = w1; r[5] = 1; } } } while (0)
+#else
+#define DDX_FT_BEGIN() do {} while (0)
+#define DDX_FT_LOADED() do {} while (0)
+#define DDX_FT_FFT() do {} while (0)
+#define DDX_FT_END(k) do {} while (0)
+#endif
+
 constexpr int kFN = 6400;
-constexpr int kFNT = 640;   // 10 waves; 3 workgroups (3 x 51 KB of LDS) per CU.  (__launch_bounds__ second argument = min waves per SIMD: 8 -> <= 64 VGPRs)
+// Threads per frame.  512 = eight waves = two per SIMD, so the three workgroups that 3 x 51 KB of LDS allow really are resident (six waves per
+// SIMD).  Rounds 1-3 ran 640 threads (ten waves: 6400 / 640 = 10 points per thread, no tail in any stage) and the per-phase trace of round 4
+// (tools/fgla_trace.sh) showed 1.9 workgroups in flight per CU, not 3: ten waves land 3 + 3 + 2 + 2 on the SIMDs and a third workgroup would
+// need a ninth wave slot on one of them.  512 threads: 2.9 in flight, every phase of a frame slower (FFT 24 -> 31 k cycles), the iteration
+// 2.06 -> 1.95 ms at B=4, 8.59 -> 8.21 ms at B=16.  (-DDDX_FGLA_NT=n rebuilds with another count: 384 / 320 / 256 measured 2.19 / 2.22 / 2.28 ms.)
+#ifndef DDX_FGLA_NT
+#define DDX_FGLA_NT 512
+#endif
+constexpr int kFNT = DDX_FGLA_NT;
+constexpr int kFMinWaves = kFNT >= 512 ? 8 : 4;   // (__launch_bounds__ second argument = min waves per SIMD: 8 -> <= 64 VGPRs)
 
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][ustride] state, NB valid per row (nullptr: angles = 1)
@@ -30,11 +61,12 @@ struct FglaSynthParams {
   int final_pass, stereo_merge;
 };
 
-__global__ __launch_bounds__(kFNT, 8) void fgla_synth_kernel(const FglaSynthParams p) {
+__global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_synth_kernel(const FglaSynthParams p) {
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  DDX_FT_BEGIN();
   const size_t sbase = ((size_t)b * p.T + t) * p.C * p.ustride;
   // two bins per lane: rows of the state (ustride even) and of the magnitudes (mstride even) start 16 / 8-byte aligned,
   // so the state is read as one 16-byte vector per channel; the second bin of the last pair (k = NB) is row padding
@@ -73,7 +105,9 @@ __global__ __launch_bounds__(kFNT, 8) void fgla_synth_kernel(const FglaSynthPara
       if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
     }
   }
+  DDX_FT_LOADED();
   fft6400_inplace<true, kFNT>(bufA, p.tw, tid);
+  DDX_FT_FFT();
   float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
   const float invn = 1.0f / (float)N;
   for (int n = 4 * tid; n < N; n += 4 * kFNT) {   // 16 bytes per lane: four samples of each channel
@@ -88,6 +122,7 @@ __global__ __launch_bounds__(kFNT, 8) void fgla_synth_kernel(const FglaSynthPara
     *reinterpret_cast<f32x4*>(fr + n) = l4;
     if (p.C > 1) *reinterpret_cast<f32x4*>(fr + N + n) = r4;
   }
+  DDX_FT_END(0);
 }
 
 // overlap-add + window-envelope normalisation (torch.istft, center=True, length = hop*(T-1))
@@ -132,11 +167,12 @@ __device__ __forceinline__ int reflect_idx(int j, int L) {
   return j;
 }
 
-__global__ __launch_bounds__(kFNT, 8) void fgla_analysis_kernel(const FglaAnalysisParams p) {
+__global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_analysis_kernel(const FglaAnalysisParams p) {
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  DDX_FT_BEGIN();
   const float* aL = p.audio + (size_t)b * p.C * p.L;
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
   const int base = t * p.hop - N / 2;
@@ -158,7 +194,9 @@ __global__ __launch_bounds__(kFNT, 8) void fgla_analysis_kernel(const FglaAnalys
 #pragma unroll
     for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
   }
+  DDX_FT_LOADED();
   fft6400_inplace<false, kFNT>(bufA, p.tw, tid);
+  DDX_FT_FFT();
   float2* ro = p.u + ((size_t)b * p.T + t) * p.C * p.ustride;
   for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {   // two bins per lane: 16-byte read-modify-write of the state rows
     f32x4 ul = *reinterpret_cast<const f32x4*>(ro + k0), ur = {0.f, 0.f, 0.f, 0.f};
@@ -177,6 +215,7 @@ __global__ __launch_bounds__(kFNT, 8) void fgla_analysis_kernel(const FglaAnalys
     *reinterpret_cast<f32x4*>(ro + k0) = ul;
     if (p.C > 1) *reinterpret_cast<f32x4*>(ro + p.ustride + k0) = ur;
   }
+  DDX_FT_END(1);
 }
 
 // mel samples (B, C, n_mel, T) -> linear mel amplitudes laid out [B*C][T][n_mel] for the un-mel GEMM:
@@ -196,6 +235,35 @@ __global__ __launch_bounds__(256) void mel_to_amp_kernel(const float* __restrict
 }  // namespace ddx
 
 using namespace ddx;
+
+// trace builds: print and reset the per-phase counters of kernel k after its launch (synchronises: timing experiments only)
+static void fgla_trace_report(int k, const char* name) {
+#ifdef DDX_FGLA_TRACE
+  (void)k;
+  static std::vector<unsigned long long> h((size_t)kFtMax * 6);
+  if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_ftrace), h.size() * 8) == hipSuccess) {
+    double ph[3] = {0, 0, 0}, life = 0, n = 0;
+    unsigned long long w0 = ~0ull, w1 = 0;
+    for (int i = 0; i < kFtMax; ++i) {
+      const unsigned long long* r = &h[(size_t)i * 6];
+      if (!r[5]) continue;
+      ph[0] += r[0]; ph[1] += r[1]; ph[2] += r[2]; life += (double)(r[4] - r[3]); n += 1;
+      w0 = std::min(w0, r[3]); w1 = std::max(w1, r[4]);
+    }
+    if (n > 0) {
+      const double span = (double)(w1 - w0);
+      fprintf(stderr, "[fgla trace] %-8s %6.0f workgroups: cycles per workgroup  operands->LDS %7.0f  FFT-6400 %7.0f  results out %7.0f | lifetime %.2f us, "
+              "kernel span %.1f us, %.2f workgroups in flight per CU\n", name, n, ph[0] / n, ph[1] / n, ph[2] / n, life / n / 100.0, span / 100.0,
+              span > 0 ? life / span / 256.0 : 0.0);
+    }
+  }
+  (void)hipMemset(nullptr, 0, 0);
+  void* sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_ftrace)) == hipSuccess) (void)hipMemset(sym, 0, (size_t)kFtMax * 6 * 8);
+#else
+  (void)k; (void)name;
+#endif
+}
 
 static int set_fft_smem(const void* kern, bool* done) {
   if (!*done) {
@@ -219,6 +287,7 @@ extern "C" int ddx_fgla_synth(const float* u, int32_t u_stride, const float* mag
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_synth_kernel), &done)) return rc;
     hipLaunchKernelGGL(fgla_synth_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
+    fgla_trace_report(0, "synth");
     return check_launch("fgla_synth");
   }, stream, "fgla_synth");
 }
@@ -247,6 +316,7 @@ extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const 
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_analysis_kernel), &done)) return rc;
     hipLaunchKernelGGL(fgla_analysis_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
+    fgla_trace_report(1, "analysis");
     return check_launch("fgla_analysis");
   }, stream, "fgla_analysis");
 }
