@@ -61,7 +61,7 @@ class ConvDesc(C.Structure):
                 ("out_scale", C.c_void_p), ("out2", C.c_void_p), ("out_act", C.c_int32), ("out2_scale", C.c_float),
                 ("pad_mode", C.c_int32), ("prologue_rows", C.c_int32),
                 ("out2_linear", C.c_int32), ("layout", C.c_int32), ("out2_chan_scale", C.c_void_p), ("src0_alt", C.c_void_p),
-                ("residual_up", C.c_int32)]
+                ("residual_up", C.c_int32), ("out_head_norm", C.c_int32), ("out_head_eps", C.c_float)]
 
 
 class DgradActDesc(C.Structure):

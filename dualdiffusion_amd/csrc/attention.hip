@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   const size_t rbase = (size_t)b_img * Tn * fold + (size_t)(b - b_img * fold);
   const int C = heads * D;
   const float inv_sqrt_d = rsqrtf((float)D);
+  const bool pre = sizeof(T) == 2 && eps < 0.f;   // see ddx_attn_fold_fwd: negative eps = q, k, v already RMS-normalised per head (bf16)
 
   const int sv = tid % VPR;        // vector inside the row handled by this thread while staging
   const int sr = tid / VPR;
@@ -114,8 +115,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
     float ss = 0.f;
 #pragma unroll
     for (int e = 0; e < EV; ++e) { f[e] = x.get(e); ss += f[e] * f[e]; }
-    ss = group_sum<VPR>(ss);
-    const float sc = inv_sqrt_d / (eps + sqrtf(ss) * inv_sqrt_d);
+    float sc = inv_sqrt_d;                       // (eps < 0: q, k, v arrive normalised from their producer's epilogue -- only the 1 / sqrt(D))
+    if (!pre) {
+      ss = group_sum<VPR>(ss);
+      sc = inv_sqrt_d / (eps + sqrtf(ss) * inv_sqrt_d);
+    }
     Vec16<T> y;
 #pragma unroll
     for (int e = 0; e < EV; ++e) y.set(e, f[e] * sc);
@@ -141,6 +145,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 
   // ---- stage K (normalised) and V^T (normalised, transposed) of one chunk from the registers loaded ahead
   auto stage_kv = [&](T* sK, T* sVt) {
+    if constexpr (sizeof(T) == 2) {
+      if (pre) {     // normalised operands: the rows go to LDS as they came (no conversion, no reduction)
+#pragma unroll
+        for (int i = 0; i < NPK; ++i) {
+          const int r = sr + i * RPP;
+          *reinterpret_cast<VT*>(sK + r * QS + sv * EV) = kreg[i];
+          *reinterpret_cast<VT*>(sVt + r * QS + sv * EV) = vreg[i];
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
       const int r = sr + i * RPP;

@@ -168,6 +168,10 @@ static int conv_fill(const ddx_conv_desc& d, ConvParams* pp) {
   p.clip = d.clip;
   p.out_cs = d.out_scale; p.out2 = d.out2; p.out_act = d.out_act; p.out2_scale = d.out2_scale;
   p.src0_alt = d.src0_alt; p.out2_cs = d.out2_chan_scale; p.out2_linear = d.out2_linear;
+  p.head_norm = d.out_head_norm; p.head_eps = d.out_head_eps;
+  if (d.out_head_norm && (d.out_head_norm != 64 || d.ksize != 1 || d.groups != 1 || d.Cout % 64 || d.epilogue != DDX_EPI_STORE || d.out2 || d.out_act ||
+                          d.out_scale || d.dtype != DDX_BF16 || !(d.out_head_eps >= 0.f)))
+    return set_error(DDX_ERR_UNSUPPORTED, "conv: out_head_norm is served for 64-channel heads on plain-store bf16 1x1 layers without groups");
   if (d.out2_linear && (!d.out2 || !d.out2_chan_scale)) return set_error(DDX_ERR_ARG, "conv: out2_linear needs out2 and out2_chan_scale");
   if (d.src0_alt && (d.prologue != DDX_PRO_NONE || d.prologue_rows <= 0)) return set_error(DDX_ERR_ARG, "conv: src0_alt needs prologue_rows > 0 and no prologue");
   p.layout = d.layout;
@@ -222,6 +226,8 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
   // >= 16: the register-staged kernel with tile / split-K configuration (force_direct - 16), see ConvParams::force_cfg
   if (d.force_direct >= 16) p.force_cfg = d.force_direct - 16 + 1;
   // CK = 16 is the weight layout of the small-M weight-streaming kernel (conv_sm.hip): the choice was made when the weights were prepared
+  if (d.out_head_norm && (d.CK == 16 || d.force_direct == 1 || d.force_direct == 3 || d.force_direct == 4 || d.force_direct == 5))
+    return set_error(DDX_ERR_UNSUPPORTED, "conv: out_head_norm runs on the 1x1 GEMM kernel and the register-staged kernel only");
   if (d.CK == 16 && d.force_direct != 1 && d.force_direct != 3 && !d.layout) {
     if ((d.force_direct != 0 && d.force_direct != 4) || !conv_sm_supported(p, ks, dt))
       return set_error(DDX_ERR_UNSUPPORTED, "conv: weights prepared with CK = 16 run on the small-M kernel only, and this layer does not qualify");
@@ -254,7 +260,9 @@ static int conv_fwd_impl(const ddx_conv_desc& d, ddx_stream stream, bool query) 
   if (d.force_direct == 3 && !conv_dma_supported(p, ks, dt, /*any_size=*/true))
     return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the LDS-DMA kernel");
   const bool dma = d.force_direct == 3 || d.epilogue == DDX_EPI_PIXELNORM ||
-                   (d.force_direct == 0 && mfma && dma_enabled && conv_dma_supported(p, ks, dt, false));
+                   (d.force_direct == 0 && mfma && dma_enabled && !d.out_head_norm && conv_dma_supported(p, ks, dt, false));
+  if (d.out_head_norm && (!mfma || conv_mfma_tile_bn(p, ks, dt) % d.out_head_norm))
+    return set_error(DDX_ERR_UNSUPPORTED, "conv: out_head_norm needs a channel tile that is a multiple of the head size");
   if (d.force_direct >= 16 && !mfma) return set_error(DDX_ERR_UNSUPPORTED, "conv: layer does not qualify for the register-staged MFMA kernel");
   if (d.out2_linear && d.CK != 16 && (dma || !mfma))
     return set_error(DDX_ERR_UNSUPPORTED, "conv: out2_linear is served by the small-M kernel (CK = 16) and the register-staged MFMA kernel only");
@@ -281,7 +289,7 @@ static int dgrad_act_fill(const ddx_dgrad_act_desc& d, ConvParams* pp) {
   if (d.dchan_scale && (!d.chan_scale || d.split > 0)) return set_error(DDX_ERR_ARG, "dgrad_act: dchan_scale needs chan_scale and one part");
   p.epilogue = DDX_EPI_SILU_BWD;
   p.res = d.y0; p.bwd_y1 = d.y1; p.bwd_out1 = d.out1; p.bwd_add = d.add; p.out_cs = d.chan_scale;
-  p.bwd_dc = d.dchan_scale; p.bwd_ws = nullptr;
+  p.bwd_dc = d.dchan_scale;
   p.bwd_split = d.split; p.bwd_act = d.act; p.bwd_s0 = d.scale0; p.bwd_s1 = d.scale1;
   *pp = p;
   return 0;

@@ -171,8 +171,17 @@ __global__ __launch_bounds__(256, smem_bytes(GK, NS) <= 80 * 1024 ? 2 : 1) void 
     const int idx = tid + it * 256;
     const int ml = idx >> 5, c4 = idx & 31;
     const int m = m0 + ml, n = n0 + c4 * 4;
+    f32x4 y4 = *reinterpret_cast<const f32x4*>(sE + (size_t)ml * ES + c4 * 4);
+    if (p.head_norm) {
+      // 16 consecutive lanes hold the 64 channels of one head of one pixel (ddx_conv_desc::out_head_norm): y / (eps + |y| / sqrt(64))
+      float ss = y4[0] * y4[0] + y4[1] * y4[1] + y4[2] * y4[2] + y4[3] * y4[3];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float sc = 1.0f / (p.head_eps + sqrtf(ss) * 0.125f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y4[e] *= sc;
+    }
     if (m >= a.M || n >= p.Ng) continue;
-    const f32x4 y4 = *reinterpret_cast<const f32x4*>(sE + (size_t)ml * ES + c4 * 4);
     bf16x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = (bf16)(p.clip > 0.f ? fminf(fmaxf(y4[e], -p.clip), p.clip) : y4[e]);

@@ -484,6 +484,16 @@ __global__ __launch_bounds__(256 * KSP, (KSP == 1 ? 2 : 1)) void conv_mfma_kerne
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(y[e], -p.clip), p.clip);
     }
+    if (p.head_norm) {
+      // BN is a multiple of 64 here (conv.hip checks): 16 consecutive lanes hold the 64 channels of one head of one pixel
+      // (ddx_conv_desc::out_head_norm): y / (eps + |y| / sqrt(64)).  Every lane takes part (items past the tile read row BM * G4 - 1).
+      float ss = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float sc = 1.0f / (p.head_eps + sqrtf(ss) * 0.125f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] *= sc;
+    }
     if (eoff[it] < 0) continue;
     if (p.out2) {  // activated twin for the next block's conv_res0
       Vec4<T> tv;
@@ -668,6 +678,11 @@ static int launch_t(const ConvParams& p, int ksize, const Choice& c, hipStream_t
   if (ksize == 1 && p.CK == 64) return launch_ks<T, 1, 64>(p, c, s);
   if (ksize == 1 && p.CK == 32) return launch_ks<T, 1, 32>(p, c, s);
   return set_error(DDX_ERR_UNSUPPORTED, "conv_mfma: ksize/CK combination not built");
+}
+
+int conv_mfma_tile_bn(const ConvParams& p, int ksize, int dtype) {
+  const Choice c = choose(p, ksize, dtype);
+  return c.BM == 0 ? 0 : c.BN;
 }
 
 int launch_conv_mfma(const ConvParams& p_in, int ksize, int dtype, hipStream_t s) {

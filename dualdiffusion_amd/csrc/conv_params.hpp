@@ -31,6 +31,8 @@ struct ConvParams {
   const void* src0_alt; // small-M kernel: source of the output-channel tiles below pro_rows (x * c twin), or null
   const float* out2_cs; // small-M kernel: per-(b, channel) scale of a LINEAR twin (out2 = y * out2_cs), with out2_linear
   int out2_linear;
+  int head_norm;        // > 0: RMS-normalise every run of head_norm output channels of a pixel in the epilogue (ddx_conv_desc::out_head_norm)
+  float head_eps;
   int layout;           // DDX_LAYOUT_* bits: which tensors are channel-blocked [B][C/16][H][W][16] (LDS-DMA kernel)
   int swap1;            // src1 is read from image b ^ 1 (DDX_PAD_SWAP_SRC1)
   int paired;           // input = [src0 | src1 | src0' | src1'], ' = image b ^ 1 (DDX_PAD_SWAP_PAIRED); Cin = 2 * (C0 + C1)
@@ -38,8 +40,7 @@ struct ConvParams {
   const void* bwd_y1;   // y of the second channel part (or null)
   void* bwd_out1;       // output of the second channel part
   const void* bwd_add;  // [B][H][W][Cout] gradient added to the result (or null)
-  float* bwd_ws;        // (unused since round 4: the channel sums go to bwd_dc with per-wave atomics)
-  float* bwd_dc;        // [B][Cout] accumulated chan_scale gradient
+  float* bwd_dc;        // [B][Cout] accumulated chan_scale gradient (one atomic per wave and channel)
   int bwd_split, bwd_act;
   float bwd_s0, bwd_s1;
   // spatial tiling (MFMA kernel)
@@ -56,6 +57,7 @@ __host__ __device__ inline size_t wp_index(int g, int n, int tap, int c, int nch
 
 int launch_conv_mfma(const ConvParams& p, int ksize, int dtype, hipStream_t s);   // conv_mfma.hip
 bool conv_mfma_supported(const ConvParams& p, int ksize, int dtype);
+int conv_mfma_tile_bn(const ConvParams& p, int ksize, int dtype);   // output channels per tile of the configuration launch_conv_mfma will pick (0: none)
 void conv_mfma_plan_tiles(ConvParams& p, int ksize, int dtype);
 int launch_conv_direct(const ConvParams& p, int ksize, int dtype, hipStream_t s);  // conv_direct.hip
 bool conv_dma_supported(const ConvParams& p, int ksize, int dtype, bool any_size);  // conv_dma.hip

@@ -87,7 +87,7 @@ extern "C" int64_t ddx_abi_sizeof(int32_t which) {
 extern "C" int64_t ddx_abi_offsetof_tail(int32_t which) {
   switch (which) {
     case 0: return offsetof(ddx_wprep_desc, rows_total);
-    case 1: return offsetof(ddx_conv_desc, residual_up);
+    case 1: return offsetof(ddx_conv_desc, out_head_eps);
     case 2: return offsetof(ddx_dgrad_act_desc, scale1);
     case 3: return offsetof(ddx_wgrad_desc, accumulate);
     case 4: return offsetof(ddx_linear_bwd_job, groups);

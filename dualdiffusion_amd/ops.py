@@ -113,7 +113,7 @@ class tuning:
 def _conv_signature(d: "L.ConvDesc") -> tuple:
     return (d.B, d.H, d.W, d.C0, d.C1, d.Cout, d.groups, d.ksize, d.CK, d.resample, d.prologue, d.epilogue, d.dtype, d.out_act,
             bool(d.chan_scale), bool(d.out_scale), bool(d.out2), d.pad_mode, d.prologue_rows, d.scale0 == 1.0, d.scale1 == 1.0, d.clip > 0,
-            bool(d.src0_alt), d.out2_linear, d.residual_up)
+            bool(d.src0_alt), d.out2_linear, d.residual_up, d.out_head_norm)
 
 
 def _tune_conv(d: "L.ConvDesc") -> int:
@@ -176,7 +176,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
            out_scale: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out2_scale: float = 1.0,
            path: str = "auto", reflect_w: bool = False, prologue_rows: int = 0, swap_src1: bool = False, swap_paired: bool = False, pixelnorm_eps: float = 0.0,
            out2_chan_scale: Optional[torch.Tensor] = None, src0_alt: Optional[torch.Tensor] = None, query: bool = False,
-           residual_up: bool = False):
+           residual_up: bool = False, head_norm: int = 0, head_eps: float = 1e-4):
     """Magnitude-preserving conv2d forward with fused prologue / epilogue (see include/ddx_hip.h).
     path: "auto" | "direct" (scalar kernel) | "mfma" (register-staged) | "dma" (LDS-DMA staged; raw bf16 operands only)
     | "sm" (small-M weight-streaming kernel; weights prepared with CK = 16, which also selects it automatically)
@@ -191,6 +191,8 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
     Small-M kernel only: out2_chan_scale [B, Cout] makes out2 the LINEAR twin y_final * out2_chan_scale (operand of attn_qk);
     src0_alt (with prologue_rows > 0): output channels below prologue_rows read src0_alt instead of src0.
     residual_up: `residual` is [B, H/2, W/2, Cout] and enters mp_sum nearest-upsampled (skip conv of an up block run at the source size).
+    head_norm = 64: every 64 consecutive output channels of a pixel are RMS-normalised in the epilogue (normalize() of the q | k | v vectors of the
+    merged attn_qk | attn_v conv; the attention op then takes prenorm=True).  1x1 GEMM kernel / register-staged kernel with 64-multiple tiles.
     Tensors marked with `mark_c16` are channel-blocked [B, C/16, H, W, 16] (same shape attribute, same bytes; 3x3 LDS-DMA kernel only).
     query=True: no launch, returns the kernel code the library would choose (2 register-staged, 3 LDS-DMA, 4 small-M, 1 scalar)."""
     B, sH, sW, C0 = src0.shape
@@ -212,7 +214,7 @@ def conv2d(src0: torch.Tensor, pw: PreparedWeight, *, out_hw: Optional[tuple] = 
                    out_scale=ptr(out_scale), out2=ptr(out2), out_act=int(out_act), out2_scale=float(out2_scale),
                    pad_mode=(L.PAD_REFLECT_W if reflect_w else L.PAD_ZERO) | (L.PAD_SWAP_SRC1 if swap_src1 else 0) | (L.PAD_SWAP_PAIRED if swap_paired else 0),
                    prologue_rows=prologue_rows, out2_linear=int(out2_chan_scale is not None), out2_chan_scale=ptr(out2_chan_scale), src0_alt=ptr(src0_alt),
-                   residual_up=int(residual_up))
+                   residual_up=int(residual_up), out_head_norm=int(head_norm), out_head_eps=float(head_eps if head_norm else 0.0))
     if query:
         return int(lib().ddx_mpconv2d_path(C.byref(d)))
     d.layout = ((L.LAYOUT_SRC0_C16 if is_c16(src0) else 0) | (L.LAYOUT_SRC1_C16 if is_c16(src1) else 0) |
@@ -253,9 +255,9 @@ def conv2d_dgrad_act(dy: torch.Tensor, pw_t: PreparedWeight, y0: torch.Tensor, *
                      add: Optional[torch.Tensor] = None, act: bool = True):
     """Data gradient of a conv whose operand was a = mp_silu(y * chan_scale * scale) (act) / y * chan_scale * scale, through the
     activation:  returns (dy0, dy1 | None) = silu_scale_bwd(conv2d(dy, pw_t), y, ...) per channel part (y0 | y1 are the two
-    sources of an mp_cat operand), `add` [.., C0 + C1] is added, dchan_scale [B, C] accumulates.  One LDS-DMA launch with the
-    activation backward in its epilogue when the layer qualifies (include/ddx_hip.h: ddx_mpconv2d_dgrad_act), otherwise the
-    conv followed by ddx_silu_scale_bwd per part."""
+    sources of an mp_cat operand), `add` [.., C0 + C1] is added, dchan_scale [B, C] accumulates.  One launch with the activation
+    backward in the conv's epilogue when the layer qualifies (LDS-DMA or register-staged kernel; include/ddx_hip.h:
+    ddx_mpconv2d_dgrad_act), otherwise the conv followed by ddx_silu_scale_bwd per part."""
     B, H, W, C0 = dy.shape
     Cs = y0.shape[-1]
     split = Cs if y1 is not None else 0
@@ -272,8 +274,6 @@ def conv2d_dgrad_act(dy: torch.Tensor, pw_t: PreparedWeight, y0: torch.Tensor, *
     if nbytes:
         global _dgrad_act_fused_calls
         _dgrad_act_fused_calls += 1
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if dchan_scale is not None else None
-        d.workspace = ptr(ws)
         check(lib().ddx_mpconv2d_dgrad_act(C.byref(d), current_stream()), "mpconv2d_dgrad_act")
         return out0, out1
     da = conv2d(dy, pw_t)
@@ -472,10 +472,15 @@ def pixelnorm(x: torch.Tensor, out: Optional[torch.Tensor] = None, eps: float = 
 
 
 def attention(qk: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None, eps: float = 1e-4,
-              out_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out_scale: Optional[torch.Tensor] = None, prenorm: bool = False) -> torch.Tensor:
     """qk `[B, H, W, 2C]` (head, {q,k}, d), v `[B, H, W, C]` (head, d) -> `[B, H, W, C]`;
     with `out_scale` [B, C] fp32 the stored result is mp_silu(o * out_scale) (operand of attn_proj).
-    qk / v may be channel slices of one wider NHWC tensor (a merged attn_qk | attn_v conv output)."""
+    qk / v may be channel slices of one wider NHWC tensor (a merged attn_qk | attn_v conv output).
+    prenorm (bf16): q, k, v were normalised per head by the conv that made them (conv2d(head_norm=...)); the kernel stages them untouched."""
+    if prenorm:
+        if v.dtype != torch.bfloat16:
+            raise L.DDXError("attention: prenorm is a bf16 path")
+        eps = -1.0
     B, H, W, Cn = v.shape
     if out is None:
         out = torch.empty(B, H, W, Cn, dtype=v.dtype, device=v.device)

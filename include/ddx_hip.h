@@ -169,6 +169,13 @@ typedef struct {
    * resample exactly (every output pixel is the same dot product), so the host runs the skip conv at the SOURCE size -- a quarter
    * of the matrix work and of the output bytes -- and the consumer gathers: the upsampled tensor never exists. */
   int32_t residual_up;
+  /* > 0: every run of `out_head_norm` consecutive output channels of a pixel is RMS-normalised in the epilogue, in fp32 on the accumulators:
+   * y / (out_head_eps + |y|_2 / sqrt(out_head_norm)) -- normalize(x, dim) of mp_tools.py:42-49 applied to the q | k | v vectors of the merged
+   * attn_qk | attn_v conv (unet_edm2_b4.py:141-143), so that the attention kernel stages them as they are (pass it eps < 0).  Served for 64
+   * on plain-store 1x1 layers by the mid-size GEMM kernel and by the register-staged kernel when its channel tile is a multiple of 64;
+   * DDX_ERR_UNSUPPORTED otherwise (ddx_mpconv2d_path tells). */
+  int32_t out_head_norm;
+  float out_head_eps;
 } ddx_conv_desc;
 
 int ddx_mpconv2d_fwd(const ddx_conv_desc* d, ddx_stream stream);
@@ -388,7 +395,9 @@ int ddx_attn_act_fwd_ld(const void* qk, int32_t qk_ld, const void* v, int32_t v_
  * [N][T][fold][channels] and the T tokens of an entry are `fold` rows apart -- attention along H for every (b, z, w) of the
  * reference's DAE_G1 block (modules/daes/dae_edm2_g1.py:209-228) without transposing the maps.  fold = 1 is ddx_attn_act_fwd_ld
  * (tokens = the H*W pixels of image n).  out_scale, if given, is indexed by image ([N][heads * head_dim]).
- * N * fold <= 65535. */
+ * N * fold <= 65535.
+ * eps < 0 (bf16): q, k and v are already RMS-normalised per head by their producer (ddx_conv_desc::out_head_norm); the kernel then only
+ * applies 1 / sqrt(head_dim) to q and stages k / v untouched.  The same holds for the three entry points above. */
 int ddx_attn_fold_fwd(const void* qk, int32_t qk_ld, const void* v, int32_t v_ld, void* out, const float* out_scale, int32_t N, int32_t T,
                       int32_t fold, int32_t heads, int32_t head_dim, float eps, int32_t dtype, ddx_stream stream);
 

@@ -42,8 +42,8 @@ def test_descriptor_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.MssDesc) == 96    # 7 pointers, 8 int32, float (+4 tail padding)
     assert ctypes.sizeof(_lib.WPathJob) == 120  # 8 pointers, float, 9 int32, 2 floats, 2 int32
     assert ctypes.sizeof(_lib.LinearBwdJob) == 40  # 4 pointers, 2 int32
-    assert ctypes.sizeof(_lib.DgradActDesc) == 184 + 7 * 8 + 4 * 4
-    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 12 * 4 + 4 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8 + 2 * 8 + 8   # + pad_mode, prologue_rows | out2_linear, layout, 2 pointers | residual_up (+4 tail padding)
+    assert ctypes.sizeof(_lib.DgradActDesc) == 192 + 7 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 6 * 8 + 12 * 4 + 4 * 4 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 8 + 2 * 8 + 16   # + pad_mode, prologue_rows | out2_linear, layout, 2 pointers | residual_up, out_head_norm, out_head_eps (+4 tail padding)
     assert ctypes.sizeof(_lib.LinearJob) == 3 * 8 + 2 * 4 + 4 * 4
     lib = _lib.lib() if os.path.isfile(_lib.LIB_PATH) else None
     if lib is not None:

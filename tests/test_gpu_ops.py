@@ -1155,3 +1155,73 @@ def test_conv_pair_matches_the_two_convs(case):
         assert rel_l2(out2.float(), ref2.float()) <= 3e-3
     if clip < 256:
         assert out.float().abs().max().item() <= clip
+
+
+@pytest.mark.parametrize("case", ["gemm_l3", "mfma_l4"])
+def test_conv_head_norm_epilogue(case):
+    """ddx_conv_desc::out_head_norm: the q | k | v vectors of the merged attn_qk | attn_v conv RMS-normalised per 64-channel head in the conv's
+    epilogue (fp32, on the accumulators; normalize() of mp_tools.py:42-49) -- on the mid-size GEMM kernel (level 3) and on the register-staged
+    kernel with its x * c prologue (level 4) -- against the same conv in fp32 + torch normalisation: a bf16 rounding of the result."""
+    ops = _ops()
+    from dualdiffusion_amd import _lib as L
+    dev = "cuda"
+    torch.manual_seed(21)
+    B, H, W, Cn = (4, 4, 86, 1024) if case == "gemm_l3" else (4, 2, 43, 1280)
+    x = torch.randn(B, H, W, Cn, device=dev).to(torch.bfloat16)
+    w = torch.randn(3 * Cn, Cn, 1, 1, device=dev)
+    c = torch.rand(B, Cn, device=dev) + 0.5
+    npix = B * H * W
+    kw = {}
+    if case == "mfma_l4":
+        kw = dict(prologue=L.PRO_SCALE, chan_scale=c, prologue_rows=2 * Cn)
+    outs = {}
+    for dt in (torch.bfloat16, torch.float32):
+        pw = ops.wprep(w, 1, dt, normalize=True, npix=npix, CK=ops.pick_ck(Cn, 1, dt, npix))
+        xx = x.to(dt)
+        if dt == torch.bfloat16:
+            code = ops.conv2d(xx, pw, query=True, head_norm=64, **kw)
+            assert code == (6 if case == "gemm_l3" else 2), code
+            outs[dt] = ops.conv2d(xx, pw, head_norm=64, head_eps=1e-4, **kw).float()
+        else:
+            y = ops.conv2d(xx, pw, **kw).float().reshape(B, H, W, 3 * Cn // 64, 64)
+            nrm = torch.linalg.vector_norm(y, dim=-1, keepdim=True)
+            outs[dt] = (y / (1e-4 + nrm * 64 ** -0.5)).reshape(B, H, W, 3 * Cn)
+    torch.cuda.synchronize()
+    e = rel_l2(outs[torch.bfloat16], outs[torch.float32])
+    print(f"head_norm {case}: rel-L2 {e:.2e}")
+    assert e <= 6e-3       # bf16 weights / activations vs fp32 weights: the usual bf16 forward error of one layer
+    rms = outs[torch.bfloat16].reshape(-1, 64).square().mean(dim=-1).sqrt()
+    assert (rms - 1.0).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("T", [(4, 86), (2, 43)])
+def test_attention_prenorm_matches_in_kernel_normalisation(T):
+    """ddx_attn_* with eps < 0 (operands normalised by their producer) against the kernel's own normalisation on the same, already
+    normalised bf16 operands: normalising a unit-RMS vector again only divides by (1 + eps)."""
+    ops = _ops()
+    dev = "cuda"
+    torch.manual_seed(22)
+    B, (H, W), heads, D = 4, T, 4, 64
+    Cn = heads * D
+
+    def nrm(t):
+        t = t.reshape(*t.shape[:-1], -1, D)
+        return (t / (1e-4 + torch.linalg.vector_norm(t, dim=-1, keepdim=True) * D ** -0.5)).reshape(*t.shape[:-2], -1)
+
+    qk = nrm(torch.randn(B, H, W, 2 * Cn, device=dev)).to(torch.bfloat16)
+    v = nrm(torch.randn(B, H, W, Cn, device=dev)).to(torch.bfloat16)
+    cs = torch.rand(B, Cn, device=dev) + 0.5
+    a = ops.attention(qk, v, heads, out_scale=cs).float()
+    b = ops.attention(qk, v, heads, out_scale=cs, prenorm=True).float()
+    torch.cuda.synchronize()
+    e = rel_l2(b, a)
+    print(f"attention prenorm T={H * W}: rel-L2 {e:.2e}")
+    assert e <= 5e-3
+    # ... and it really skips the normalisation: on operands that are NOT unit-RMS it is plain softmax(q k^T / sqrt(D)) v of what it was given
+    qk2, v2 = (qk.float() * 1.5).to(torch.bfloat16), (v.float() * 0.5).to(torch.bfloat16)
+    got = ops.attention(qk2, v2, heads, prenorm=True).float().reshape(B, H * W, heads, D)
+    q_, k_ = qk2.float().reshape(B, H * W, heads, 2, D).unbind(3)
+    v_ = v2.float().reshape(B, H * W, heads, D)
+    ref = torch.nn.functional.scaled_dot_product_attention(q_.transpose(1, 2), k_.transpose(1, 2), v_.transpose(1, 2)).transpose(1, 2)
+    assert rel_l2(got, ref) <= 1e-2
+    assert rel_l2(ops.attention(qk2, v2, heads).float().reshape(B, H * W, heads, D), ref) > 5e-2
