@@ -602,7 +602,9 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
       const size_t smem = std::max(group * ksp, epi);
       if (smem > 160 * 1024) continue;
       const double un = (double)p.Ng / round_up(p.Ng, BN);
-      double eff = (BN == 32 ? 0.80 : 1.0) * (BM == 128 ? 0.92 : 1.0);
+      // (32-channel tiles reuse a staged activation chunk half as often; a 3x3 layer does nine taps of matrix work per chunk, so it costs it
+      // less: the plan-time tuner of round 4 preferred 128 x 32 tiles without split-K by >= 4 % on five level-3 conv_res0 shapes)
+      double eff = (BN == 32 ? (ksize == 3 ? 0.86 : 0.80) : 1.0) * (BM == 128 ? 0.92 : 1.0);
       if (ksp == 1 && smem > 80 * 1024) eff *= 0.85;                    // one workgroup per CU: no phase overlap
       // parallelism: waves in flight relative to what fills the chip (256 CUs x 8 waves)
       const double fill = std::min(1.0, (double)wgs * 4 * ksp / 2048.0);
