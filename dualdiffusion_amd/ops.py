@@ -141,7 +141,7 @@ def _tune_conv(d: "L.ConvDesc") -> int:
 
     t_auto = timed(0)
     best_code, best_t = 0, t_auto
-    for code in [3] + [16 + i for i in range(12)]:
+    for code in [3, 6] + [16 + i for i in range(12)]:
         t = timed(code)
         if t < best_t:
             best_code, best_t = code, t
