@@ -313,6 +313,226 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Key-split kernel for the UNet's attention layers (bf16, head_dim 64, operands normalised by the qkv conv's epilogue, at most 384 tokens).
+//
+// The kernel above walks the keys in chunks that its four waves stage together: at 344 tokens six chunks, each behind a barrier, on a
+// workgroup whose useful work is a few hundred MFMA cycles -- the layer is a chain of latencies (8 us + 2.4 us per chunk).  Here the four
+// waves of a workgroup split the KEYS: wave w owns keys [w * kpw, (w + 1) * kpw) (kpw = ceil(T / 4) <= 96) for ALL the queries of the
+// workgroup's tile (NQT x 32).  Nothing is shared on the way in: the K and Q fragments are 16 contiguous bytes of a token row per lane, so
+// they are loaded from global memory straight into the MFMA operand registers; V needs the key-major -> dim-major transpose and goes
+// through a wave-private LDS region (ds_read_b64_tr_b16), written and read by the same wave, no barrier.  Every global load of the
+// workgroup is issued before the first is consumed.  Each wave ends with an (m, l, O^T) partial of its key range; the partials meet in LDS
+// behind the kernel's ONE barrier (the V region is reused: a wave has finished its P.V before it writes), and wave w' then combines
+// dims [16 w', 16 w' + 16) of every query (flash-decoding's combine) and stores 32 contiguous bytes per lane.
+template <int NKT, int NQT>
+__global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ v, bf16* __restrict__ out,
+                                                      const float* __restrict__ out_cs, int Tn, int heads, int qk_ld, int v_ld, int fold) {
+  constexpr int D = 64, QS = D + 8;
+  constexpr int VREG = NKT * 32 * QS * 2;                     // bytes of a wave's V rows
+  constexpr int OREG = NQT * D * 32 * 4 + NQT * 32 * 8;       // ... of its (O^T, m, l) partial
+  constexpr int REG = VREG > OREG ? VREG : OREG;
+  __shared__ __attribute__((aligned(16))) char smem[4 * REG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int q0 = blockIdx.x * (NQT * 32);
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int b_img = b / fold;
+  const size_t rbase = (size_t)b_img * Tn * fold + (size_t)(b - b_img * fold);
+  const int C = heads * D;
+  const int kpw = (Tn + 3) >> 2;
+  const int k0 = wave * kpw;
+  const int kend = min(Tn, k0 + kpw);          // keys [k0, kend) are this wave's (possibly none)
+  const int last = Tn - 1;
+
+  // ---- every global load of the wave: V rows (8 per instruction), Q and K fragments (row index clamped, the masks come later)
+  bf16x8 vreg[NKT * 4], qf[NQT][4], kf[NKT][4];
+#pragma unroll
+  for (int i = 0; i < NKT * 4; ++i) {
+    const int key = min(k0 + i * 8 + (lane >> 3), last);
+    vreg[i] = *reinterpret_cast<const bf16x8*>(v + (rbase + (size_t)key * fold) * v_ld + head * D + (lane & 7) * 8);
+  }
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) {
+    const bf16* rp = qk + (rbase + (size_t)min(q0 + qt * 32 + l31, last) * fold) * qk_ld + head * 2 * D + khalf * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
+  }
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const bf16* rp = qk + (rbase + (size_t)min(k0 + kt * 32 + l31, last) * fold) * qk_ld + head * 2 * D + D + khalf * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
+  }
+  // (the combine's channel scales travel with them: loaded where they are used they cost sixteen exposed round trips; without
+  // out_scale the loads read the q row instead -- unconditional, so that nothing waits on them here -- and are ignored)
+  f32x4 c4[4];
+  {
+    const float* csp = out_cs ? out_cs + (size_t)b_img * C + head * D + wave * 16
+                              : reinterpret_cast<const float*>(qk + (rbase + (size_t)min(q0, last) * fold) * qk_ld + head * 2 * D);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c4[e] = *reinterpret_cast<const f32x4*>(csp + e * 4);
+  }
+  bf16* sV = reinterpret_cast<bf16*>(smem + wave * REG);
+#pragma unroll
+  for (int i = 0; i < NKT * 4; ++i) *reinterpret_cast<bf16x8*>(sV + (i * 8 + (lane >> 3)) * QS + (lane & 7) * 8) = vreg[i];
+
+  // ---- per query tile: S^T = K . Q^T, softmax over the wave's keys (base 2, the 1 / sqrt(D) inside the exponent), P as bf16 fragments
+  constexpr float kSc = 0.125f * 1.4426950408889634f;
+  bf16x8 pf[NQT][NKT][2];
+  float m_w[NQT], l_w[NQT];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) {
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], s[kt], 0, 0, 0);
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (key >= kend) s[kt][r] = -1e30f;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const float pv = exp2f((s[kt][8 * j + kk] - mx) * kSc);
+          psum += pv;
+          pf[qt][kt][j][kk] = (bf16)pv;
+        }
+    psum += __shfl_xor(psum, 32, 64);
+    m_w[qt] = mx;
+    l_w[qt] = k0 < kend ? psum : 0.f;         // (a wave without keys: its exponentials are exp2(0) -- weight 0 in the combine)
+  }
+
+  // ---- O^T = V^T . P^T over the wave's keys (the transpose read of the kernel above, on the wave's own rows)
+  f32x16 oacc[NQT][2];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qt][dt][r] = 0.f;
+  {
+    const int gq = lane >> 4, li = lane & 15;
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kb = kt * 32 + 16 * j + 4 * (gq >> 1) + (li >> 2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16* vp = sV + kb * QS + dt * 32 + (gq & 1) * 16 + (li & 3) * 4;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp + 8 * QS));
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) oacc[qt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][kt][j], oacc[qt][dt], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- the wave's partial into its region: O^T as [qt][dim][query] fp32 (consecutive lanes = consecutive queries), then (m, l) per query
+  float* sO = reinterpret_cast<float*>(smem + wave * REG);
+  float* sML = sO + NQT * D * 32;
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sO[(qt * D + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * 32 + l31] = oacc[qt][dt][r];
+    if (khalf == 0) {
+      sML[qt * 64 + l31] = m_w[qt];
+      sML[qt * 64 + 32 + l31] = l_w[qt];
+    }
+  }
+  __syncthreads();
+
+  // ---- combine: wave w' takes dims [16 w', 16 w' + 16) of query (lane) of tile qt (lanes beyond NQT * 32 queries idle)
+  const int cq = lane & 31, cqt = lane >> 5;
+  if (cqt < NQT) {
+    float mw[4], lw[4], m = -1e30f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* ml = reinterpret_cast<const float*>(smem + w * REG) + NQT * D * 32 + cqt * 64;
+      mw[w] = ml[cq]; lw[w] = ml[32 + cq];
+      if (lw[w] > 0.f) m = fmaxf(m, mw[w]);
+    }
+    float lt = 0.f, aw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      aw[w] = lw[w] > 0.f ? exp2f((mw[w] - m) * kSc) : 0.f;
+      lt += lw[w] * aw[w];
+    }
+    const float inv_l = 1.0f / lt;
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* po = reinterpret_cast<const float*>(smem + w * REG) + (cqt * D + wave * 16) * 32 + cq;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] += po[e * 32] * aw[w];
+    }
+    const int q = q0 + cqt * 32 + cq;
+    if (q < Tn) {
+      bf16* orow = out + (rbase + (size_t)q * fold) * C + head * D + wave * 16;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float val = o[h * 8 + e] * inv_l;
+          ov[e] = (bf16)(out_cs ? mp_silu_f(val * c4[h * 2 + (e >> 2)][e & 3]) : val);
+        }
+        *reinterpret_cast<bf16x8*>(orow + h * 8) = ov;
+      }
+    }
+  }
+}
+
+template <int NKT, int NQT>
+static int launch_attn_ks(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, hipStream_t s, int qk_ld, int v_ld,
+                          int fold) {
+  dim3 grid((Tn + NQT * 32 - 1) / (NQT * 32), heads, B);
+  hipLaunchKernelGGL((attn_ks_kernel<NKT, NQT>), grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)v, (bf16*)out, cs, Tn, heads, qk_ld, v_ld, fold);
+  return check_launch("attn_ks");
+}
+
+// bf16, head_dim 64, pre-normalised operands, at most 4 x 96 keys: the key-split kernel (64-query tiles where that still fills the part).
+// Measured (B = 4, 16 / 20 heads, graph of back-to-back launches, chunked -> key-split): 86 tokens 7.7 -> 4.8 us, 128: 8.3 -> 4.9, 256: 11.4 ->
+// 9.5, 344: 14.9 -> 14.5, 384: 15.3 -> 15.1; B = 8 at 344 tokens 20.9 -> 21.9 (it moves 128 KB per 64 queries through the CU's load path where
+// the chunked kernel moves 104 KB per 128: the K / Q fragment loads touch 32 lines per instruction, 3.1 of the 14.5 us) -- three key tiles
+// per wave on more than 512 workgroups stay on the chunked kernel.  In the B = 4 step: attention family 0.247 -> 0.199 ms, step 4.488 -> 4.436.
+static bool attn_ks_applies(int B, int Tn, int heads, int head_dim, float eps, int dtype) {
+  if (!(dtype == DDX_BF16 && head_dim == 64 && eps < 0.f && Tn >= 4 && (Tn + 3) / 4 <= 96)) return false;
+  return (Tn + 3) / 4 <= 64 || (long)((Tn + 63) / 64) * heads * B <= 512;
+}
+
+static int launch_attn_keysplit(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, hipStream_t s, int qk_ld,
+                                int v_ld, int fold) {
+  const int nkt = ((Tn + 3) / 4 + 31) / 32;
+  const bool two = (long)((Tn + 63) / 64) * heads * B >= 320;
+  if (nkt == 1) return two ? launch_attn_ks<1, 2>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<1, 1>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+  if (nkt == 2) return two ? launch_attn_ks<2, 2>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<2, 1>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+  return two ? launch_attn_ks<3, 2>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<3, 1>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+}
+
 template <typename T, int D, int KC>
 static int launch_attn_kc(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, float eps, hipStream_t s, int qk_ld,
                           int v_ld, int fold) {
@@ -376,6 +596,9 @@ extern "C" int ddx_attn_fold_fwd(const void* qk, int32_t qk_ld, const void* v, i
   const int ev = dtype == DDX_BF16 ? 8 : 4;
   if (qk_ld < 2 * heads * head_dim || v_ld < heads * head_dim || qk_ld % ev || v_ld % ev) return set_error(DDX_ERR_ARG, "attn: bad row strides");
   return dispatch([=](hipStream_t s) -> int {
+    static const int ablate = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;    // bit 32: the chunked kernel for these layers too (timing A/B)
+    if (attn_ks_applies(B, T, heads, head_dim, eps, dtype) && !(ablate & 32))
+      return launch_attn_keysplit(qk, v, out, out_scale, B, T, heads, s, qk_ld, v_ld, fold);
     if (dtype == DDX_BF16) {
       if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
       if (head_dim == 64) return launch_attn<bf16, 64>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);

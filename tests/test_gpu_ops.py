@@ -1194,14 +1194,17 @@ def test_conv_head_norm_epilogue(case):
     assert (rms - 1.0).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("T", [(4, 86), (2, 43)])
-def test_attention_prenorm_matches_in_kernel_normalisation(T):
+@pytest.mark.parametrize("T,heads", [((4, 86), 16), ((4, 86), 4), ((2, 43), 20), ((2, 43), 4), ((1, 5), 4), ((3, 128), 16), ((1, 100), 4), ((1, 200), 16),
+                                     ((5, 77), 4)])
+def test_attention_prenorm_matches_in_kernel_normalisation(T, heads):
     """ddx_attn_* with eps < 0 (operands normalised by their producer) against the kernel's own normalisation on the same, already
-    normalised bf16 operands: normalising a unit-RMS vector again only divides by (1 + eps)."""
+    normalised bf16 operands: normalising a unit-RMS vector again only divides by (1 + eps).  With head_dim 64 and at most 384 tokens the
+    pre-normalised call runs the KEY-SPLIT kernel (one, two or three key tiles per wave; 32- or 64-query tiles by grid size; (1, 5): a wave
+    without keys; (5, 77) = 385 tokens: the chunked kernel again), the other call the chunked kernel: two kernels, one result."""
     ops = _ops()
     dev = "cuda"
     torch.manual_seed(22)
-    B, (H, W), heads, D = 4, T, 4, 64
+    B, (H, W), D = 4, T, 64
     Cn = heads * D
 
     def nrm(t):

@@ -9,6 +9,7 @@ from dualdiffusion_amd import _lib as L  # noqa: E402
 from dualdiffusion_amd import ops  # noqa: E402
 
 dt = torch.bfloat16
+pre = os.environ.get("ATTN_PRENORM", "1") != "0"      # operands normalised by their producer (the UNet path): the key-split kernel up to 384 tokens
 for (B, H, W, heads) in ([(4, 4, 86, 16)] if os.environ.get("ATTN_ONE") else [(4, 4, 86, 16), (4, 4, 64, 16), (4, 4, 32, 16), (4, 4, 96, 16), (4, 2, 43, 20), (4, 4, 86, 20), (8, 4, 86, 16)]):
     C = heads * 64
     qkv = torch.randn(B, H, W, 3 * C, device="cuda").to(dt)
@@ -16,12 +17,12 @@ for (B, H, W, heads) in ([(4, 4, 86, 16)] if os.environ.get("ATTN_ONE") else [(4
     cs = torch.rand(B, C, device="cuda") + 0.5
     out = torch.empty(B, H, W, C, device="cuda", dtype=dt)
     for _ in range(3):
-        ops.attention(qk, v, heads, out=out, out_scale=cs)
+        ops.attention(qk, v, heads, out=out, out_scale=cs, prenorm=pre)
     torch.cuda.synchronize()
     plan = L.Plan()
     with plan.record():
         for _ in range(40):
-            ops.attention(qk, v, heads, out=out, out_scale=cs)
+            ops.attention(qk, v, heads, out=out, out_scale=cs, prenorm=pre)
     cap = torch.cuda.Stream()
     plan.graph_build(cap.cuda_stream)
     cap.synchronize()
