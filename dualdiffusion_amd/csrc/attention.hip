@@ -26,6 +26,24 @@ template <> struct AttnMma<float> {
   using Frag = float;
 };
 
+// XCD-aware tile order.  Workgroup L of a 1-D grid runs on XCD L % 8, each with its own 4 MB L2; the query tiles of one (batch entry, head)
+// read the same K / V rows.  With the plain (tile, head, batch) grid those tiles land on different XCDs, every XCD touches every head
+// (8.4 MB of q | k | v at level 3: more than its L2) and K / V come out of the Infinity Cache once per TILE.  Here XCD x takes the
+// (batch, head) pairs p = x (mod 8) and runs their nq tiles back to back (needs heads * B to be a multiple of 8).
+__device__ __forceinline__ void xcd_tile(int nq, int heads, int& qtile, int& head, int& b) {
+  const int L = blockIdx.x, slot = L >> 3;
+  const int pair = (slot / nq) * 8 + (L & 7);
+  qtile = slot % nq;
+  head = pair % heads;
+  b = pair / heads;
+}
+
+// DDX_ABLATE (timing A/B; results stay right): 32 the chunked kernel where the key-split one would run, 64 the plain (tile, head, batch) grid
+static int ablate_bits() {
+  static const int bits = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;
+  return bits;
+}
+
 // Sum over aligned groups of N consecutive lanes (N = 16-byte vectors per token row), every lane gets the total.  DPP moves inside a
 // 16-lane row (quad permutes, row_half_mirror, row_mirror: pure VALU, a few cycles) instead of a chain of ds_bpermute round trips;
 // the staging of a key chunk runs two such reductions per token row.
@@ -42,7 +60,7 @@ __device__ __forceinline__ float group_sum(float v) {
 template <typename T, int D, int KC_>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v, T* __restrict__ out,
                                                        const float* __restrict__ out_cs, int B, int Tn, int heads, float eps, int qk_ld, int v_ld,
-                                                       int fold) {
+                                                       int fold, int nq_xcd) {
   constexpr int EV = 16 / (int)sizeof(T);
   constexpr int VPR = D / EV;           // 16-byte vectors per token row
   constexpr int RPP = 256 / VPR;        // rows staged per pass
@@ -62,8 +80,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int q0 = blockIdx.x * 128;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int qtile = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if (nq_xcd) xcd_tile(nq_xcd, heads, qtile, head, b);
+  const int q0 = qtile * 128;
   // token t of batch entry b lives in row rbase + t * fold of the [rows][channels] tensors.  fold = 1: the H*W tokens of image b
   // (rbase = b * T); fold = W > 1: AXIS-FOLDED attention -- the batch entries are the (image, column) pairs of [N][H][W] maps and
   // the tokens run along H (reference modules/daes/dae_edm2_g1.py:209-228: attention over h for every (b, z, w)).
@@ -327,7 +346,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 // dims [16 w', 16 w' + 16) of every query (flash-decoding's combine) and stores 32 contiguous bytes per lane.
 template <int NKT, int NQT>
 __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ v, bf16* __restrict__ out,
-                                                      const float* __restrict__ out_cs, int Tn, int heads, int qk_ld, int v_ld, int fold) {
+                                                      const float* __restrict__ out_cs, int Tn, int heads, int qk_ld, int v_ld, int fold,
+                                                      int nq_xcd) {
   constexpr int D = 64, QS = D + 8;
   constexpr int VREG = NKT * 32 * QS * 2;                     // bytes of a wave's V rows
   constexpr int OREG = NQT * D * 32 * 4 + NQT * 32 * 8;       // ... of its (O^T, m, l) partial
@@ -336,8 +356,9 @@ __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ q
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int q0 = blockIdx.x * (NQT * 32);
-  const int head = blockIdx.y, b = blockIdx.z;
+  int qtile = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  if (nq_xcd) xcd_tile(nq_xcd, heads, qtile, head, b);
+  const int q0 = qtile * (NQT * 32);
   const int b_img = b / fold;
   const size_t rbase = (size_t)b_img * Tn * fold + (size_t)(b - b_img * fold);
   const int C = heads * D;
@@ -509,8 +530,11 @@ __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ q
 template <int NKT, int NQT>
 static int launch_attn_ks(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, hipStream_t s, int qk_ld, int v_ld,
                           int fold) {
-  dim3 grid((Tn + NQT * 32 - 1) / (NQT * 32), heads, B);
-  hipLaunchKernelGGL((attn_ks_kernel<NKT, NQT>), grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)v, (bf16*)out, cs, Tn, heads, qk_ld, v_ld, fold);
+  const int nq = (Tn + NQT * 32 - 1) / (NQT * 32);
+  const bool xcd = (heads * (long)B) % 8 == 0 && !(ablate_bits() & 64);
+  dim3 grid = xcd ? dim3((unsigned)(nq * heads * B)) : dim3(nq, heads, B);
+  hipLaunchKernelGGL((attn_ks_kernel<NKT, NQT>), grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)v, (bf16*)out, cs, Tn, heads, qk_ld, v_ld, fold,
+                     xcd ? nq : 0);
   return check_launch("attn_ks");
 }
 
@@ -547,8 +571,10 @@ static int launch_attn_kc(const void* qk, const void* v, void* out, const float*
       return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(attn)");
     attr_done = true;
   }
-  dim3 grid((Tn + 127) / 128, heads, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps, qk_ld, v_ld, fold);
+  const int nq = (Tn + 127) / 128;
+  const bool xcd = nq > 1 && (heads * (long)B) % 8 == 0 && (long)nq * heads * B <= 0x7fffffff && !(ablate_bits() & 64);
+  dim3 grid = xcd ? dim3((unsigned)(nq * heads * B)) : dim3(nq, heads, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const T*)qk, (const T*)v, (T*)out, cs, B, Tn, heads, eps, qk_ld, v_ld, fold, xcd ? nq : 0);
   return check_launch("attn_fwd");
 }
 
@@ -596,8 +622,7 @@ extern "C" int ddx_attn_fold_fwd(const void* qk, int32_t qk_ld, const void* v, i
   const int ev = dtype == DDX_BF16 ? 8 : 4;
   if (qk_ld < 2 * heads * head_dim || v_ld < heads * head_dim || qk_ld % ev || v_ld % ev) return set_error(DDX_ERR_ARG, "attn: bad row strides");
   return dispatch([=](hipStream_t s) -> int {
-    static const int ablate = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;    // bit 32: the chunked kernel for these layers too (timing A/B)
-    if (attn_ks_applies(B, T, heads, head_dim, eps, dtype) && !(ablate & 32))
+    if (attn_ks_applies(B, T, heads, head_dim, eps, dtype) && !(ablate_bits() & 32))
       return launch_attn_keysplit(qk, v, out, out_scale, B, T, heads, s, qk_ld, v_ld, fold);
     if (dtype == DDX_BF16) {
       if (head_dim == 32) return launch_attn<bf16, 32>(qk, v, out, out_scale, B, T, heads, eps, s, qk_ld, v_ld, fold);
