@@ -11,6 +11,8 @@
 //     made real by Hermitian symmetrisation so that the two channels again share one inverse FFT,
 //   * the windowed gradient is scattered back with float atomics through the adjoint of the reflect padding.
 // HBM traffic: the two input images (L2/MALL resident, re-read by the overlapping blocks) + the gradient image.
+#include <cstdlib>
+
 #include "fft_lds.hpp"
 
 namespace ddx {
@@ -234,6 +236,255 @@ __global__ __launch_bounds__(kMssNT, 8) void mss_loss_kernel(const MssParams p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same pass with every 1-D transform done by ONE thread in registers.
+//
+// The kernel above spreads each radix-4 stage of a block over 1024 threads: one butterfly per thread between two barriers, 24 barriers
+// per 2-D transform, three transforms per block -- the block is a chain of barrier latencies (5.7 ms per call at width 64 for 20 GFLOP).
+// Here a thread reads a whole line (row, then column) of W points from LDS into registers, runs the W-point transform there (radix-2
+// decimation in frequency, fully unrolled, twiddles as literals, bit reversal folded into the store indices) and writes the line back
+// over itself: a 2-D transform is two LDS round trips and two barriers.  128 threads per workgroup (width 64: one wave per array in the
+// forward passes), rows padded to W + 1 entries (lane = row reads would otherwise all hit one bank), 2 x 33-37 KB of LDS.
+// Everything around the transforms (windowed load, left / right un-mixing, loss terms, Hermitian packing, windowed scatter) is the
+// arithmetic of the kernel above on the padded layout.
+constexpr int kRegNT = 256;
+__device__ __constant__ const float kCos64[32] = {1.0000000000e+00f, 9.9518472667e-01f, 9.8078528040e-01f, 9.5694033573e-01f, 9.2387953251e-01f, 8.8192126435e-01f, 8.3146961230e-01f, 7.7301045336e-01f, 7.0710678119e-01f, 6.3439328416e-01f, 5.5557023302e-01f, 4.7139673683e-01f, 3.8268343237e-01f, 2.9028467725e-01f, 1.9509032202e-01f, 9.8017140330e-02f, 6.1232339957e-17f, -9.8017140330e-02f, -1.9509032202e-01f, -2.9028467725e-01f, -3.8268343237e-01f, -4.7139673683e-01f, -5.5557023302e-01f, -6.3439328416e-01f, -7.0710678119e-01f, -7.7301045336e-01f, -8.3146961230e-01f, -8.8192126435e-01f, -9.2387953251e-01f, -9.5694033573e-01f, -9.8078528040e-01f, -9.9518472667e-01f};
+__device__ __constant__ const float kSin64[32] = {0.0000000000e+00f, 9.8017140330e-02f, 1.9509032202e-01f, 2.9028467725e-01f, 3.8268343237e-01f, 4.7139673683e-01f, 5.5557023302e-01f, 6.3439328416e-01f, 7.0710678119e-01f, 7.7301045336e-01f, 8.3146961230e-01f, 8.8192126435e-01f, 9.2387953251e-01f, 9.5694033573e-01f, 9.8078528040e-01f, 9.9518472667e-01f, 1.0000000000e+00f, 9.9518472667e-01f, 9.8078528040e-01f, 9.5694033573e-01f, 9.2387953251e-01f, 8.8192126435e-01f, 8.3146961230e-01f, 7.7301045336e-01f, 7.0710678119e-01f, 6.3439328416e-01f, 5.5557023302e-01f, 4.7139673683e-01f, 3.8268343237e-01f, 2.9028467725e-01f, 1.9509032202e-01f, 9.8017140330e-02f};
+
+template <int N, int LEN, bool INV> struct RegFftStage {
+  static __device__ __forceinline__ void run(cf (&a)[N]) {
+    constexpr int HALF = LEN / 2;
+#pragma unroll
+    for (int start = 0; start < N; start += LEN)
+#pragma unroll
+      for (int j = 0; j < HALF; ++j) {
+        const cf u = a[start + j], v = a[start + j + HALF];
+        a[start + j] = cadd(u, v);
+        const cf d = csub(u, v);
+        const int t = j * (64 / LEN);          // W_LEN^j = W_64^t
+        if (t == 0) a[start + j + HALF] = d;
+        else if (t == 16) a[start + j + HALF] = cmul_mi<INV>(d);
+        else a[start + j + HALF] = cmul(d, cf{kCos64[t], INV ? kSin64[t] : -kSin64[t]});
+      }
+    if constexpr (LEN > 2) RegFftStage<N, LEN / 2, INV>::run(a);
+  }
+};
+__host__ __device__ constexpr int bit_reverse(int k, int n) {
+  int r = 0;
+  for (int b = 1; b < n; b <<= 1) { r = (r << 1) | (k & 1); k >>= 1; }
+  return r;
+}
+
+// W-point transforms of every line of `narr` arrays of NBLK blocks [W][W + 1] along rows or columns, in place, a line per thread --
+// or (SPLIT = 2, width 64: 128 lines for 256 threads) a line per lane PAIR (l, l + 32) of one wave: both lanes read the whole line, lane
+// half h keeps x[j] + x[j + 32] (h = 0) or (x[j] - x[j + 32]) W^j (h = 1) -- the first radix-2 stage --, runs the 32-point transform and
+// writes bins 2 m + h.  Every read of the wave precedes its writes, so the pair needs no barrier; 0.63 x the instructions per thread
+// on twice the threads and half the registers.
+template <int W, bool INV, bool ROWS, int SPLIT>
+__device__ __forceinline__ void mss_reg_lines(cf* __restrict__ x0, cf* __restrict__ x1, int narr) {
+  constexpr int P = W + 1, BSZ = W * P, LINES = kMssPts / W, ES = ROWS ? 1 : P;
+  constexpr int N = W / SPLIT;
+  for (int t = threadIdx.x; t < narr * LINES * SPLIT; t += kRegNT) {      // (LINES is a multiple of 64: a wave works on one array)
+    const int ln = SPLIT == 1 ? t : (t >> 6) * 32 + (t & 31);
+    const int h = SPLIT == 1 ? 0 : (t >> 5) & 1;
+    cf* x = ln >= LINES ? x1 : x0;
+    const int line = ln >= LINES ? ln - LINES : ln;
+    const int blk = line / W, i = line - blk * W;
+    cf* base = x + blk * BSZ + (ROWS ? i * P : i);
+    cf a[N];
+    if constexpr (SPLIT == 1) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) a[k] = base[k * ES];
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const cf u = base[j * ES], v = base[(j + N) * ES];
+        const cf sum = cadd(u, v);
+        cf d = csub(u, v);
+        const int tw = j * (64 / W);
+        if (tw == 16) d = cmul_mi<INV>(d);
+        else if (tw != 0) d = cmul(d, cf{kCos64[tw], INV ? kSin64[tw] : -kSin64[tw]});
+        a[j] = h ? d : sum;
+      }
+    }
+    RegFftStage<N, N, INV>::run(a);
+#pragma unroll
+    for (int k = 0; k < N; ++k) base[(SPLIT * k + h) * ES] = a[bit_reverse(k, N)];
+  }
+  __syncthreads();
+}
+
+template <int W>
+__global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p) {
+  constexpr int NBLK = kMssPts / (W * W);
+  constexpr int P = W + 1, BSZ = W * P, ASZ = NBLK * BSZ;
+  constexpr int HB = W / 2 + 1;
+  constexpr int NHALF = NBLK * W * HB;
+  constexpr int NITEM = (NHALF + kRegNT - 1) / kRegNT;
+  constexpr int NPT = kMssPts / kRegNT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* A = reinterpret_cast<cf*>(smem);
+  cf* Bt = A + ASZ;
+  __shared__ float red[kRegNT / 64];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, by = blockIdx.y, bx0 = blockIdx.x * NBLK;
+  const size_t plane = (size_t)p.H * p.Wd;
+  const float* sL = p.sample + (size_t)b * 2 * plane; const float* sR = sL + plane;
+  const float* tL = p.target + (size_t)b * 2 * plane; const float* tR = tL + plane;
+
+  // ---- load: windowed, reflect-padded blocks; z = left + i*right
+#pragma unroll
+  for (int it = 0; it < NPT; ++it) {
+    const int idx = tid + it * kRegNT;
+    const int blk = idx / (W * W), r = (idx / W) % W, c = idx % W;
+    const int bx = bx0 + blk;
+    cf zs{0.f, 0.f}, zt{0.f, 0.f};
+    if (bx < p.nbw) {
+      const int gy = reflect_pad_index(by * p.step - W / 2 + r, p.H);
+      const int gx = reflect_pad_index(bx * p.step - W / 2 + c, p.Wd);
+      const float w = p.window[r * W + c];
+      const size_t o = (size_t)gy * p.Wd + gx;
+      zs = cf{sL[o] * w, sR[o] * w};
+      zt = cf{tL[o] * w, tR[o] * w};
+    }
+    A[blk * BSZ + r * P + c] = zs;
+    Bt[blk * BSZ + r * P + c] = zt;
+  }
+  __syncthreads();
+  constexpr int SPLIT = W == 64 ? 2 : 1;
+  mss_reg_lines<W, false, true, SPLIT>(A, Bt, 2);
+  mss_reg_lines<W, false, false, SPLIT>(A, Bt, 2);
+
+  // ---- loss terms and spectral gradient on the half spectrum
+  const float inv_w = 1.0f / (float)W;
+  cf gl[NITEM], gr[NITEM];
+  float lsum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NITEM; ++it) {
+    const int idx = tid + it * kRegNT;
+    gl[it] = cf{0.f, 0.f}; gr[it] = cf{0.f, 0.f};
+    if (idx >= NHALF) continue;
+    const int blk = idx / (W * HB), rem = idx - blk * (W * HB);
+    const int kh = rem / HB, kw = rem - kh * HB;
+    if (bx0 + blk >= p.nbw) continue;
+    const int o = blk * BSZ + kh * P + kw;
+    const int om = blk * BSZ + ((W - kh) % W) * P + ((W - kw) % W);
+    auto unmix = [&](const cf* Z, cf& c0, cf& c1) {
+      const cf z = Z[o], zc = cconj(Z[om]);
+      const cf sum = cadd(z, zc), dif = csub(z, zc);
+      const cf xl{0.5f * inv_w * sum.x, 0.5f * inv_w * sum.y};       // F(left)[k] / w
+      const cf xr{0.5f * inv_w * dif.y, -0.5f * inv_w * dif.x};      // F(right)[k] / w = -i (z - zc) / 2w
+      if (p.midside) { c0 = cadd(xl, xr); c1 = csub(xl, xr); } else { c0 = xl; c1 = xr; }
+    };
+    cf s0, s1, t0, t1;
+    unmix(A, s0, s1);
+    unmix(Bt, t0, t1);
+    const float wgt = p.weight[kh * HB + kw];
+    auto term = [&](cf s, cf t, cf& g) {
+      const float as = sqrtf(s.x * s.x + s.y * s.y), at = sqrtf(t.x * t.x + t.y * t.y);
+      const float d = as - at;
+      lsum += wgt * (p.use_mse ? d * d : fabsf(d));
+      const float gd = p.use_mse ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      const float f = as > 0.f ? p.scale * wgt * gd / as : 0.f;
+      g = cf{f * s.x, f * s.y};
+    };
+    cf g0, g1;
+    term(s0, t0, g0);
+    term(s1, t1, g1);
+    if (p.midside) { gl[it] = cadd(g0, g1); gr[it] = csub(g0, g1); } else { gl[it] = g0; gr[it] = g1; }
+  }
+  lsum = wave_sum(lsum);
+  if ((tid & 63) == 0) red[tid >> 6] = lsum;
+  __syncthreads();  // also: every thread is done reading the spectra
+  if (tid == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRegNT / 64; ++w) tot += red[w];
+    atomicAdd(p.loss + b, tot * p.scale);
+  }
+  if (!p.grad) return;
+
+  // ---- gradient: G on the half spectrum -> Hermitian-symmetric packed spectrum -> inverse transform -> window -> scatter
+#pragma unroll
+  for (int it = 0; it < NITEM; ++it) {
+    const int idx = tid + it * kRegNT;
+    if (idx >= NHALF) continue;
+    const int blk = idx / (W * HB), rem = idx - blk * (W * HB);
+    const int kh = rem / HB, kw = rem - kh * HB;
+    const int o = blk * BSZ + kh * P + kw;
+    A[o] = gl[it];
+    Bt[o] = gr[it];
+  }
+  __syncthreads();
+  cf pks[NPT];
+#pragma unroll
+  for (int it = 0; it < NPT; ++it) {
+    const int idx = tid + it * kRegNT;
+    const int blk = idx / (W * W), kh = (idx / W) % W, kw = idx % W;
+    const int mh = (W - kh) % W, mw = (W - kw) % W;
+    cf pk{0.f, 0.f};
+    if (kw < HB) {  // (G_L + i G_R) / 2
+      const cf a = A[blk * BSZ + kh * P + kw], c = Bt[blk * BSZ + kh * P + kw];
+      pk.x += 0.5f * (a.x - c.y); pk.y += 0.5f * (a.y + c.x);
+    }
+    if (mw < HB) {  // (conj(G_L[-k]) + i conj(G_R[-k])) / 2
+      const int om = blk * BSZ + mh * P + mw;
+      const cf a = A[om], c = Bt[om];
+      pk.x += 0.5f * (a.x + c.y); pk.y += 0.5f * (c.x - a.y);
+    }
+    pks[it] = pk;
+  }
+  __syncthreads();  // every thread has read its G entries: the packed spectrum replaces them in A
+#pragma unroll
+  for (int it = 0; it < NPT; ++it) {
+    const int idx = tid + it * kRegNT;
+    A[(idx / (W * W)) * BSZ + ((idx / W) % W) * P + idx % W] = pks[it];
+  }
+  __syncthreads();
+  mss_reg_lines<W, true, true, SPLIT>(A, nullptr, 1);
+  mss_reg_lines<W, true, false, SPLIT>(A, nullptr, 1);
+  // ---- windowed scatter.  The NBLK blocks of the workgroup are neighbours along x, `step` pixels apart: a pixel column of the strip gets
+  // up to W / step contributions from them.  They are summed here (a gather in the padded coordinate xr = blk * step + c, which the
+  // reflection maps to the image afterwards -- the same pixel the per-block scatter would hit), so the global atomics are one pair per
+  // strip pixel instead of one per block pixel (width 8: 568 pairs instead of 4096).
+  float* gL = p.grad + (size_t)b * 2 * plane; float* gR = gL + plane;
+  const int ncols = (NBLK - 1) * p.step + W;
+  const int gy0 = by * p.step - W / 2, gx0 = bx0 * p.step - W / 2;
+  for (int o = tid; o < W * ncols; o += kRegNT) {
+    const int r = o / ncols, xr = o - r * ncols;
+    int b_hi = min(NBLK - 1, xr / p.step);
+    b_hi = min(b_hi, p.nbw - 1 - bx0);
+    const int b_lo = max(0, (xr - W + p.step) / p.step);
+    cf acc{0.f, 0.f};
+    for (int blk = b_lo; blk <= b_hi; ++blk) {
+      const int c = xr - blk * p.step;
+      const float w = p.window[r * W + c];
+      const cf v = A[blk * BSZ + r * P + c];
+      acc.x += v.x * w; acc.y += v.y * w;
+    }
+    if (b_hi < b_lo) continue;
+    const size_t go = (size_t)reflect_pad_index(gy0 + r, p.H) * p.Wd + reflect_pad_index(gx0 + xr, p.Wd);
+    unsafeAtomicAdd(gL + go, acc.x * inv_w);
+    unsafeAtomicAdd(gR + go, acc.y * inv_w);
+  }
+}
+
+template <int W>
+static int launch_mss_reg(const MssParams& p, hipStream_t s) {
+  constexpr int NBLK = kMssPts / (W * W);
+  const size_t smem = 2 * (size_t)NBLK * W * (W + 1) * sizeof(cf);
+  auto kern = mss_loss_reg_kernel<W>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(mss_loss_reg)");
+    attr_done = true;
+  }
+  dim3 grid(ceil_div(p.nbw, NBLK), p.nbh, p.B);
+  hipLaunchKernelGGL(kern, grid, dim3(kRegNT), smem, s, p);
+  return check_launch("mss_loss_reg");
+}
+
 template <int W>
 static int launch_mss(const MssParams& p, hipStream_t s) {
   constexpr int NBLK = kMssPts / (W * W);
@@ -274,6 +525,15 @@ extern "C" int ddx_mss_loss_scale(const ddx_mss_desc* dp, ddx_stream stream) {
   const double flops = blocks * 3.0 * 2.0 * w * (5.0 * w * log2((double)w));  // three complex 2-D FFTs per block
   const double bytes = (double)p.B * 2 * d.H * d.W * 4 * (d.grad ? 3 : 2);
   return dispatch([p, w](hipStream_t s) -> int {
+    static const int ablate = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;     // bit 256: the barrier-per-stage kernel
+    if (!(ablate & 256)) {
+      switch (w) {
+        case 8: return launch_mss_reg<8>(p, s);
+        case 16: return launch_mss_reg<16>(p, s);
+        case 32: return launch_mss_reg<32>(p, s);
+        default: return launch_mss_reg<64>(p, s);
+      }
+    }
     switch (w) {
       case 8: return launch_mss<8>(p, s);
       case 16: return launch_mss<16>(p, s);
