@@ -187,6 +187,8 @@ PROTOTYPES = {
     "ddx_fgla_ola": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_fgla_analysis": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "ddx_fgla_iter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "ddx_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "ddx_mpconv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "ddx_wgrad_parts": (C.c_int32, [C.POINTER(WgradDesc)]),

@@ -49,7 +49,7 @@ constexpr int kFN = 6400;
 #define DDX_FGLA_NT 512
 #endif
 constexpr int kFNT = DDX_FGLA_NT;
-constexpr int kFMinWaves = kFNT >= 512 ? 8 : 4;   // (__launch_bounds__ second argument = min waves per SIMD: 8 -> <= 64 VGPRs)
+constexpr int kFMinWaves = kFNT >= 512 ? 6 : 4;   // (__launch_bounds__ second argument = min waves per SIMD: three 8-wave workgroups per CU are six per SIMD: <= 80 VGPRs)
 
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][ustride] state, NB valid per row (nullptr: angles = 1)
@@ -218,6 +218,105 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_analysis_kernel(const F
   DDX_FT_END(1);
 }
 
+// analysis of iteration i and synthesis of iteration i + 1 of one frame in ONE workgroup.  Both are per-frame with the same (t, b) grid, and
+// the synthesis of a frame reads nothing but that frame's state row (just written) and magnitudes: fused, the state is read once and written
+// once per iteration instead of read twice (FGLA is HBM-bound: 6.25 GB per iteration at B = 4 -- state 3 x 1.1 GB, frames 2 x 1.1 GB,
+// magnitudes -- at 3.7 TB/s; the fused pass moves 4.7 GB), one launch and one LDS fill less.  The loop over the bin pairs reads Z[k] and
+// Z[N - k] of the forward transform, updates the state, and writes the next iteration's packed spectrum into the same two entries -- the
+// only entries of the buffer this thread touches, so the hand-over needs no barrier.
+struct FglaIterParams {
+  const float* audio; const float* mags; const float* window; const float2* tw;
+  float2* u; float* frames;
+  int B, C, T, L, hop, ustride, mstride;
+  float momentum, t_lerp;
+  int final_pass, stereo_merge;
+};
+
+__global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_iter_kernel(const FglaIterParams p) {
+  constexpr int N = kFN, NB = N / 2 + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cf* bufA = reinterpret_cast<cf*>(smem);
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* aL = p.audio + (size_t)b * p.C * p.L;
+  const float* aR = p.C > 1 ? aL + p.L : nullptr;
+  const int base = t * p.hop - N / 2;
+  for (int n = 4 * tid; n < N; n += 4 * kFNT) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.window + n);
+    const int j0 = base + n;
+    f32x4 l4, r4 = {0.f, 0.f, 0.f, 0.f};
+    if (j0 >= 0 && j0 + 3 < p.L && (p.L & 3) == 0) {   // interior: 16-byte loads (base and n are multiples of 4)
+      l4 = *reinterpret_cast<const f32x4*>(aL + j0);
+      if (aR) r4 = *reinterpret_cast<const f32x4*>(aR + j0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = reflect_idx(j0 + e, p.L);
+        l4[e] = aL[j];
+        if (aR) r4[e] = aR[j];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
+  }
+  fft6400_inplace<false, kFNT>(bufA, p.tw, launder(tid));   // (laundered: else the index arithmetic of the two transforms is shared and kept live across the loop between them)
+  float2* ro = p.u + ((size_t)b * p.T + t) * p.C * p.ustride;
+  for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {
+    f32x4 ul = *reinterpret_cast<const f32x4*>(ro + k0), ur = {0.f, 0.f, 0.f, 0.f};
+    if (p.C > 1) ur = *reinterpret_cast<const f32x4*>(ro + p.ustride + k0);
+    float mg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [channel][bin]
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+      if (ch < p.C) {
+        const float2 m2 = *reinterpret_cast<const float2*>(p.mags + (((size_t)b * p.C + ch) * p.T + t) * p.mstride + k0);
+        mg[ch][0] = fmaxf(m2.x, 0.f); mg[ch][1] = fmaxf(m2.y, 0.f);
+      }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = k0 + e;
+      if (k >= NB) break;    // (the second bin of the last pair is row padding: written back unchanged)
+      // ---- analysis (fgla_analysis_kernel): the state of this bin
+      const cf zk = bufA[k], zn = cconj(bufA[(N - k) % N]);
+      const cf sl = cadd(zk, zn), sr = csub(zk, zn);
+      ul[2 * e] = 0.5f * sl.x - p.momentum * ul[2 * e];
+      ul[2 * e + 1] = 0.5f * sl.y - p.momentum * ul[2 * e + 1];
+      ur[2 * e] = 0.5f * sr.y - p.momentum * ur[2 * e];
+      ur[2 * e + 1] = -0.5f * sr.x - p.momentum * ur[2 * e + 1];
+      // ---- synthesis (fgla_synth_kernel) from the value just formed
+      cf x[2] = {cf{0.f, 0.f}, cf{0.f, 0.f}};
+      const float merged = 0.5f * (mg[0][e] + mg[1][e]);
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        if (ch >= p.C) continue;
+        const float ax = ch ? ur[2 * e] : ul[2 * e], ay = ch ? ur[2 * e + 1] : ul[2 * e + 1];
+        const float inv = 1.0f / (sqrtf(ax * ax + ay * ay) + 1e-16f);
+        float m = mg[ch][e];
+        if (!p.final_pass && p.stereo_merge) m = p.t_lerp > 0.f ? merged + p.t_lerp * (mg[ch][e] - merged) : merged;
+        x[ch] = cf{ax * inv * m, ay * inv * m};
+        if (k == 0 || k == N / 2) x[ch].y = 0.f;
+      }
+      bufA[k] = cf{x[0].x - x[1].y, x[0].y + x[1].x};
+      if (k > 0 && k < N / 2) bufA[N - k] = cf{x[0].x + x[1].y, -x[0].y + x[1].x};
+    }
+    *reinterpret_cast<f32x4*>(ro + k0) = ul;
+    if (p.C > 1) *reinterpret_cast<f32x4*>(ro + p.ustride + k0) = ur;
+  }
+  fft6400_inplace<true, kFNT>(bufA, p.tw, launder(tid));
+  float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
+  const float invn = 1.0f / (float)N;
+  for (int n = 4 * tid; n < N; n += 4 * kFNT) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.window + n);
+    f32x4 l4, r4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const cf z = bufA[n + e];
+      l4[e] = z.x * (w4[e] * invn);
+      r4[e] = z.y * (w4[e] * invn);
+    }
+    *reinterpret_cast<f32x4*>(fr + n) = l4;
+    if (p.C > 1) *reinterpret_cast<f32x4*>(fr + N + n) = r4;
+  }
+}
+
 // mel samples (B, C, n_mel, T) -> linear mel amplitudes laid out [B*C][T][n_mel] for the un-mel GEMM:
 // amp = clip(x / scale + mean, 0) ** (1 / abs_exponent)   (reference spectrogram.py:232,183)
 __global__ __launch_bounds__(256) void mel_to_amp_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int n_mel, int T,
@@ -319,6 +418,24 @@ extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const 
     fgla_trace_report(1, "analysis");
     return check_launch("fgla_analysis");
   }, stream, "fgla_analysis");
+}
+
+extern "C" int ddx_fgla_iter(const float* audio, const float* window, const float* twiddle, float* u, int32_t u_stride, const float* mags,
+                             int32_t mag_stride, float* frames, int32_t B, int32_t C, int32_t T, int32_t L, int32_t n_fft, int32_t hop,
+                             float momentum, float t_lerp, int32_t final_pass, ddx_stream stream) {
+  if (!audio || !window || !twiddle || !u || !mags || !frames || B <= 0 || (C != 1 && C != 2) || T <= 0 || L <= kFN / 2)
+    return set_error(DDX_ERR_ARG, "fgla_iter: bad args");
+  if (n_fft != kFN) return set_error(DDX_ERR_UNSUPPORTED, "fgla_iter: only n_fft = 6400 is built");
+  if (u_stride < kFN / 2 + 2 || (u_stride & 1) || mag_stride < kFN / 2 + 2 || (mag_stride & 1))
+    return set_error(DDX_ERR_ARG, "fgla_iter: row strides must be even and >= n_fft/2 + 2 (two bins per 16-byte access)");
+  FglaIterParams p{audio, mags, window, reinterpret_cast<const float2*>(twiddle), reinterpret_cast<float2*>(u), frames, B, C, T, L, hop,
+                   u_stride, mag_stride, momentum, t_lerp, final_pass, C == 2};
+  return dispatch([p](hipStream_t s) -> int {
+    static bool done = false;
+    if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_iter_kernel), &done)) return rc;
+    hipLaunchKernelGGL(fgla_iter_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
+    return check_launch("fgla_iter");
+  }, stream, "fgla_iter");
 }
 
 extern "C" int ddx_mel_to_amplitude(const float* mel, float* amp, int32_t rows, int32_t n_mel, int32_t T, float scale, float mean,

@@ -191,8 +191,14 @@ class SpectrogramFormat(DualDiffusionFormat):
             check(lib().ddx_fgla_synth(ptr(state), us, ptr(mags), W, TW, ptr(frames), B, Cn, T, N, mstride, t_lerp, int(final), st), "fgla_synth")
             check(lib().ddx_fgla_ola(ptr(frames), W, ptr(audio), B, Cn, T, N, hop, st), "fgla_ola")
 
+        # reference loop: [synth_i, analysis_i] for i < n_iter, then the final synth (waveform = istft(angles * specgram)).  The analysis of
+        # iteration i and the synthesis of iteration i + 1 (the final one after the last) are per-frame passes over the same state row:
+        # ddx_fgla_iter runs them in one launch (the state is read once and written once per iteration; FGLA is HBM-bound)
+        synth(None, -c.stereo_coherence, False)                                     # i == 0: angles = 1 (rand_init False)
         for i in range(n_iter):
-            synth(None if i == 0 else u, i / n_iter - c.stereo_coherence, False)   # i == 0: angles = 1 (rand_init False)
-            check(lib().ddx_fgla_analysis(ptr(audio), W, TW, ptr(u), us, B, Cn, T, Lout, N, hop, momentum, st), "fgla_analysis")
-        synth(u, 0.0, True)                                                         # waveform = istft(angles * specgram)
+            last = i == n_iter - 1
+            t_lerp = 0.0 if last else (i + 1) / n_iter - c.stereo_coherence
+            check(lib().ddx_fgla_iter(ptr(audio), W, TW, ptr(u), us, ptr(mags), mstride, ptr(frames), B, Cn, T, Lout, N, hop, momentum,
+                                      t_lerp, int(last), st), "fgla_iter")
+            check(lib().ddx_fgla_ola(ptr(frames), W, ptr(audio), B, Cn, T, N, hop, st), "fgla_ola")
         return audio

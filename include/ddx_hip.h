@@ -554,6 +554,8 @@ int ddx_ms_mel_spec(const ddx_msmel_desc* d, ddx_stream stream);
  *   fgla_analysis    : u[b][t][c][k] <- rfft(window * reflect_pad(audio) frame t)[k] - momentum * u[b][t][c][k]
  *                      (torch.stft + the in-place `angles.sub_(tprev, alpha=momentum)` whose result the reference keeps
  *                      as tprev, phase_recovery.py:110-119)
+ *   fgla_iter        : fgla_analysis of one iteration followed by fgla_synth of the next, per frame in one launch: same state, same
+ *                      frames as the two calls (u read once and written once; the synthesis uses the value just formed)
  * The state u is frame-major [B][T][C][u_stride] complex64 (re, im pairs; n_fft/2+1 valid bins per row, u_stride even and
  * >= n_fft/2+2 so that two bins move per 16-byte access; mag_stride likewise), zero before the first iteration.
  * ------------------------------------------------------------------------------------------------ */
@@ -566,6 +568,9 @@ int ddx_fgla_ola(const float* frames, const float* window, float* audio, int32_t
                  int32_t hop, ddx_stream stream);
 int ddx_fgla_analysis(const float* audio, const float* window, const float* twiddle, float* u, int32_t u_stride, int32_t B,
                       int32_t C, int32_t T, int32_t L, int32_t n_fft, int32_t hop, float momentum, ddx_stream stream);
+int ddx_fgla_iter(const float* audio, const float* window, const float* twiddle, float* u, int32_t u_stride, const float* mags,
+                  int32_t mag_stride, float* frames, int32_t B, int32_t C, int32_t T, int32_t L, int32_t n_fft, int32_t hop,
+                  float momentum, float t_lerp, int32_t final_pass, ddx_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched bf16 GEMM + row softmax: the pieces of the attention BACKWARD pass (unet_edm2_b4.py:137-148 under autograd;

@@ -84,6 +84,32 @@ def test_fgla_linear_pieces_match_oracle():
     assert e < 2e-5
 
 
+@pytest.mark.parametrize("final,t_lerp", [(0, 0.3), (0, -0.2), (1, 0.0)])
+def test_fgla_iter_equals_analysis_then_synth(final, t_lerp):
+    """ddx_fgla_iter (analysis of one iteration + synthesis of the next, one launch per frame) against the two calls it replaces on the
+    same inputs: the same state and the same frames (same arithmetic in the same order: 1e-6)."""
+    from dualdiffusion_amd._lib import check, current_stream, lib, ptr
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, Cn, T, nb, hop, N = 2, 2, 33, 3201, 256, 6400
+    us, ms, Lout = nb + 1, nb + 3, hop * (T - 1)
+    audio = torch.randn(B, Cn, Lout, device="cuda", generator=g)
+    u0 = torch.randn(B, T, Cn, us, 2, device="cuda", generator=g)
+    mg = torch.randn(B, Cn, T, ms, device="cuda", generator=g)           # (negative entries: the relu of the un-mel is part of the read)
+    st = current_stream()
+    ua, fa = u0.clone(), torch.empty(B, T, Cn, N, device="cuda")
+    check(lib().ddx_fgla_analysis(ptr(audio), ptr(fmt.window), ptr(fmt.twiddle), ptr(ua), us, B, Cn, T, Lout, N, hop, 0.4975, st))
+    check(lib().ddx_fgla_synth(ptr(ua), us, ptr(mg), ptr(fmt.window), ptr(fmt.twiddle), ptr(fa), B, Cn, T, N, ms, t_lerp, final, st))
+    ub, fb = u0.clone(), torch.empty(B, T, Cn, N, device="cuda")
+    check(lib().ddx_fgla_iter(ptr(audio), ptr(fmt.window), ptr(fmt.twiddle), ptr(ub), us, ptr(mg), ms, ptr(fb), B, Cn, T, Lout, N, hop,
+                              0.4975, t_lerp, final, st))
+    torch.cuda.synchronize()
+    assert rel_l2(ub[:, :, :, :nb], ua[:, :, :, :nb]) < 1e-6
+    assert torch.equal(ub[:, :, :, nb:], u0[:, :, :, nb:])               # row padding written back unchanged
+    assert rel_l2(fb, fa) < 1e-6
+
+
 def test_fgla_sample_to_raw_tracks_reference():
     """un-mel (pseudo-inverse GEMM) + 4 FGLA iterations.  The iteration re-normalises near-empty bins to unit phasors, so
     the float32 result is rounding-sensitive: the REFERENCE's own float32 output sits ~8 % (rel-L2) from the float64
