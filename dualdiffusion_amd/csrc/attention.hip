@@ -38,7 +38,8 @@ __device__ __forceinline__ void xcd_tile(int nq, int heads, int& qtile, int& hea
   b = pair / heads;
 }
 
-// DDX_ABLATE (timing A/B; results stay right): 32 the chunked kernel where the key-split one would run, 64 the plain (tile, head, batch) grid
+// DDX_ABLATE (timing A/B; results stay right): 32 the chunked kernel where the key-split one would run, 64 the plain (tile, head, batch) grid,
+// 128 Q / K fragments straight from global memory in every key-split variant
 static int ablate_bits() {
   static const int bits = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;
   return bits;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qk,
 // workgroup is issued before the first is consumed.  Each wave ends with an (m, l, O^T) partial of its key range; the partials meet in LDS
 // behind the kernel's ONE barrier (the V region is reused: a wave has finished its P.V before it writes), and wave w' then combines
 // dims [16 w', 16 w' + 16) of every query (flash-decoding's combine) and stores 32 contiguous bytes per lane.
-template <int NKT, int NQT>
+template <int NKT, int NQT, bool STAGE>
 __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ v, bf16* __restrict__ out,
                                                       const float* __restrict__ out_cs, int Tn, int heads, int qk_ld, int v_ld, int fold,
                                                       int nq_xcd) {
@@ -367,24 +368,37 @@ __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ q
   const int kend = min(Tn, k0 + kpw);          // keys [k0, kend) are this wave's (possibly none)
   const int last = Tn - 1;
 
-  // ---- every global load of the wave: V rows (8 per instruction), Q and K fragments (row index clamped, the masks come later)
+  // ---- every global load of the wave, all issued before the first is used (row index clamped, the masks come later): V rows, the combine's
+  // channel scales and Q / K -- either as MFMA fragments straight from global memory (lane = row, 16 bytes each: an instruction touches 32 cache
+  // lines; cheapest for one key tile) or (STAGE) as whole rows, 8 per instruction like V, that the wave turns into fragments through its own
+  // LDS region before V takes it over: the wave's LDS instructions execute in order, so write -> read -> overwrite needs no barrier.
   bf16x8 vreg[NKT * 4], qf[NQT][4], kf[NKT][4];
+  bf16x8 qreg[STAGE ? NQT * 4 : 1], kreg[STAGE ? NKT * 4 : 1];
 #pragma unroll
   for (int i = 0; i < NKT * 4; ++i) {
     const int key = min(k0 + i * 8 + (lane >> 3), last);
     vreg[i] = *reinterpret_cast<const bf16x8*>(v + (rbase + (size_t)key * fold) * v_ld + head * D + (lane & 7) * 8);
   }
+  if constexpr (STAGE) {
 #pragma unroll
-  for (int qt = 0; qt < NQT; ++qt) {
-    const bf16* rp = qk + (rbase + (size_t)min(q0 + qt * 32 + l31, last) * fold) * qk_ld + head * 2 * D + khalf * 8;
+    for (int i = 0; i < NQT * 4; ++i)
+      qreg[i] = *reinterpret_cast<const bf16x8*>(qk + (rbase + (size_t)min(q0 + i * 8 + (lane >> 3), last) * fold) * qk_ld + head * 2 * D + (lane & 7) * 8);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
-  }
+    for (int i = 0; i < NKT * 4; ++i)
+      kreg[i] = *reinterpret_cast<const bf16x8*>(qk + (rbase + (size_t)min(k0 + i * 8 + (lane >> 3), last) * fold) * qk_ld + head * 2 * D + D + (lane & 7) * 8);
+  } else {
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    const bf16* rp = qk + (rbase + (size_t)min(k0 + kt * 32 + l31, last) * fold) * qk_ld + head * 2 * D + D + khalf * 8;
+    for (int qt = 0; qt < NQT; ++qt) {
+      const bf16* rp = qk + (rbase + (size_t)min(q0 + qt * 32 + l31, last) * fold) * qk_ld + head * 2 * D + khalf * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const bf16* rp = qk + (rbase + (size_t)min(k0 + kt * 32 + l31, last) * fold) * qk_ld + head * 2 * D + D + khalf * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
+    }
   }
   // (the combine's channel scales travel with them: loaded where they are used they cost sixteen exposed round trips; without
   // out_scale the loads read the q row instead -- unconditional, so that nothing waits on them here -- and are ignored)
@@ -396,6 +410,23 @@ __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ q
     for (int e = 0; e < 4; ++e) c4[e] = *reinterpret_cast<const f32x4*>(csp + e * 4);
   }
   bf16* sV = reinterpret_cast<bf16*>(smem + wave * REG);
+  if constexpr (STAGE) {
+    static_assert(NQT <= NKT, "the query rows pass through the region sized for the key rows");
+    bf16* wr = sV + (lane >> 3) * QS + (lane & 7) * 8;
+    const bf16* rd = sV + l31 * QS + khalf * 8;
+#pragma unroll
+    for (int i = 0; i < NQT * 4; ++i) *reinterpret_cast<bf16x8*>(wr + i * 8 * QS) = qreg[i];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(rd + qt * 32 * QS + ks * 16);
+#pragma unroll
+    for (int i = 0; i < NKT * 4; ++i) *reinterpret_cast<bf16x8*>(wr + i * 8 * QS) = kreg[i];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *reinterpret_cast<const bf16x8*>(rd + kt * 32 * QS + ks * 16);
+  }
 #pragma unroll
   for (int i = 0; i < NKT * 4; ++i) *reinterpret_cast<bf16x8*>(sV + (i * 8 + (lane >> 3)) * QS + (lane & 7) * 8) = vreg[i];
 
@@ -527,13 +558,13 @@ __global__ __launch_bounds__(256) void attn_ks_kernel(const bf16* __restrict__ q
   }
 }
 
-template <int NKT, int NQT>
+template <int NKT, int NQT, bool STAGE>
 static int launch_attn_ks(const void* qk, const void* v, void* out, const float* cs, int B, int Tn, int heads, hipStream_t s, int qk_ld, int v_ld,
                           int fold) {
   const int nq = (Tn + NQT * 32 - 1) / (NQT * 32);
   const bool xcd = (heads * (long)B) % 8 == 0 && !(ablate_bits() & 64);
   dim3 grid = xcd ? dim3((unsigned)(nq * heads * B)) : dim3(nq, heads, B);
-  hipLaunchKernelGGL((attn_ks_kernel<NKT, NQT>), grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)v, (bf16*)out, cs, Tn, heads, qk_ld, v_ld, fold,
+  hipLaunchKernelGGL((attn_ks_kernel<NKT, NQT, STAGE>), grid, dim3(256), 0, s, (const bf16*)qk, (const bf16*)v, (bf16*)out, cs, Tn, heads, qk_ld, v_ld, fold,
                      xcd ? nq : 0);
   return check_launch("attn_ks");
 }
@@ -552,9 +583,14 @@ static int launch_attn_keysplit(const void* qk, const void* v, void* out, const 
                                 int v_ld, int fold) {
   const int nkt = ((Tn + 3) / 4 + 31) / 32;
   const bool two = (long)((Tn + 63) / 64) * heads * B >= 320;
-  if (nkt == 1) return two ? launch_attn_ks<1, 2>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<1, 1>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
-  if (nkt == 2) return two ? launch_attn_ks<2, 2>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<2, 1>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
-  return two ? launch_attn_ks<3, 2>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<3, 1>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+  const bool stage = !(ablate_bits() & 128);     // (two or three key tiles per wave: Q / K as whole rows through the LDS region)
+  if (nkt == 1) return two ? launch_attn_ks<1, 2, false>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<1, 1, false>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+  if (nkt == 2) {
+    if (stage) return two ? launch_attn_ks<2, 2, true>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<2, 1, true>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+    return two ? launch_attn_ks<2, 2, false>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<2, 1, false>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+  }
+  if (stage) return two ? launch_attn_ks<3, 2, true>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<3, 1, true>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
+  return two ? launch_attn_ks<3, 2, false>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold) : launch_attn_ks<3, 1, false>(qk, v, out, cs, B, Tn, heads, s, qk_ld, v_ld, fold);
 }
 
 template <typename T, int D, int KC>

@@ -40,16 +40,19 @@ __device__ unsigned long long g_ftrace[kFtMax][6];   // per workgroup: load, fft
 #endif
 
 constexpr int kFN = 6400;
-// Threads per frame.  512 = eight waves = two per SIMD, so the three workgroups that 3 x 51 KB of LDS allow really are resident (six waves per
-// SIMD).  Rounds 1-3 ran 640 threads (ten waves: 6400 / 640 = 10 points per thread, no tail in any stage) and the per-phase trace of round 4
-// (tools/fgla_trace.sh) showed 1.9 workgroups in flight per CU, not 3: ten waves land 3 + 3 + 2 + 2 on the SIMDs and a third workgroup would
-// need a ninth wave slot on one of them.  512 threads: 2.9 in flight, every phase of a frame slower (FFT 24 -> 31 k cycles), the iteration
-// 2.06 -> 1.95 ms at B=4, 8.59 -> 8.21 ms at B=16.  (-DDDX_FGLA_NT=n rebuilds with another count: 384 / 320 / 256 measured 2.19 / 2.22 / 2.28 ms.)
+// Threads per frame: 512 (the 6400-point transform runs as per-thread register transforms, fft_lds.hpp fft6400_reg: 400 / 400 / 256 lines in its
+// three passes) at <= 128 registers: two workgroups per CU.  History: rounds 1-3 ran the staged transform on 640 threads (1.9 workgroups in
+// flight per CU: ten waves land 3 + 3 + 2 + 2 on the SIMDs), round 4 first on 512 threads / 64 registers (2.9 in flight: 2.06 -> 1.95 ms per
+// iteration at B=4) and then with the register transform: 1.65 -> 1.45 ms (256 threads x two lines at three workgroups per CU: 1.73; an
+// 80-register cap spills: 2.4 ms).  (-DDDX_FGLA_NT=n -DDDX_FGLA_MINWAVES=m rebuild with other counts.)
 #ifndef DDX_FGLA_NT
 #define DDX_FGLA_NT 512
 #endif
+#ifndef DDX_FGLA_MINWAVES
+#define DDX_FGLA_MINWAVES 4
+#endif
 constexpr int kFNT = DDX_FGLA_NT;
-constexpr int kFMinWaves = kFNT >= 512 ? 6 : 4;   // (__launch_bounds__ second argument = min waves per SIMD: three 8-wave workgroups per CU are six per SIMD: <= 80 VGPRs)
+constexpr int kFMinWaves = DDX_FGLA_MINWAVES;   // (__launch_bounds__ second argument = min waves per SIMD: 4 -> <= 128 VGPRs)
 
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][ustride] state, NB valid per row (nullptr: angles = 1)
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_synth_kernel(const Fgla
     }
   }
   DDX_FT_LOADED();
-  fft6400_inplace<true, kFNT>(bufA, p.tw, tid);
+  fft6400_reg<true, kFNT>(bufA, p.tw, tid);
   DDX_FT_FFT();
   float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
   const float invn = 1.0f / (float)N;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_analysis_kernel(const F
     for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
   }
   DDX_FT_LOADED();
-  fft6400_inplace<false, kFNT>(bufA, p.tw, tid);
+  fft6400_reg<false, kFNT>(bufA, p.tw, tid);
   DDX_FT_FFT();
   float2* ro = p.u + ((size_t)b * p.T + t) * p.C * p.ustride;
   for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {   // two bins per lane: 16-byte read-modify-write of the state rows
@@ -220,8 +223,9 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_analysis_kernel(const F
 
 // analysis of iteration i and synthesis of iteration i + 1 of one frame in ONE workgroup.  Both are per-frame with the same (t, b) grid, and
 // the synthesis of a frame reads nothing but that frame's state row (just written) and magnitudes: fused, the state is read once and written
-// once per iteration instead of read twice (FGLA is HBM-bound: 6.25 GB per iteration at B = 4 -- state 3 x 1.1 GB, frames 2 x 1.1 GB,
-// magnitudes -- at 3.7 TB/s; the fused pass moves 4.7 GB), one launch and one LDS fill less.  The loop over the bin pairs reads Z[k] and
+// once per iteration instead of read twice (6.25 -> 4.7 GB per iteration at B = 4: state 3 x 1.1 GB -> 2 x, frames 2 x 1.1 GB, magnitudes),
+// one launch and one LDS fill less.  With the staged transform the two forms took the same time (1.65 ms: the transforms bound it); with the
+// register transform 1.62 -> 1.47 ms.  The loop over the bin pairs reads Z[k] and
 // Z[N - k] of the forward transform, updates the state, and writes the next iteration's packed spectrum into the same two entries -- the
 // only entries of the buffer this thread touches, so the hand-over needs no barrier.
 struct FglaIterParams {
@@ -258,18 +262,34 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_iter_kernel(const FglaI
 #pragma unroll
     for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
   }
-  fft6400_inplace<false, kFNT>(bufA, p.tw, launder(tid));   // (laundered: else the index arithmetic of the two transforms is shared and kept live across the loop between them)
+  fft6400_reg<false, kFNT>(bufA, p.tw, tid);
   float2* ro = p.u + ((size_t)b * p.T + t) * p.C * p.ustride;
-  for (int k0 = 2 * tid; k0 < NB; k0 += 2 * kFNT) {
-    f32x4 ul = *reinterpret_cast<const f32x4*>(ro + k0), ur = {0.f, 0.f, 0.f, 0.f};
-    if (p.C > 1) ur = *reinterpret_cast<const f32x4*>(ro + p.ustride + k0);
-    float mg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [channel][bin]
+  // (the state rows and magnitudes of all rounds are requested together: four load -> compute -> store round trips in a row were the longest
+  // phase of the frame once the transforms shrank)
+  constexpr int ITER = (NB + 2 * kFNT - 1) / (2 * kFNT);
+  f32x4 ulv[ITER], urv[ITER];
+  float2 m2v[ITER][2];
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-      if (ch < p.C) {
-        const float2 m2 = *reinterpret_cast<const float2*>(p.mags + (((size_t)b * p.C + ch) * p.T + t) * p.mstride + k0);
-        mg[ch][0] = fmaxf(m2.x, 0.f); mg[ch][1] = fmaxf(m2.y, 0.f);
-      }
+  for (int it = 0; it < ITER; ++it) {
+    const int k0 = 2 * tid + it * 2 * kFNT;
+    const int kc = k0 < NB ? k0 : 0;
+    ulv[it] = *reinterpret_cast<const f32x4*>(ro + kc);
+    urv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.C > 1) urv[it] = *reinterpret_cast<const f32x4*>(ro + p.ustride + kc);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      m2v[it][ch] = float2{0.f, 0.f};
+      if (ch < p.C) m2v[it][ch] = *reinterpret_cast<const float2*>(p.mags + (((size_t)b * p.C + ch) * p.T + t) * p.mstride + kc);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int k0 = 2 * tid + it * 2 * kFNT;
+    if (k0 >= NB) continue;
+    f32x4 ul = ulv[it], ur = urv[it];
+    float mg[2][2];   // [channel][bin]
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) { mg[ch][0] = fmaxf(m2v[it][ch].x, 0.f); mg[ch][1] = fmaxf(m2v[it][ch].y, 0.f); }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int k = k0 + e;
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_iter_kernel(const FglaI
     *reinterpret_cast<f32x4*>(ro + k0) = ul;
     if (p.C > 1) *reinterpret_cast<f32x4*>(ro + p.ustride + k0) = ur;
   }
-  fft6400_inplace<true, kFNT>(bufA, p.tw, launder(tid));
+  fft6400_reg<true, kFNT>(bufA, p.tw, tid);
   float* fr = p.frames + ((size_t)b * p.T + t) * p.C * N;
   const float invn = 1.0f / (float)N;
   for (int n = 4 * tid; n < N; n += 4 * kFNT) {
@@ -385,7 +405,7 @@ extern "C" int ddx_fgla_synth(const float* u, int32_t u_stride, const float* mag
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_synth_kernel), &done)) return rc;
-    hipLaunchKernelGGL(fgla_synth_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
+    hipLaunchKernelGGL(fgla_synth_kernel, dim3(p.T, p.B), dim3(kFNT), kFft6400RegEntries * sizeof(cf), s, p);
     fgla_trace_report(0, "synth");
     return check_launch("fgla_synth");
   }, stream, "fgla_synth");
@@ -414,7 +434,7 @@ extern "C" int ddx_fgla_analysis(const float* audio, const float* window, const 
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_analysis_kernel), &done)) return rc;
-    hipLaunchKernelGGL(fgla_analysis_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
+    hipLaunchKernelGGL(fgla_analysis_kernel, dim3(p.T, p.B), dim3(kFNT), kFft6400RegEntries * sizeof(cf), s, p);
     fgla_trace_report(1, "analysis");
     return check_launch("fgla_analysis");
   }, stream, "fgla_analysis");
@@ -433,7 +453,7 @@ extern "C" int ddx_fgla_iter(const float* audio, const float* window, const floa
   return dispatch([p](hipStream_t s) -> int {
     static bool done = false;
     if (int rc = set_fft_smem(reinterpret_cast<const void*>(fgla_iter_kernel), &done)) return rc;
-    hipLaunchKernelGGL(fgla_iter_kernel, dim3(p.T, p.B), dim3(kFNT), kFN * sizeof(cf), s, p);
+    hipLaunchKernelGGL(fgla_iter_kernel, dim3(p.T, p.B), dim3(kFNT), kFft6400RegEntries * sizeof(cf), s, p);
     return check_launch("fgla_iter");
   }, stream, "fgla_iter");
 }

@@ -20,6 +20,9 @@ from .format import DualDiffusionFormat, DualDiffusionFormatConfig
 from .frequency_scale import FrequencyScale
 
 
+FGLA_FUSED_ITER = True     # analysis_i + synth_{i+1} in one launch per frame (ddx_fgla_iter); tests / tools flip it for the A/B
+
+
 @dataclass
 class SpectrogramFormatConfig(DualDiffusionFormatConfig):
     raw_to_sample_scale: float = 2.247
@@ -194,6 +197,12 @@ class SpectrogramFormat(DualDiffusionFormat):
         # reference loop: [synth_i, analysis_i] for i < n_iter, then the final synth (waveform = istft(angles * specgram)).  The analysis of
         # iteration i and the synthesis of iteration i + 1 (the final one after the last) are per-frame passes over the same state row:
         # ddx_fgla_iter runs them in one launch (the state is read once and written once per iteration; FGLA is HBM-bound)
+        if not FGLA_FUSED_ITER:                                                     # (the reference's loop as three launches per iteration)
+            for i in range(n_iter):
+                synth(None if i == 0 else u, i / n_iter - c.stereo_coherence, False)
+                check(lib().ddx_fgla_analysis(ptr(audio), W, TW, ptr(u), us, B, Cn, T, Lout, N, hop, momentum, st), "fgla_analysis")
+            synth(u, 0.0, True)
+            return audio
         synth(None, -c.stereo_coherence, False)                                     # i == 0: angles = 1 (rand_init False)
         for i in range(n_iter):
             last = i == n_iter - 1

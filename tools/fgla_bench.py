@@ -2,7 +2,10 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dualdiffusion_amd.modules.formats import spectrogram as _sp  # noqa: E402
 from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig  # noqa: E402
+
+_sp.FGLA_FUSED_ITER = os.environ.get("FGLA_FUSED", "1") != "0"      # 0: the three-launch loop (A/B of ddx_fgla_iter)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
