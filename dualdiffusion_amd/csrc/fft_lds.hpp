@@ -272,6 +272,56 @@ __device__ __forceinline__ void fft6400_reg(cf* a, const float2* __restrict__ tw
   __syncthreads();
 }
 
+// 4096 = 16 x 16 x 16 the same way (256 lines per pass, 256 threads or more): n = 256 a + r, k = k1 + 16 k2, r = 16 b + c, k2 = k2a + 16 k2b;
+// I1 = a[r + 257 k1] (odd k1-stride), I2 = a[k1 + 16 c + 272 k2a] (272 = 16 mod 32: the two k2a rows of a half-wave fall on different banks),
+// natural order out.  The buffer needs 4336 entries.
+constexpr int kFft4096RegEntries = 4336;
+template <bool INV, int NT>
+__device__ __forceinline__ void fft4096_reg(cf* a, const float2* __restrict__ tw, int tid) {
+  static_assert(NT >= 256, "one line per thread");
+  __syncthreads();
+  cf x[16];
+  const bool act = tid < 256;
+  if (act) {                                                       // ---- pass 1 (lane = r)
+    const cf w1 = twiddle<INV>(tw, tid);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = a[256 * j + tid];
+    fft_rr_reg<4, INV>(x, kW16c, kW16s);
+    mul_powers16(x, w1);
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[tid + 257 * k] = x[k];
+  }
+  __syncthreads();
+  const int hi = tid >> 4, k1 = tid & 15;
+  if (act) {                                                       // ---- pass 2 (lane = 16 c + k1)
+    const cf w1 = twiddle<INV>(tw, 16 * hi);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x[b] = a[16 * b + hi + 257 * k1];
+    fft_rr_reg<4, INV>(x, kW16c, kW16s);
+    mul_powers16(x, w1);
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k1 + 16 * hi + 272 * k] = x[k];
+  }
+  __syncthreads();
+  if (act) {                                                       // ---- pass 3 (lane = 16 k2a + k1)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = a[k1 + 16 * c + 272 * hi];
+    fft_rr_reg<4, INV>(x, kW16c, kW16s);
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[tid + 256 * k] = x[k];
+  }
+  __syncthreads();
+}
+
 // N = 4096 = 4^6 (the 128 ms frames of MS_MDCT_DualFormat's mel spectrogram, reference formats/ms_mdct_dual.py:110-139)
 template <bool INV, int NT>
 __device__ __forceinline__ void fft4096_inplace(cf* a, const float2* __restrict__ tw, int tid) {

@@ -17,7 +17,7 @@
 namespace ddx {
 
 constexpr int kFPW = 8;      // frames per workgroup
-constexpr int kNT = 1024;
+constexpr int kNT = 512;      // (the transform runs as per-thread register transforms: fft_lds.hpp fft6400_reg; 1024 threads x 64 registers with the staged one)
 
 struct MelStftParams {
   const float* audio; const float* window; const float2* tw;
@@ -35,12 +35,12 @@ __device__ __forceinline__ int reflect_index(int j, int L) {
 }
 
 template <int N>
-__global__ __launch_bounds__(kNT, 8) void mel_stft_kernel(const MelStftParams p) {
+__global__ __launch_bounds__(kNT, 4) void mel_stft_kernel(const MelStftParams p) {
   // LDS: ONE transform buffer (in-place FFT, fft_lds.hpp; the magnitudes later overwrite its first half) + the output
   // staging: 51 + 16 KB, two workgroups per CU overlap each other's load / transform / filter phases
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  float* sOut = reinterpret_cast<float*>(bufA + N);   // [C * n_mel][kFPW]
+  float* sOut = reinterpret_cast<float*>(bufA + kFft6400RegEntries);   // [C * n_mel][kFPW]
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * kFPW;
   const int tid = threadIdx.x;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kNT, 8) void mel_stft_kernel(const MelStftParams p)
 #pragma unroll
       for (int e = 0; e < 4; ++e) bufA[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
     }
-    fft6400_inplace<false, kNT>(bufA, p.tw, tid);
+    fft6400_reg<false, kNT>(bufA, p.tw, tid);
     // ---- magnitudes of both channels: into registers, barrier, then over the (now consumed) spectrum as floats
     float* mag = reinterpret_cast<float*>(bufA);
     constexpr int MI = (N / 2 + 1 + kNT - 1) / kNT;
@@ -133,7 +133,7 @@ extern "C" int ddx_mel_stft(const ddx_melstft_desc* dp, ddx_stream stream) {
                   d.B, d.C, d.L, d.T, d.hop, d.n_mel, d.band_stride, d.exponent, d.mean, d.scale};
   return dispatch([p](hipStream_t s) -> int {
     constexpr int N = 6400;
-    const size_t smem = (size_t)N * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
+    const size_t smem = (size_t)kFft6400RegEntries * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
     if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "mel_stft: too many mel bands for LDS");
     auto kern = mel_stft_kernel<N>;
     static bool attr_done = false;

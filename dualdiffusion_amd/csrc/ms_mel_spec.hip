@@ -12,7 +12,7 @@ namespace ddx {
 namespace {
 
 constexpr int kFPW = 8;
-constexpr int kNT = 1024;
+constexpr int kNT = 512;      // (per-thread register transforms, fft_lds.hpp fft4096_reg; 1024 threads x 64 registers with the staged one)
 constexpr int N = 4096, NB = N / 2 + 1;
 
 struct MsMelParams {
@@ -30,10 +30,10 @@ __device__ __forceinline__ int reflect_index(int j, int L) {
   return j;
 }
 
-__global__ __launch_bounds__(kNT, 8) void ms_mel_spec_kernel(const MsMelParams p) {
+__global__ __launch_bounds__(kNT, 4) void ms_mel_spec_kernel(const MsMelParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* buf = reinterpret_cast<cf*>(smem);
-  float* sOut = reinterpret_cast<float*>(buf + N);   // [C * n_mel][kFPW]
+  float* sOut = reinterpret_cast<float*>(buf + kFft4096RegEntries);   // [C * n_mel][kFPW]
   const int b = blockIdx.y, f0 = blockIdx.x * kFPW;
   const float* aL = p.audio + (size_t)b * p.C * p.L;
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kNT, 8) void ms_mel_spec_kernel(const MsMelParams p
 #pragma unroll
         for (int e = 0; e < 4; ++e) buf[n + e] = cf{l4[e] * w4[e], r4[e] * w4[e]};
       }
-      fft4096_inplace<false, kNT>(buf, p.tw, tid);
+      fft4096_reg<false, kNT>(buf, p.tw, tid);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int k = tid + i * kNT;
@@ -127,7 +127,7 @@ extern "C" int ddx_ms_mel_spec(const ddx_msmel_desc* dp, ddx_stream stream) {
   MsMelParams p{d.audio, d.window_low, d.window_high, reinterpret_cast<const float2*>(d.twiddle), d.bin_scale_low, d.bin_scale_high,
                 d.band_start, d.band_len, d.band_w, d.out, d.B, d.C, d.L, d.T, d.hop, d.n_mel, d.band_stride, d.exponent, d.scale, d.offset};
   return dispatch([p](hipStream_t s) -> int {
-    const size_t smem = (size_t)N * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
+    const size_t smem = (size_t)kFft4096RegEntries * sizeof(cf) + (size_t)p.C * p.n_mel * kFPW * sizeof(float);
     if (smem > 160 * 1024) return set_error(DDX_ERR_UNSUPPORTED, "ms_mel_spec: too many mel bands for LDS");
     static bool attr_done = false;
     if (!attr_done) {
