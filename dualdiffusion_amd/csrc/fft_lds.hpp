@@ -1,10 +1,9 @@
-// Mixed-radix (2, 4, 5) Stockham FFT of one complex sequence held in LDS, executed by a whole workgroup.
-//
-// Used by the mel-STFT and FGLA kernels: n_fft = 6400 = 4^4 * 5^2 (reference formats/old/spectrogram.py:116-128 through
-// torch.stft) does not fit a pure radix-2 scheme.  Decimation-in-frequency Stockham autosort: stage (n, s, r) reads
-//   a_j = x[q + s*(p + m*j)],  m = n/r,  p < m, q < s,  j < r
-// and writes  y[q + s*(r*p + k)] = (sum_j a_j * W_r^{jk}) * W_n^{pk},  ping-ponging between two LDS buffers, one barrier
-// per stage, natural-order output.  Twiddles W_N^t come from a table computed in double on the host (N entries).
+// Complex FFTs of one sequence held in LDS, executed by a whole workgroup: n_fft = 6400 = 16 x 16 x 25 (mel-STFT and FGLA: reference
+// formats/old/spectrogram.py:116-128 through torch.stft) and 4096 = 16 x 16 x 16 (the dual-window mel spectrogram), as three passes of
+// 16- / 25-point transforms that ONE thread runs in registers (radix-4 / radix-5 butterflies below).  Rounds 1-3 ran staged Stockham
+// transforms (a radix-4 / 5 butterfly per thread between two barriers, twelve barriers per frame, strided writes serialising on the LDS
+// banks): 24-31 k cycles per 6400-point frame against 11-12 k here.  Twiddles W_N^t of the inter-pass factors come from
+// a table computed in double on the host (N entries); the inner ones are literals.
 #pragma once
 #include "common.hpp"
 
@@ -63,95 +62,8 @@ template <bool INV> struct Butterfly<5, INV> {
   }
 };
 
-// one Stockham stage over the whole sequence (N points), sub-length n, stride s, radix R: x -> y
-template <int N, int R, bool INV, int NT>
-__device__ __forceinline__ void fft_stage(const cf* __restrict__ x, cf* __restrict__ y, int n, int s, const float2* __restrict__ tw) {
-  const int m = n / R;
-  const int tstep = N / n;  // W_n^{t} = W_N^{t * N/n}
-  for (int idx = threadIdx.x; idx < N / R; idx += NT) {
-    const int p = idx / s, q = idx - p * s;
-    cf a[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) a[j] = x[q + s * (p + m * j)];
-    Butterfly<R, INV>::run(a);
-    y[q + s * (R * p)] = a[0];
-    // (twiddle index p*k*tstep <= (n/R - 1)(R - 1) N/n < N: no reduction modulo N needed)
-#pragma unroll
-    for (int k = 1; k < R; ++k) y[q + s * (R * p + k)] = cmul(a[k], twiddle<INV>(tw, p * k * tstep));
-  }
-}
-
-// Full transform of N = 6400 points (radices 4,4,4,4,5,5).  Input in `a`, result (natural order) in `a`; `b` is scratch.
-// Every thread of the NT-thread workgroup must call it; ends with a barrier.
-template <bool INV, int NT>
-__device__ __forceinline__ void fft6400(cf* a, cf* b, const float2* __restrict__ tw) {
-  constexpr int N = 6400;
-  __syncthreads();
-  fft_stage<N, 4, INV, NT>(a, b, 6400, 1, tw);   __syncthreads();
-  fft_stage<N, 4, INV, NT>(b, a, 1600, 4, tw);   __syncthreads();
-  fft_stage<N, 4, INV, NT>(a, b, 400, 16, tw);   __syncthreads();
-  fft_stage<N, 4, INV, NT>(b, a, 100, 64, tw);   __syncthreads();
-  fft_stage<N, 5, INV, NT>(a, b, 25, 256, tw);   __syncthreads();
-  fft_stage<N, 5, INV, NT>(b, a, 5, 1280, tw);   __syncthreads();
-}
-
-// ---- single-buffer variant: every thread first pulls ALL its butterfly inputs of the stage into registers, barrier, then
-// writes the outputs over the same array.  Two barriers per stage instead of one, but half the LDS (51 KB for 6400 points),
-// so three workgroups fit a CU and the global-memory phases of one frame overlap the transform of another.
-template <int N, int R, bool INV, int NT>
-__device__ __forceinline__ void fft_stage_inplace(cf* __restrict__ x, int n, int s, const float2* __restrict__ tw, int tid) {
-  const int m = n / R;
-  const int tstep = N / n;
-  constexpr int ROUNDS = (N / R + NT - 1) / NT;
-  cf a[ROUNDS][R];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int idx = tid + r * NT;
-    if (idx < N / R) {
-      const int p = idx / s, q = idx - p * s;
-#pragma unroll
-      for (int j = 0; j < R; ++j) a[r][j] = x[q + s * (p + m * j)];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int idx = tid + r * NT;
-    if (idx < N / R) {
-      const int p = idx / s, q = idx - p * s;
-      Butterfly<R, INV>::run(a[r]);
-      x[q + s * (R * p)] = a[r][0];
-      // one table read per butterfly: W^{pk} = (W^p)^k by repeated multiplication (k <= 4: ~3 ulp); the table sits in L2 and
-      // every read is a dependent round trip inside a barrier-separated stage (FGLA 1.87 -> 1.81 ms per iteration)
-      const cf w1 = twiddle<INV>(tw, p * tstep);
-      cf wk = w1;
-#pragma unroll
-      for (int k = 1; k < R; ++k) {
-        x[q + s * (R * p + k)] = cmul(a[r][k], wk);
-        wk = cmul(wk, w1);
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// `tid` = threadIdx.x; kernels that call this inside a loop over frames pass a value laundered through an empty asm so that
-// the compiler does not hoist the (loop-invariant) index arithmetic of all six stages out of that loop and keep it in
-// ~100 registers (which costs the occupancy the single buffer was bought for).
-template <bool INV, int NT>
-__device__ __forceinline__ void fft6400_inplace(cf* a, const float2* __restrict__ tw, int tid) {
-  constexpr int N = 6400;
-  __syncthreads();
-  fft_stage_inplace<N, 4, INV, NT>(a, 6400, 1, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 1600, 4, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 400, 16, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 100, 64, tw, tid);
-  fft_stage_inplace<N, 5, INV, NT>(a, 25, 256, tw, tid);
-  fft_stage_inplace<N, 5, INV, NT>(a, 5, 1280, tw, tid);
-}
 // ---- register variant: 6400 = 16 x 16 x 25 in three passes, every 16- / 25-point transform by ONE thread in registers.
-// The staged transforms above give a thread three butterflies between two barriers, twelve barriers per frame, and their strided writes
-// (q + s (R p + k): stride R between lanes in the first stage) serialise on the LDS banks.  Index split (n = 400 a + r, k = k1 + 16 k2 and again
+// Index split (n = 400 a + r, k = k1 + 16 k2 and again
 // inside the 400-point transforms: r = 25 b + c, k2 = k2a + 16 k2b); every access below has consecutive lanes on consecutive (or odd-stride)
 // entries:
 //   pass 1: 400 lines r (lane = r): 16 points a[400 j + r]; out[k1] * W_6400^(r k1) to I1 = a[r + 401 k1] (the skew by one entry per k1 makes the
@@ -322,18 +234,8 @@ __device__ __forceinline__ void fft4096_reg(cf* a, const float2* __restrict__ tw
   __syncthreads();
 }
 
-// N = 4096 = 4^6 (the 128 ms frames of MS_MDCT_DualFormat's mel spectrogram, reference formats/ms_mdct_dual.py:110-139)
-template <bool INV, int NT>
-__device__ __forceinline__ void fft4096_inplace(cf* a, const float2* __restrict__ tw, int tid) {
-  constexpr int N = 4096;
-  __syncthreads();
-  fft_stage_inplace<N, 4, INV, NT>(a, 4096, 1, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 1024, 4, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 256, 16, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 64, 64, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 16, 256, tw, tid);
-  fft_stage_inplace<N, 4, INV, NT>(a, 4, 1024, tw, tid);
-}
+// (kernels that call these inside a loop over frames pass a thread index laundered through an empty asm so that the compiler does not hoist
+// the loop-invariant index arithmetic out of that loop and keep it in registers)
 __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 
 }  // namespace ddx

@@ -610,7 +610,7 @@ int ddx_softmax_bwd_rows_f32(const void* p, const void* dp, void* ds, int64_t ro
  *   grad    += d(sum_b loss[b]) / d(sample)            (grad NULL: value only)
  *   S, T = rfft2(window * block, ortho) of the reflect-padded (w/2) sample / target, blocks every `step` pixels,
  *   midside 1: channels (L+R, L-R) (`use_midside_transform="stack"`), 0: (L, R).
- * sample, target, grad: [B][2][H][W] fp32; window [w][w]; weight [w][w/2+1]; twiddle [w] = (cos, -sin)(2 pi k / w);
+ * sample, target, grad: [B][2][H][W] fp32; window [w][w]; weight [w][w/2+1]; twiddle [w] = (cos, -sin)(2 pi k / w) (must be a valid buffer; the line transforms carry their factors as literals since round 4);
  * loss [B] fp32.  loss and grad are ACCUMULATED: zero them before the first block width.  w in {8, 16, 32, 64}.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
