@@ -19,7 +19,7 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 # one-off hardware probes quoted in DESIGN.md (run on the GPU box)
-probes: tools/probe/bufload_lds_probe tools/probe/ds_read_tr_probe tools/probe/launch_floor_probe tools/probe/stage_bw_probe tools/probe/grid_barrier_probe tools/probe/store_pattern_probe
+probes: tools/probe/bufload_lds_probe tools/probe/ds_read_tr_probe tools/probe/launch_floor_probe tools/probe/stage_bw_probe tools/probe/grid_barrier_probe tools/probe/store_pattern_probe tools/probe/lds_stride_probe
 tools/probe/%: tools/probe/%.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 
