@@ -88,9 +88,27 @@ def cpu_baseline(unet, fmt_range, max_seconds: float = 25.0) -> dict:
             if time.time() - t_start > max_seconds:
                 break
     t = statistics.median(times)
-    return {"value": 1.0 / (4.0 * t), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    host = host_cpu()
+    return {"value": 1.0 / (4.0 * t), "unit": "steps/s", "cores": torch.get_num_threads(), "host_cores": host["logical"], "host_cpu": host["model"],
+            "kind": "port",
             "sample": f"default UNet fp32 forward at B=1 (489.3 GFLOP) on the CPU oracle, median of {len(times)} timed runs: "
-                      f"{t:.3f} s/sample = {FLOP_PER_SAMPLE / t / 1e9:.0f} GFLOP/s; value = 1/(4*t) (B=4 step equivalent)"}
+                      f"{t:.3f} s/sample = {FLOP_PER_SAMPLE / t / 1e9:.0f} GFLOP/s; value = 1/(4*t) (B=4 step equivalent); "
+                      f"{torch.get_num_threads()} torch threads on a host with {host['logical']} logical CPUs ({host['model']}) -- torch's CPU conv "
+                      "kernels stop scaling beyond ~32 threads"}
+
+
+def host_cpu() -> dict:
+    """Logical CPU count and model string of the box the CPU baseline runs on."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"logical": os.cpu_count() or 1, "model": model}
 
 
 def train_main(a) -> None:

@@ -611,7 +611,7 @@ static Choice choose(const ConvParams& p, int ksize, int dtype) {
       eff *= 0.35 + 0.65 * fill;
       if (ksp > 1 && wgs >= 512) eff *= 0.8;                            // enough workgroups already: plain K loop
       // 3x3 layers do nine taps of matrix work per staged chunk, which hides the next chunk's latency on its own: measured
-      // (DDX_MFMA_FORCE sweep, L3 / L4 shapes) split-K only pays below one workgroup per CU (160 workgroups: 15.7 -> 13.2 us)
+      // (force_direct >= 16 sweep through tools/conv_bench.py, L3 / L4 shapes) split-K only pays below one workgroup per CU (160 workgroups: 15.7 -> 13.2 us)
       // and costs 25-35 % from 320 workgroups up (12.2 -> 16.3, 15.0 -> 20.9 us)
       if (ksize == 3 && ksp > 1 && wgs >= 256) eff *= 0.7;
       const double score = um * un * eff;

@@ -396,12 +396,17 @@ extern "C" int ddx_mpconv_pair_fwd(const ddx_conv_pair_desc* dp, ddx_stream stre
   a.B = d.B; a.H = d.H; a.W = d.W; a.C = d.C; a.G = d.groups;
   a.tiles_h = (d.H + TH - 1) / TH; a.tiles_w = (d.W + TW - 1) / TW;
   a.units = d.B * a.tiles_h * a.tiles_w;
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // (CU count and the ablation bits are read once: this runs on every launch of an eager plan)
+  static const int cus = []() {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  static const int ablate = []() { const char* e = std::getenv("DDX_ABLATE"); return e ? std::atoi(e) : 0; }();
   a.wgs_per_group = std::max(1, std::min(cus / d.groups, a.units));
   const float t = d.res_t, nrm = std::sqrt((1.f - t) * (1.f - t) + t * t);
-  a.dbg = std::getenv("DDX_ABLATE") ? std::atoi(std::getenv("DDX_ABLATE")) : 0;
+  a.dbg = ablate;
   a.res_a = (1.f - t) / nrm; a.res_b = t / nrm; a.clip = d.clip; a.out2_scale = d.out2_scale;
   const int smem = IN_BYTES + 2 * HID_BYTES + d.B * CH * 8;
   const double px = (double)d.B * d.H * d.W;

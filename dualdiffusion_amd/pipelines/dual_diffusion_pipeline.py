@@ -339,6 +339,8 @@ class DualDiffusionPipeline(torch.nn.Module):
         st = cache.get(key)
         if st is not None and st["eng"] is not eng:      # (an id() recycled by a new engine)
             st = None
+        if st is not None:
+            cache[key] = cache.pop(key)                  # LRU: a hit moves the entry to the young end (dicts keep insertion order)
         if st is None:
             st = dict(eng=eng, sample=torch.empty_like(sample), coef=torch.empty(n, 5, dtype=torch.float32, device=dev),
                       sig_table=torch.empty_like(sig_table), stepc=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -366,6 +368,10 @@ class DualDiffusionPipeline(torch.nn.Module):
             plan.graph_build(cap.cuda_stream)
             cap.synchronize()
             st["plan"] = plan
+            # at most STEP_PLAN_CACHE entries (least recently used goes first), each pinning its hipGraph, five sample-sized buffers and -- with
+            # ancestral noise -- a steps x sample fp32 buffer (<= STEP_GRAPH_NOISE_BYTES): the memory bound of the cache is
+            # STEP_PLAN_CACHE x (2 GiB + graph); sweeping cfg_scale or the step count re-records (both are part of the key)
+            cache.pop(key, None)
             while len(cache) >= self.STEP_PLAN_CACHE:
                 cache.pop(next(iter(cache)))
             cache[key] = st

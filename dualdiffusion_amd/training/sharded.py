@@ -27,6 +27,7 @@ from .optimizer import OptimizerConfig
 
 ALIGN = 64          # shard boundaries are multiples of 64 elements (16-byte accesses, whole 256-byte runs)
 ROW = 2048          # job granularity of the HIP pass: one wave per 2048-element run
+SQ_JOB = 1 << 20    # elements per job of the gradient-norm launch
 
 
 class _Dist:
@@ -97,12 +98,16 @@ class ShardedAdamW:
             self.ema_flat.append(ef)
         # ---- this rank's shard of every segment, and the replicated tails
         W, r = self.d.world, self.d.rank
-        self.shards, self.tails = [], []           # (segment start, shard length, lo, hi) / (lo, hi)
+        self.shards, self.tails = [], []           # (sharded start, shard length, lo, hi) / [(lo, hi), ...] replicated ranges of the segment
         for s, n in segments:
-            S = n // (W * ALIGN) * ALIGN
-            self.shards.append((s, S, s + r * S, s + (r + 1) * S))
-            self.tails.append((s + W * S, s + n))
-        self.own = [(lo, hi) for (_s, S, lo, hi) in self.shards if S > 0] + [(lo, hi) for lo, hi in self.tails if hi > lo]
+            # shard boundaries are multiples of ALIGN elements of the BUCKET (not of the segment): a segment that starts off the grid (the
+            # decoder's parameter count need not be a multiple of 4) would otherwise push every job of the HIP pass onto its unaligned
+            # scalar path.  The head up to the grid and what does not divide by world * ALIGN are all-reduced and updated by every rank.
+            a0 = min((s + ALIGN - 1) // ALIGN * ALIGN, s + n)
+            S = (s + n - a0) // (W * ALIGN) * ALIGN
+            self.shards.append((a0, S, a0 + r * S, a0 + (r + 1) * S))
+            self.tails.append([(lo, hi) for lo, hi in ((s, a0), (a0 + W * S, s + n)) if hi > lo])
+        self.own = [(lo, hi) for (_s, S, lo, hi) in self.shards if S > 0] + [t for ts in self.tails for t in ts]
         n_own = sum(hi - lo for lo, hi in self.own)
         self.g_own = torch.zeros(n_own, dtype=torch.float32, device=dev)       # reduced gradients of the owned ranges, packed
         self.m = torch.zeros(n_own, dtype=torch.float32, device=dev)
@@ -116,6 +121,7 @@ class ShardedAdamW:
         self.grad_norm_logvar = self.grad_norm_logmean
         self._ws = torch.zeros(3, dtype=torch.float32, device=dev)
         self._pending = []
+        self.emas_complete = True      # False between a step() at world > 1 and the next gather_emas(): only this rank's shard is current
         if self.use_hip:
             self._build_tables()
 
@@ -144,8 +150,7 @@ class ShardedAdamW:
         if S > 0:
             k = self.own.index((lo, hi))
             works.append(self.d.reduce_scatter(self.g_own[self.own_off[k]:self.own_off[k] + S], bucket[s:s + W * S], async_op))
-        tlo, thi = self.tails[i]
-        if thi > tlo:
+        for tlo, thi in self.tails[i]:
             works.append(self.d.all_reduce(bucket[tlo:thi], async_op))
             self._pending.append(("tail", tlo, thi, bucket))
         self._pending += [w for w in works if w is not None]
@@ -169,7 +174,10 @@ class ShardedAdamW:
             o = self.own_off[k]
             n = hi - lo
             pieces = [(0, n // ROW * ROW, ROW), (n // ROW * ROW, n, 0)]
-            jobs.append((lo, o, n))
+            # |g|^2: ddx_multi_grad_norm runs at most 64 workgroups per job, so a shard of up to 293 M elements is cut into jobs of
+            # SQ_JOB elements (16-byte aligned cuts) -- hundreds of jobs, like the per-tensor table of FusedAdamW
+            for a in range(0, n, SQ_JOB):
+                jobs.append((lo + a, o + a, min(SQ_JOB, n - a)))
             for a, b, fan in pieces:
                 if b > a:
                     jobs_ex.append((lo + a, o + a, b - a, (b - a) // fan if fan else 1))
@@ -198,7 +206,7 @@ class ShardedAdamW:
             sq.copy_((self.g_own.double() ** 2).sum().float().reshape(1))
         if self.d.rank != 0:
             for k, (lo, hi) in enumerate(self.own):
-                if (lo, hi) in self.tails:
+                if any((lo, hi) in ts for ts in self.tails):
                     o = self.own_off[k]
                     sq -= (self.g_own[o:o + hi - lo] ** 2).sum()
 
@@ -254,11 +262,23 @@ class ShardedAdamW:
             self.normalize()
         L.bump_weights_epoch()
         self.update_grad_norm_stats(grad_norm)
+        if self.emas and self.d.world > 1:
+            self.emas_complete = False
         return grad_norm
 
     def gather_emas(self) -> None:
-        """Complete every EMA shadow on every rank (checkpoint time): the other ranks' shards arrive by all-gather."""
+        """Complete every EMA shadow on every rank (checkpoint / evaluation time): the other ranks' shards arrive by all-gather.
+        COLLECTIVE: every rank must call it (UNetTrainStep.ema_state() does)."""
         for ef in self.ema_flat:
             for (s, S, lo, hi) in self.shards:
                 if S > 0:
                     self.d.all_gather(ef[s:s + self.d.world * S], ef[lo:hi].clone())
+        self.emas_complete = True
+
+    def ema_tensors(self, j: int) -> dict:
+        """name -> shadow tensor of EMA j, complete on this rank.  Raises when only this rank's shard is current: reading `EMASpec.tensors`
+        un-gathered at world > 1 would hand out (N - 1) / N stale values (call gather_emas() on every rank first)."""
+        if not self.emas_complete:
+            raise L.DDXError("ShardedAdamW: the EMA shadows are only current for this rank's shard -- call gather_emas() (collective) "
+                             "or UNetTrainStep.ema_state() before reading them")
+        return self.emas[j].tensors

@@ -206,6 +206,8 @@ class UNetTrainStep:
         # grad_exchange = "sharded" (DDX_GRAD_EXCHANGE=sharded): ZeRO-1 style -- reduce-scatter, parameter pass on this rank's shard of one
         # flat parameter buffer, all-gather, weight norm (training.sharded); also at world size 1, where it is the same arithmetic
         self.grad_exchange = grad_exchange or os.environ.get("DDX_GRAD_EXCHANGE", "all_reduce")
+        if self.grad_exchange not in ("all_reduce", "rs_ag", "sharded"):
+            raise ValueError(f"UNetTrainStep: grad_exchange must be all_reduce | rs_ag | sharded, not {self.grad_exchange!r}")
         self.sharded = None
         if self.grad_exchange == "sharded" and optimizer_impl is None:
             from .sharded import ShardedAdamW
@@ -332,6 +334,22 @@ class UNetTrainStep:
         self.total_samples_processed += total_batch
         return {"loss": loss, "grad_norm": grad_norm, "lr": lr}
 
+    def ema_state(self) -> dict:
+        """{EMA name: {parameter name: shadow tensor}}, complete on every rank -- THE way to read the EMA weights (checkpoint, evaluation,
+        reference ema.py:230-321 `EMA_Manager.save`).  With the sharded parameter pass a rank only keeps its own shard of every shadow
+        current between steps; this call completes them (one all-gather per EMA and bucket segment: COLLECTIVE, every rank must call it,
+        like the reference's checkpoint barrier, trainer.py:1122-1130).  Other modes: the shadows are already whole."""
+        if self.sharded is not None:
+            if not self.sharded.emas_complete:
+                self.sharded.gather_emas()
+            return {e.name: self.sharded.ema_tensors(j) for j, e in enumerate(self.emas)}
+        return {e.name: e.tensors for e in self.emas}
+
+    def prepare_checkpoint(self) -> dict:
+        """What a checkpoint of this rank holds: the model parameters and the complete EMA shadows (collective in sharded mode)."""
+        return {"params": {k: p.data for k, p in self.unet.named_parameters()}, "emas": self.ema_state(),
+                "global_step": self.global_step, "total_samples_processed": self.total_samples_processed}
+
     def _exchange(self, world: int, n_micro: int) -> Optional[GradientExchange]:
         tr = self.trainer
         # DDX_DDP_BUCKETS=1 runs the two-bucket exchange on any initialised process group (world_size 1 included: single-GPU check)
@@ -340,8 +358,7 @@ class UNetTrainStep:
             self._accum = torch.zeros_like(tr.grad_flat)
         if self.sharded is not None:
             return ShardedExchange(self.sharded, tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None)
-        mode = self.grad_exchange if self.grad_exchange in ("all_reduce", "rs_ag") else "all_reduce"
-        return GradientExchange(tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None, mode=mode) if exchange else None
+        return GradientExchange(tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None, mode=self.grad_exchange) if exchange else None
 
     def step(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
              conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:

@@ -245,7 +245,11 @@ def _sharded_worker(rank: int, ws: int, port: int, out_dir: str):
     calls = []
     opt = ShardedAdamW([(k, params[k]) for k in order], flat, views, [(0, early), (early, total - early)], cfg, emas=emas,
                        normalize=lambda: calls.append(1), use_hip=False)
-    assert opt.shards[0][1] == 128 and opt.tails[0] == (256, 288) and opt.shards[1][1] == 64      # 288 = 2 x 128 + 32, 161 = 2 x 64 + 33
+    # segment 0 = [0, 288): 2 x 128 + a replicated tail of 32; segment 1 = [288, 449) starts off the 64-element grid: replicated head
+    # [288, 320), shards 2 x 64 from 320, replicated tail [448, 449)
+    assert opt.shards[0][:2] == (0, 128) and opt.tails[0] == [(256, 288)]
+    assert opt.shards[1][:2] == (320, 64) and opt.tails[1] == [(288, 320), (448, 449)]
+    assert all(lo % 64 == 0 for (_s, S, lo, _hi) in opt.shards if S > 0)
     # reference: plain tensors, the same update on the SUM of both ranks' gradients
     rp = {k: v.clone() for k, v in start.items()}
     rm = {k: torch.zeros_like(v) for k, v in rp.items()}
@@ -281,7 +285,15 @@ def _sharded_worker(rank: int, ws: int, port: int, out_dir: str):
             assert torch.allclose(params[k].data, rp[k], rtol=1e-5, atol=1e-6), (step, k)
             assert params[k].data.data_ptr() == opt.param_flat[opt.offsets[k][0]:].data_ptr()     # the parameter IS the flat buffer's view
     assert len(calls) == 3
+    # between a step and the gather only this rank's shard of every shadow is current: the accessor refuses to hand out stale values
+    assert not opt.emas_complete
+    try:
+        opt.ema_tensors(0)
+        raise AssertionError("ema_tensors() must refuse un-gathered shadows at world size 2")
+    except Exception as exc:   # noqa: BLE001
+        assert "gather_emas" in str(exc)
     opt.gather_emas()
+    assert opt.emas_complete and opt.ema_tensors(0) is emas[0].tensors
     for k in order:
         assert torch.allclose(emas[0].tensors[k], re0[k], rtol=1e-5, atol=1e-6) and torch.allclose(emas[1].tensors[k], re1[k], rtol=1e-5, atol=1e-6), k
     dist.destroy_process_group()
@@ -292,6 +304,104 @@ def test_sharded_optimizer_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), f"sharded_ok_{r}")) for r in range(2))
+
+
+def _sharded_train_step_worker(rank: int, ws: int, port: int, out_dir: str):
+    """UNetTrainStep(grad_exchange="sharded") over gloo with the stub differentiation engine: the EMA weights read through the train-step API
+    (`ema_state()` / `prepare_checkpoint()`) are complete and identical on both ranks, and equal to the unsharded arithmetic."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dualdiffusion_amd import distributed as D
+    from dualdiffusion_amd.training.optimizer import EMASpec, LRScheduleConfig, OptimizerConfig
+    from dualdiffusion_amd.training.train_step import UNetTrainStep
+    assert D.init(backend="gloo")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            self.dec = torch.nn.Parameter(torch.randn(300, generator=g))
+            self.enc = torch.nn.Parameter(torch.randn(40, 10, generator=g))
+            self.gain = torch.nn.Parameter(torch.ones(()))
+            self.device = torch.device("cpu")
+
+        def normalize_weights(self):
+            pass
+
+    def make(mode):
+        net = Net().requires_grad_(False)
+        tr = _StubTrainer(net)
+        emas = [EMASpec(name="fast", tensors={k: p.data.clone() for k, p in net.named_parameters()}, beta=0.9),
+                EMASpec(name="fb", tensors={k: p.data.clone() for k, p in net.named_parameters()}, beta=0.8, feedback_beta=0.95)]
+        kw = dict(grad_exchange="sharded") if mode == "sharded" else dict(optimizer_impl=None)
+        if mode != "sharded":
+            return net, tr, emas, None
+        st = UNetTrainStep(net, None, OptimizerConfig(dynamic_max_grad_norm_z=None), LRScheduleConfig(lr_schedule="constant", learning_rate=1e-2, lr_warmup_steps=1),
+                           trainer=tr, emas=emas, **kw)
+        st.global_step = 1
+        return net, tr, emas, st
+
+    net, tr, emas, st = make("sharded")
+    assert st.sharded is not None and not st.sharded.use_hip
+    start = {k: p.data.clone() for k, p in net.named_parameters()}
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(3, ws * 2, 1, 2, 2, generator=g)
+    sig = torch.rand(3, ws * 2, generator=g) + 0.5
+    for i in range(3):
+        x, s_ = data[i][rank * 2:(rank + 1) * 2], sig[i][rank * 2:(rank + 1) * 2]
+        st.step(x, torch.zeros(2, 4), s_, torch.zeros_like(x), torch.ones(2, dtype=torch.bool))
+    assert not st.sharded.emas_complete
+    state = st.ema_state()                      # collective: completes the shadows
+    ck = st.prepare_checkpoint()
+    assert st.sharded.emas_complete and set(state) == {"fast", "fb"} and set(ck["emas"]) == {"fast", "fb"}
+    # identical on both ranks
+    for name in ("fast", "fb"):
+        v = torch.cat([t.flatten() for t in state[name].values()])
+        both = [torch.empty_like(v) for _ in range(ws)]
+        dist.all_gather(both, v)
+        assert torch.equal(both[0], both[1]), name
+    # equal to the plain arithmetic on the summed gradients (what every rank of the reference computes after accelerate's all-reduce)
+    import math
+    cfg = OptimizerConfig(dynamic_max_grad_norm_z=None)
+    rp = {k: v.clone() for k, v in start.items()}
+    rm = {k: torch.zeros_like(v) for k, v in rp.items()}
+    rv = {k: torch.zeros_like(v) for k, v in rp.items()}
+    re = [{k: v.clone() for k, v in rp.items()} for _ in range(2)]
+    keys = list(rp)
+    for i in range(3):
+        pers = [(data[i][r * 2:(r + 1) * 2].flatten(1).mean(1) * sig[i][r * 2:(r + 1) * 2]).mean() for r in range(ws)]
+        gsum = {keys[0]: sum(float(p) for p in pers), keys[1]: sum(float(p * 2) for p in pers), keys[2]: sum(float(p) * 3 for p in pers)}
+        gscale = cfg.loss_scale / ws
+        gn = math.sqrt(sum(gsum[k] ** 2 * rp[k].numel() for k in keys)) * gscale
+        coef = min(1.0, cfg.max_grad_norm / (gn + 1e-6))
+        b1, b2 = 1 - cfg.adam_beta1 ** (i + 1), 1 - cfg.adam_beta2 ** (i + 1)
+        betas = [emas[0].effective_beta(1 + i, 0, 0), emas[1].effective_beta(1 + i, 0, 0)]
+        for k in keys:
+            gk = torch.full_like(rp[k], gsum[k] * gscale * coef)
+            rm[k].mul_(cfg.adam_beta1).add_(gk, alpha=1 - cfg.adam_beta1)
+            rv[k].mul_(cfg.adam_beta2).addcmul_(gk, gk, value=1 - cfg.adam_beta2)
+            rp[k].mul_(1 - 1e-2 * cfg.adam_weight_decay)
+            rp[k].addcdiv_(rm[k], rv[k].sqrt() / math.sqrt(b2) + cfg.adam_epsilon, value=-1e-2 / b1)
+            re[0][k].lerp_(rp[k], 1 - betas[0])
+            re[1][k].lerp_(rp[k], 1 - betas[1])
+            rp[k].lerp_(re[1][k], 1 - 0.95)
+    for k in keys:
+        assert torch.allclose(ck["params"][k], rp[k], rtol=1e-5, atol=1e-6), k
+        assert torch.allclose(state["fast"][k], re[0][k], rtol=1e-5, atol=1e-6) and torch.allclose(state["fb"][k], re[1][k], rtol=1e-5, atol=1e-6), k
+    # an unknown exchange mode is an error, not a silent all-reduce
+    try:
+        UNetTrainStep(Net().requires_grad_(False), None, trainer=_StubTrainer(Net()), optimizer_impl=object(), grad_exchange="shraded")
+        raise AssertionError("unknown grad_exchange accepted")
+    except ValueError:
+        pass
+    D.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"sts_ok_{rank}"), "w").write("ok")
+
+
+def test_sharded_train_step_reads_complete_emas_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_sharded_train_step_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), f"sts_ok_{r}")) for r in range(2))
 
 
 def test_single_process_fallbacks():

@@ -207,3 +207,66 @@ def test_unmel_and_one_fgla_iteration_vs_fixture():
     e_fix, e_ref = rel_l2(raw, g["default.raw"]), rel_l2(g["default.raw"], truth)
     print(f"FGLA x{gm['n_iter']}: HIP vs the reference's waveform {e_fix:.3e} (reference fp32 vs fp64: {e_ref:.3e})")
     assert e_fix < 2.5 * e_ref + 1e-3
+
+
+def test_device_band_tables_bit_exact():
+    """SURVEY.md 8 a-11 on the GPU box: the integer band tables the mel kernels actually index with -- the DEVICE buffers `band_start` / `band_len`
+    of SpectrogramFormat (mel scale, 3201 bins) and MS_MDCT_DualFormat (slaney, 2049 bins) -- read back and compared bit for bit with the
+    reference's non-zero filter support (`band_edges`, `nnz`, `filter_colsum` of the fixtures made from frequency_scale.py:45-58,144-168), and the
+    device filter weights with the reference's filter values inside that support."""
+    from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+    from dualdiffusion_amd.modules.formats.ms_mdct_dual import MS_MDCT_DualFormat, MS_MDCT_DualFormatConfig
+    cases = (("mel_stft", _fmt(), lambda f: f.freq_scale),
+             ("ms_mel_spec", MS_MDCT_DualFormat(MS_MDCT_DualFormatConfig()).to(device="cuda"), lambda f: f.ms_freq_scale))
+    for name, fmt, scale_of in cases:
+        t, m = load_golden(name)
+        assert fmt.band_start.is_cuda and fmt.band_len.is_cuda and fmt.band_w.is_cuda
+        assert fmt.band_start.dtype == torch.int32 and fmt.band_len.dtype == torch.int32
+        start, length, bw = fmt.band_start.cpu(), fmt.band_len.cpu(), fmt.band_w.cpu()
+        edges = t["band_edges"]                                   # (filters, 2) int32: first / last bin with non-zero weight, inclusive
+        assert torch.equal(start, edges[:, 0]) and torch.equal(start + length - 1, edges[:, 1]), name
+        # the weights the kernel multiplies with: zero outside [0, len), their count and column sums are the reference filter bank's
+        cols = torch.arange(bw.shape[1]).unsqueeze(0)
+        assert bool((bw[cols >= length.unsqueeze(1)] == 0).all())
+        assert int((bw > 0).sum()) == m["nnz"], (name, int((bw > 0).sum()), m["nnz"])
+        sc = scale_of(fmt)
+        host = FrequencyScale(sc.freq_scale, sc.freq_min, sc.freq_max, sc.sample_rate, sc.num_stft_bins, sc.num_filters, sc.filter_norm)
+        assert torch.equal(host.band_edges(), edges)
+        fb = host.filters
+        for k in range(0, fb.shape[1], 17):
+            n = int(length[k])
+            assert torch.equal(bw[k, :n], fb[int(start[k]):int(start[k]) + n, k])
+        assert torch.equal(fb.sum(dim=0), t["filter_colsum"])
+
+
+def test_fgla_full_size_geometry():
+    """BASELINE configs[4] geometry of the phase reconstruction: `sample_to_raw` on a (2, 2, 256, 5504) mel (45 s stereo, 1 408 768 samples; 5504
+    frames x 32-row frame blocks, the 0.28 GB state / noise buffers) with 8 iterations -- finite, the right length, the re-encoded mel within the
+    short-clip round trip's bound, and GEOMETRY INDEPENDENCE: every kernel of the iteration is per frame (+ a 25-frame overlap-add), so the first
+    frames of the long call must equal the same call on a crop of the mel away from the crop's right edge (reference phase_recovery.py:78-119)."""
+    fmt = _fmt()
+    c = fmt.config
+    g = torch.Generator().manual_seed(21)
+    n = 1408768
+    tt = torch.arange(n) / 32000.0
+    a = torch.stack([0.08 * torch.sin(2 * torch.pi * (220.0 + 3.0 * tt) * tt) + 0.04 * torch.sin(2 * torch.pi * 1330 * tt),
+                     0.06 * torch.sin(2 * torch.pi * 554.4 * tt) + 0.05 * torch.sin(2 * torch.pi * (900.0 - 2.0 * tt) * tt)])[None].repeat(2, 1, 1)
+    a[1] = a[1].flip(0) * 0.7
+    a = a + 0.002 * torch.randn(a.shape, generator=g)
+    mel = fmt.raw_to_sample(a)
+    assert tuple(mel.shape) == (2, 2, 256, 5504)
+    rec = fmt.sample_to_raw(mel, n_fgla_iters=8, quiet=True)
+    assert tuple(rec.shape) == (2, 2, n) and bool(torch.isfinite(rec).all())
+    mel2 = fmt.raw_to_sample(rec)
+    e = rel_l2(mel2[..., 16:-16], mel.cpu()[..., 16:-16])
+    print(f"full size: mel(decode(mel)) vs mel after 8 iterations: {e:.3e}")
+    assert e < 0.25, e
+    # geometry independence (the iteration is deterministic: rand_init is off in the reference's call): one iteration moves information by at
+    # most 25 frames (a frame's analysis window covers the audio that 25 frames on either side were overlap-added into), so after 8 iterations and
+    # the final synthesis the first 512 - 9 * 25 - 32 frames of a 512-frame crop have seen exactly the neighbours they see in the long call
+    crop = 512
+    rec_c = fmt.sample_to_raw(mel[..., :crop].contiguous(), n_fgla_iters=8, quiet=True)
+    keep = (crop - 9 * 25 - 32) * c.hop_length - c.padded_length // 2
+    e_c = rel_l2(rec[..., :keep], rec_c[..., :keep])
+    print(f"full size vs {crop}-frame crop on the first {keep} samples: {e_c:.3e}")
+    assert e_c < 1e-5, e_c
