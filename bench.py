@@ -181,6 +181,227 @@ def train_main(a) -> None:
         dist.destroy_process_group()
 
 
+DEFAULT_VAE = dict(in_channels=2, out_channels=2, latent_channels=4, label_dim=1612, dropout=0.0, target_snr=31.984371183438952,
+                   model_channels=96, channel_mult=[1, 2, 3, 5], channel_mult_emb=None, channels_per_head=64, num_layers_per_block=3,
+                   res_balance=0.3, attn_balance=0.3, mlp_multiplier=1, mlp_groups=1, add_mid_block_attention=False)   # config/models/default/vae.json
+VAE_ENCODE_FLOP, VAE_DECODE_FLOP = 4.48e12, 10.10e12     # per 45 s sample
+MEL_FLOP, MSS_FLOP = 4.64e9, 3 * 33e9                    # per sample: FFT-6400 + banded mel; MSS block FFTs, value + gradient ~ 3 forward passes
+PEAK_HBM_GBS = 8000.0
+
+
+def build_vae(device, dtype, seed: int):
+    from dualdiffusion_amd.modules.vaes.vae_edm2 import AutoencoderKL_EDM2, DualDiffusionVAE_EDM2Config
+    torch.manual_seed(seed)
+    vae = AutoencoderKL_EDM2(DualDiffusionVAE_EDM2Config(**DEFAULT_VAE)).requires_grad_(False).train(False)
+    with torch.no_grad():
+        for p in vae.parameters():
+            if p.ndim == 0:
+                p.fill_(0.7)
+    vae = vae.to(device=device, dtype=torch.float32)
+    vae.normalize_weights()
+    return vae.to(dtype=dtype)
+
+
+class _MelFmt:
+    """The `format` argument of the UNet / VAE forward: frequency scale of the mel-spectrogram format (spectrogram.py:240-244)."""
+
+    def __init__(self):
+        from dualdiffusion_amd.modules.formats.frequency_scale import FrequencyScale
+        self.ms_freq_scale = self.fs = FrequencyScale("mel", 20.0, 16000.0, 32000, 3201, 256)
+
+    def get_ln_freqs(self, x):
+        ln = self.fs.get_unscaled(x.shape[2] + 2, device=x.device)[1:-1].log2()
+        ln = ln.view(1, 1, -1, 1).repeat(x.shape[0], 1, 1, x.shape[3])
+        return ((ln - ln.mean()) / ln.std()).to(x.dtype)
+
+
+def _stage_timer():
+    """Per-stage device time with events on the current stream (every stage of these modes launches on it)."""
+    marks = []
+
+    def mark(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((name, ev))
+
+    def read():
+        torch.cuda.synchronize()
+        return {marks[i + 1][0]: marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)}
+    return mark, read
+
+
+def config3_main(a) -> None:
+    """BASELINE.json configs[2] as ONE timed step on one GPU (N > 1: independent replicas of it, no collective -- the optimizer step and its
+    gradient exchange are `--mode train`): audio (B, 2, 1 408 768) resident in HBM -> mel-STFT (`raw_to_sample`) -> VAE.encode(...).mode() ->
+    UNet train batch (forward, EDM2 loss, backward; stratified ln_sech sigma) -> VAE.decode(latents) -> multi-scale spectral loss value +
+    gradient against the mel spectrogram (reference unet_trainer.py:222-296, dae_trainer_g1.py:51-127).  B = 8, bf16 bodies / fp32 audio
+    kernels.  value = steps/s of the whole chain; `stages_ms` = device time per stage; `roofline` = the stage with the largest share."""
+    from dualdiffusion_amd import distributed as D
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    from dualdiffusion_amd.training.loss.multiscale_spectral import MSSLoss2D, MSSLoss2DConfig
+    from dualdiffusion_amd.training.sigma_sampler import SigmaSampler, SigmaSamplerConfig
+    from dualdiffusion_amd.training.unet_grad import UNetTrainer
+    rank, world, local_rank = D.world()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init(backend="nccl", device=dev)
+    B = a.batch if a.batch != 4 else 8
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device=dev)
+    ffmt = _MelFmt()
+    vae = build_vae(dev, torch.bfloat16, seed=3)
+    vae.max_plan_batch = 2
+    unet = build_model(dev, torch.float32, seed=0).train(True)
+    trainer = UNetTrainer(unet)
+    mss = MSSLoss2D(MSSLoss2DConfig(), dev)
+    g = torch.Generator(device=dev).manual_seed(10 + rank)
+    audio = torch.randn(B, 2, fmt.sample_raw_crop_width(), device=dev, generator=g) * 0.1
+    labels = torch.randn(B, DEFAULT_VAE["label_dim"], device=dev, generator=g)
+    clap = torch.randn(B, 512, device=dev, generator=g)
+    noise = torch.randn(B, 4, 32, 688, device=dev, generator=g)
+    mask = torch.rand(B, device=dev, generator=g) > 0.1
+    sigma = SigmaSampler(SigmaSamplerConfig(sigma_max=200.0, sigma_min=0.03, sigma_data=1.0, distribution="ln_sech")).sample(
+        B, jitter=torch.tensor([0.5])).float().to(dev)
+    with torch.no_grad():
+        vemb = vae.get_embeddings(labels, labels_like=labels)
+
+    def one_step(mark=None):
+        m = mark or (lambda name: None)
+        m("start")
+        with torch.no_grad():
+            mel = fmt.raw_to_sample(audio); m("mel_stft")
+            latents = vae.encode(mel, vemb, ffmt).mode(); m("vae_encode")
+        loss, grads = trainer.train_batch(latents.float(), clap, sigma, noise, mask, ffmt); m("unet_train_batch")
+        with torch.no_grad():
+            recon = vae.decode(latents, vemb, ffmt); m("vae_decode")
+        ml, mgrad = mss.mss_loss_and_grad(recon.float(), mel); m("mss_loss_grad")
+        return loss, ml, mgrad, grads
+
+    for _ in range(max(a.warmup, 1)):
+        out = one_step()
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = one_step()
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    loss, ml, mgrad, grads = out
+    assert torch.isfinite(loss).all() and torch.isfinite(ml).all() and torch.isfinite(mgrad).all(), "non-finite config-3 step"
+    total_steps, elapsed = D.replica_throughput(a.steps, elapsed)
+    if rank == 0:
+        mark, read = _stage_timer()
+        one_step(mark)
+        stages = read()
+        flops = {"mel_stft": B * MEL_FLOP, "vae_encode": B * VAE_ENCODE_FLOP, "unet_train_batch": 3 * B * FLOP_PER_SAMPLE, "vae_decode": B * VAE_DECODE_FLOP,
+                 "mss_loss_grad": B * MSS_FLOP}
+        # algorithmic HBM bytes of the two audio-side stages (SURVEY.md 8d): mel read + write 2 x 11.27 MB per sample; MSS two images in, one gradient out
+        hbm = {"mel_stft": B * 2 * 11.27e6, "mss_loss_grad": B * 3 * 11.27e6}
+        dom = max(stages, key=stages.get)
+        if dom in hbm:
+            ach = hbm[dom] / (stages[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        else:
+            ach = flops[dom] / (stages[dom] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None}
+        roof.update(kernel=dom, share_of_step_time=round(stages[dom] / sum(stages.values()), 3),
+                    stage_tflops={k: round(flops[k] / (v * 1e-3) / 1e12, 1) for k, v in stages.items()},
+                    note="stage-level: model FLOPs (or algorithmic bytes) of the stage / its device time; per-kernel rooflines of each stage: profiles/")
+        ms = elapsed / a.steps * 1e3
+        line = {"metric": "configs[2] training-step chain steps/sec (mel-STFT + VAE encode + UNet fwd+bwd + VAE decode + MSS loss)", "value": round(total_steps / elapsed, 4),
+                "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "configs[2]: training step fwd+bwd: VAE mel encode + UNet + multiscale spectral loss, batch 8, 45 s @ 32 kHz stereo "
+                                       "(audio 8x2x1408768 -> mel 8x2x256x5504 -> latents 8x4x32x688), default unet.json / vae.json shapes, random-init weights",
+                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"replicas x{world}", "graph": False},
+                "samples_per_s": round(B * total_steps / elapsed, 2), "stages_ms": {k: round(v, 2) for k, v in stages.items()},
+                "stages_sum_ms": round(sum(stages.values()), 2), "unet_loss_mean": round(float(loss.mean()), 4), "mss_loss_mean": round(float(ml.mean()), 4),
+                "roofline": roof}
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        D.barrier()
+        dist.destroy_process_group()
+
+
+def sample_main(a) -> None:
+    """BASELINE.json configs[4] (the stages on SURVEY.md 8's path): 100-step EDM sampler over the default UNet (CFG: 2B rows per call, Heun: 199
+    calls, one hipGraph per step) -> VAE decode -> FGLA stereo phase reconstruction (200 iterations), batch 16 (reference
+    dual_diffusion_pipeline.py:589-752).  One `step` = the whole pipeline for one batch of B clips; value = 45 s clips per second.
+    N > 1: independent replicas."""
+    from dualdiffusion_amd import distributed as D
+    from dualdiffusion_amd.modules.formats.spectrogram import SpectrogramFormat, SpectrogramFormatConfig
+    from dualdiffusion_amd.pipelines.dual_diffusion_pipeline import DualDiffusionPipeline, SampleParams
+    rank, world, local_rank = D.world()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init(backend="nccl", device=dev)
+    B = a.batch if a.batch != 4 else 16
+    n_steps, n_fgla = a.sampler_steps, a.fgla_iters
+    dt = torch.bfloat16
+    unet = build_model(dev, dt, seed=0)
+    unet.compile()
+    vae = build_vae(dev, dt, seed=3)
+    fmt = SpectrogramFormat(SpectrogramFormatConfig()).to(device=dev)
+    pipe = DualDiffusionPipeline({"unet": unet, "vae": vae, "format": fmt})
+    torch.manual_seed(1 + rank)
+    clap = torch.randn(1, 512, device=dev).repeat(2 * B, 1)
+    labels = torch.randn(B, DEFAULT_VAE["label_dim"], device=dev)
+    shape = (B, 4, 32, 688)
+    with torch.no_grad():
+        vemb = vae.get_embeddings(labels)
+
+    def one(steps, fgla, mark=None):
+        m = mark or (lambda name: None)
+        m("start")
+        latents = pipe.diffusion_decode(SampleParams(seed=1, num_steps=steps, batch_size=B, cfg_scale=1.5, use_heun=True, input_perturbation=1.0,
+                                                     sigma_max=200.0, sigma_min=0.03, rho=7.0), quiet=True, audio_embedding=clap, sample_shape=shape)
+        m("sampler")
+        with torch.no_grad():
+            mel = vae.decode(latents.to(dt), vemb, fmt); m("vae_decode")
+            audio = fmt.sample_to_raw(mel.float(), n_fgla_iters=fgla, quiet=True); m("fgla")
+        return audio
+
+    one(2, 1)                                   # first calls: plans, graphs, un-mel pseudo-inverse, FFT tables
+    for _ in range(a.warmup):
+        one(n_steps, n_fgla)
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        audio = one(n_steps, n_fgla)
+    torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(audio).all() and tuple(audio.shape) == (B, 2, 1408768), "non-finite / mis-shaped audio"
+    total_steps, elapsed = D.replica_throughput(a.steps, elapsed)
+    if rank == 0:
+        mark, read = _stage_timer()
+        one(n_steps, n_fgla, mark)
+        stages = read()
+        evals = 2 * n_steps - 1
+        ach = evals * 2 * B * FLOP_PER_SAMPLE / (stages["sampler"] * 1e-3) / 1e12
+        fg_gbs = n_fgla * B * 0.70e9 / (stages["fgla"] * 1e-3) / 1e9        # SURVEY.md 8d: 0.70 GB algorithmic per sample and iteration
+        line = {"metric": "full sampling pipeline 45 s clips/sec (EDM sampler + VAE decode + FGLA)", "value": round(B * total_steps / elapsed, 4), "unit": "clips/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"configs[4]: {n_steps}-step EDM sampler (cfg_scale 1.5, Heun, input_perturbation 1.0, sigma 200 -> 0.03, rho 7) + VAE decode + "
+                                       f"FGLA ({n_fgla} iterations, coherence 0.67), batch {B}; the MCLT diffusion-decoder stage of the live chain is timed by tools/ddec_bench.py",
+                           "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"replicas x{world}", "graph": True},
+                "stages_ms": {k: round(v, 1) for k, v in stages.items()}, "unet_calls": evals, "unet_call_batch": 2 * B,
+                "ms_per_unet_call": round(stages["sampler"] / evals, 2), "ms_per_fgla_iteration": round(stages["fgla"] / max(n_fgla, 1), 3),
+                "seconds_per_clip": round(elapsed / a.steps / B, 3),
+                "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                             "kernel": "sampler (UNet forward at batch 2B)", "share_of_step_time": round(stages["sampler"] / sum(stages.values()), 3),
+                             "fgla_algorithmic_GBps": round(fg_gbs, 1), "fgla_frac_of_hbm_peak": round(fg_gbs / PEAK_HBM_GBS, 4),
+                             "vae_decode_tflops": round(B * VAE_DECODE_FLOP / (stages["vae_decode"] * 1e-3) / 1e12, 1)}}
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        D.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,12 +411,22 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--layer-table", action="store_true", help="print the per-op hipEvent profile (rank 0)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
-                    help="infer: the BASELINE metric (UNet denoise steps/s, replicas); train: BASELINE configs[3], data-parallel optimizer steps/s")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "config3", "sample"],
+                    help="infer: the BASELINE metric (UNet denoise steps/s, replicas); train: BASELINE configs[3], data-parallel optimizer steps/s; "
+                         "config3: BASELINE configs[2], the whole training-step chain at B=8 with per-stage times; sample: BASELINE configs[4], sampler + VAE decode + FGLA at B=16")
+    ap.add_argument("--sampler-steps", type=int, default=100, help="--mode sample: sampler steps")
+    ap.add_argument("--fgla-iters", type=int, default=200, help="--mode sample: FGLA iterations")
     ap.add_argument("--accum", type=int, default=1, help="--mode train: gradient-accumulation micro-steps per optimizer step")
     a = ap.parse_args()
     if a.mode == "train":
         return train_main(a)
+    if a.mode in ("config3", "sample"):
+        # these steps take 0.2 s / 6 s each: fewer of them by default (explicit --steps / --warmup win)
+        if "--steps" not in sys.argv:
+            a.steps = 5 if a.mode == "config3" else 1
+        if "--warmup" not in sys.argv:
+            a.warmup = 2 if a.mode == "config3" else 0
+        return config3_main(a) if a.mode == "config3" else sample_main(a)
 
     from dualdiffusion_amd import distributed as D
     rank, world, local_rank = D.world()
