@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   const int ck_shift = __builtin_ctz(p.CK);
   struct Unit { int b, h0, w0, n0, g; };
   const float inv_px = 1.0f / (float)ntile_px, inv_nn = 1.0f / (float)ntile_n;
-  const float inv_tw = 1.0f / (float)p.tiles_w, inv_th = 1.0f / (float)p.tiles_h;
+  const float inv_tw = 1.0f / (float)p.tiles_w, inv_th = 1.0f / (float)p.tiles_h, inv_img = 1.0f / (float)(p.tiles_h * p.tiles_w);
   // XCD-aware order (per_xcd > 0; chosen per layer by the launcher): workgroups are dealt round-robin to the 8 XCDs, so slot
   // u belongs to XCD u % 8, which walks its own contiguous eighth of a list ordered pixel tile -> channel tile -> group.
   // All channel slices of a pixel tile (64-byte runs of the same 128-byte lines when Cg = 32) and its halo neighbours then
@@ -199,6 +199,24 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
       tile = u - r * ntile_px;
       t.g = fdiv(r, inv_nn);
       t.n0 = (r - t.g * ntile_n) * BN;
+    }
+    if (p.tile_order) {
+      // XCD-contiguous, column-major tiles (round 5).  Workgroups are dealt round-robin to the 8 XCDs and every unit order above hands XCD x
+      // the tiles == x (mod 8) (the contiguous per_xcd order excepted): neighbouring tiles, which share two halo rows / columns of the
+      // input, then sit in eight different L2s and every halo is fetched from the fabric twice (FETCH_SIZE 1.3 - 1.5 x the tensor, r04).
+      // Here logical tile t = x + 8 k becomes physical tile start_x + k of XCD x's own contiguous range, and physical tiles are numbered
+      // down the tile columns of an image first: the few tiles an XCD has in flight are vertical neighbours, the next ones the column beside.
+      if (!per_xcd || WSMAP) {
+        const int base = ntile_px >> 3, rem = ntile_px & 7, x = tile & 7;
+        tile = x * base + min(x, rem) + (tile >> 3);
+      }
+      const int per_img = p.tiles_h * p.tiles_w;
+      t.b = fdiv(tile, inv_img);
+      const int r = tile - t.b * per_img;
+      const int colm = fdiv(r, inv_th);
+      t.w0 = colm * p.TW;
+      t.h0 = (r - colm * p.tiles_h) * p.TH;
+      return t;
     }
     // tile -> (image, tile row, tile column), row-major
     const int row = fdiv(tile, inv_tw);
@@ -1212,6 +1230,9 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   p.tiles_h = ceil_div(p.H, TH); p.tiles_w = ceil_div(p.W, TW);
   p.arows_alloc = (TH + 2 * pad) * (TW + 2 * pad);
   p.inv_TWP = 1.0f / (float)(TW + 2 * pad);
+  // 3x3 layers: XCD-contiguous column-major tile order (DDX_TILE_ORDER=0: row-major round-robin, for the A/B)
+  static const bool tile_order_on = []() { const char* e = std::getenv("DDX_TILE_ORDER"); return !e || e[0] != '0'; }();
+  p.tile_order = (tile_order_on && ksize == 3 && (long)p.B * p.tiles_h * p.tiles_w >= 64) ? 1 : 0;
   // channel tile: 32 (one fragment column) or 64 with 4 waves and 2 workgroups per CU; 256 for wide 1x1 layers (8 waves).
   // (A 128-channel 8-wave 3x3 variant measured within 3% of the 64-channel one and loses on ragged groups: not built.)
   if (p.epilogue == DDX_EPI_SILU_BWD) {

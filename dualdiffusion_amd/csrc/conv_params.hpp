@@ -47,6 +47,8 @@ struct ConvParams {
   int TH, TW, tiles_h, tiles_w, arows_alloc;
   float inv_TWP;
   int group_smem;  // LDS bytes of one split-K group's staging region
+  int tile_order;  // LDS-DMA kernel: 1 = pixel tiles numbered column-major inside an image, each XCD walking ONE contiguous range of them (halo rows and
+                   // columns of neighbouring tiles then meet in the same L2 within a few units); 0 = row-major, tiles dealt round-robin to the XCDs
   int force_cfg;   // register-staged kernel: 0 = heuristic choice, else 1 + 3 * tile (0..3: 256x64, 256x32, 128x64, 128x32) + split-K index (1, 2, 4)
 };
 
