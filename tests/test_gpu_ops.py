@@ -839,6 +839,9 @@ def test_conv_dma_modes_against_the_register_staged_kernel():
     g = torch.Generator(device="cuda").manual_seed(3)
     for (B, H, W, C0, C1, Cout, G, res, ks) in [(2, 40, 200, 128, 0, 128, 2, True, 3), (2, 40, 200, 64, 64, 64, 2, False, 3), (4, 32, 344, 256, 0, 512, 8, False, 3),
                                                  (4, 16, 344, 768, 0, 768, 8, True, 3), (4, 32, 700, 512, 0, 256, 8, True, 3),
+                                                 # 96-channel tiles (NF = 3, epilogue patches inside stage 1): the VAE's dense 96 / 192 / 288-channel layers
+                                                 (2, 128, 1030, 96, 0, 96, 1, True, 3), (2, 128, 1030, 96, 0, 96, 1, False, 3), (1, 64, 1376, 96, 96, 192, 1, False, 3),
+                                                 (2, 61, 700, 192, 0, 288, 1, True, 3), (4, 16, 344, 768, 0, 768, 8, False, 3),
                                                  (2, 64, 301, 256, 0, 256, 1, True, 1), (2, 64, 301, 256, 128, 512, 1, False, 1),   # wide 1x1 (flat pixel list)
                                                  (4, 8, 172, 1024, 768, 768, 1, False, 1)]:                                        # small-M, long K: 96-pixel units
         a0 = torch.randn(B, H, W, C0, device="cuda", generator=g).bfloat16()
@@ -915,6 +918,10 @@ C16_CASES = {
     "pcs_up_96": (4, 16, 344, 768, 0, 1536, 8, True, False, True, False, (1, 0, 1, 0)),           # nearest-up source, three channel tiles
     "pcs_ng32": (6, 64, 640, 96, 0, 32, 1, False, True, False, True, (1, 0, 0, 1)),               # one fragment column per wave
     "pcs_ragged_h": (4, 20, 344, 768, 0, 768, 8, False, False, False, False, (1, 0, 1, 0)),       # ragged tile rows and columns, Ng = 96
+    # 96-channel tiles (NF = 3): blocked source / activated blocked output, and NHWC residual + blocked twin, dense VAE shapes
+    "bn96_res0": (2, 120, 1030, 96, 0, 96, 1, False, False, True, False, (1, 0, 1, 0)),
+    "bn96_res1": (2, 120, 1030, 96, 0, 96, 1, False, True, False, True, (1, 0, 0, 1)),
+    "bn96_cat_192": (1, 64, 1376, 96, 96, 192, 1, False, False, True, True, (1, 1, 1, 1)),
 }
 
 
