@@ -213,6 +213,10 @@ PROTOTYPES = {
     "ddx_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "ddx_edm2_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int64, C.c_void_p]),
+    "ddx_edm2_loss_v": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_int64, C.c_void_p]),
+    "ddx_mp_dropout": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p]),
+    "ddx_unet_xref_mix_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ddx_multi_grad_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "ddx_clip_coef": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "ddx_multi_adamw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -25,12 +25,17 @@ def _named(unet):
 class _UNetForward(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, unet, x_in, sigma, format, embeddings, perturbed_input, *params):
+    def forward(ctx, unet, x_in, sigma, format, embeddings, perturbed_input, x_ref, *params):
         tr = unet._get_trainer()
+        # config.dropout > 0 (unet_edm2_b4.py:124-125): one draw per forward from torch's generator of the module's device, like F.dropout's
+        seed = None
+        if float(getattr(unet.config, "dropout", 0.0) or 0.0) > 0:
+            seed = int(torch.randint(0, 2 ** 62, (1,), device=unet.device).item())
         with torch.no_grad():
-            out = tr.forward(x_in, sigma, format, embeddings, perturbed_input)
+            out = tr.forward(x_in, sigma, format, embeddings, perturbed_input, x_ref=x_ref, dropout_seed=seed)
         tr._tape_owner = ctx
         ctx.unet, ctx.emb_dtype = unet, embeddings.dtype
+        ctx.xref_dtype = x_ref.dtype if (x_ref is not None and x_ref.requires_grad) else None
         ctx.names = [k for k, _ in _named(unet)]
         return out
 
@@ -42,9 +47,11 @@ class _UNetForward(torch.autograd.Function):
         grads = tr.backward(d_out.contiguous().float())
         tr._tape_owner, tr.tape = None, None
         d_emb = grads.pop("embeddings").to(ctx.emb_dtype)
+        d_xref = grads.pop("x_ref", None)
+        d_xref = d_xref.to(ctx.xref_dtype) if (d_xref is not None and ctx.xref_dtype is not None) else None
         g = tr.store_grads(grads)
         # clones: autograd may keep what it is handed as `.grad`, and the trainer's flat bucket is overwritten by the next backward
-        return (None, None, None, None, d_emb, None) + tuple(g[k].clone() if k in g else None for k in ctx.names)
+        return (None, None, None, None, d_emb, None, d_xref) + tuple(g[k].clone() if k in g else None for k in ctx.names)
 
 
 class _Embeddings(torch.autograd.Function):
@@ -85,9 +92,8 @@ def wants_grad(unet) -> bool:
 
 
 def unet_forward(unet, x_in, sigma, format, embeddings, x_ref: Optional[torch.Tensor], perturbed_input: Optional[torch.Tensor]):
-    if x_ref is not None:
-        raise DDXError("autograd through the HIP UNet does not take x_ref (the reference's unet_train_batch passes none for this model)")
-    return _UNetForward.apply(unet, x_in, sigma, format, embeddings, perturbed_input, *[p for _, p in _named(unet)])
+    # x_ref (unet_edm2_b4.py:293-294) is differentiable: its gradient -- reference channels and blend weight t -- comes back through the node
+    return _UNetForward.apply(unet, x_in, sigma, format, embeddings, perturbed_input, x_ref, *[p for _, p in _named(unet)])
 
 
 def get_embeddings(unet, emb_in, conditioning_mask):

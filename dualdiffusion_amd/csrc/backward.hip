@@ -240,11 +240,12 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dx_multi_kernel(const dd
 //   wl = mean_chw((D - x)^2) * (sigma^2 + sd^2) / (sigma * sd)^2,   loss = wl / exp(logvar) + logvar,
 // and the gradients of mean_b(loss): dD = (2 w / (N B exp(logvar))) (D - x), dlogvar = (1 - wl / exp(logvar)) / B.
 __global__ __launch_bounds__(256) void edm2_loss_grad_kernel(const float* __restrict__ d, const float* __restrict__ x, const float* __restrict__ sigma,
-                                                             const float* __restrict__ logvar, float sd, float* __restrict__ dd, float* __restrict__ ss,
-                                                             int B, size_t n) {
+                                                             const float* __restrict__ logvar, float sd, const float* __restrict__ sdv,
+                                                             float* __restrict__ dd, float* __restrict__ ss, int B, size_t n) {
   __shared__ float scratch[4];
   const int b = blockIdx.y;
   const float sg = sigma[b];
+  if (sdv) sd = sdv[b];      // use_dynamic_sigma_data (unet_trainer.py:263-269): the loss weight's sigma_data is per sample
   const float w = (sg * sg + sd * sd) / ((sg * sd) * (sg * sd));
   const float k = 2.0f * w / ((float)n * (float)B * __expf(logvar ? logvar[b] : 0.f));
   float acc = 0.f;
@@ -257,10 +258,11 @@ __global__ __launch_bounds__(256) void edm2_loss_grad_kernel(const float* __rest
   if (threadIdx.x == 0) atomicAdd(ss + b, acc);
 }
 __global__ void edm2_loss_finish_kernel(const float* __restrict__ ss, const float* __restrict__ sigma, const float* __restrict__ logvar, float sd,
-                                        float* __restrict__ loss, float* __restrict__ dlogvar, int B, size_t n) {
+                                        const float* __restrict__ sdv, float* __restrict__ loss, float* __restrict__ dlogvar, int B, size_t n) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float sg = sigma[b];
+  if (sdv) sd = sdv[b];
   const float w = (sg * sg + sd * sd) / ((sg * sd) * (sg * sd));
   const float wl = ss[b] / (float)n * w;
   const float lv = logvar ? logvar[b] : 0.f;
@@ -407,17 +409,99 @@ extern "C" int ddx_add3(const void* a, const void* b, const void* c, void* out, 
   }, stream, "add3", 0.0, (c ? 4.0 : 3.0) * (double)n * (double)dtype_size(dtype));
 }
 
-extern "C" int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data, float* loss,
-                             float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream) {
+extern "C" int ddx_edm2_loss_v(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data,
+                               const float* sigma_data_vec, float* loss, float* d_denoised, float* d_logvar, float* workspace, int32_t B,
+                               int64_t n_per_sample, ddx_stream stream) {
   if (!denoised || !target || !sigma || !loss || !workspace || B <= 0 || n_per_sample <= 0) return set_error(DDX_ERR_ARG, "edm2_loss: bad args");
   return dispatch([=](hipStream_t s) -> int {
     if (int rc = zero_bytes(workspace, sizeof(float) * B, s)) return rc;   // (a kernel, not a memset node: common.hpp)
     dim3 grid((unsigned)std::min<int64_t>((n_per_sample + 255) / 256, 512), (unsigned)B);
-    hipLaunchKernelGGL(edm2_loss_grad_kernel, grid, dim3(256), 0, s, denoised, target, sigma, logvar, sigma_data, d_denoised, workspace, B, (size_t)n_per_sample);
-    hipLaunchKernelGGL(edm2_loss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)workspace, sigma, logvar, sigma_data, loss, d_logvar, B,
+    hipLaunchKernelGGL(edm2_loss_grad_kernel, grid, dim3(256), 0, s, denoised, target, sigma, logvar, sigma_data, sigma_data_vec, d_denoised, workspace, B,
                        (size_t)n_per_sample);
+    hipLaunchKernelGGL(edm2_loss_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const float*)workspace, sigma, logvar, sigma_data, sigma_data_vec, loss,
+                       d_logvar, B, (size_t)n_per_sample);
     return check_launch("edm2_loss");
   }, stream, "edm2_loss");
+}
+
+extern "C" int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data, float* loss,
+                             float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream) {
+  return ddx_edm2_loss_v(denoised, target, sigma, logvar, sigma_data, nullptr, loss, d_denoised, d_logvar, workspace, B, n_per_sample, stream);
+}
+
+// ---- magnitude-preserving dropout (unet_edm2_b4.py:124-125: F.dropout(y, p) * (1 - p)^0.5, training only) and its backward: the same
+// element-wise factor keep / sqrt(1 - p).  The keep mask is never stored: Philox4x32-10 over (element index / 4, stream id) with the draw's
+// 64-bit seed as key regenerates it wherever it is needed (forward on the activation, backward on its gradient).
+namespace ddx {
+namespace {
+struct u32x4_t { unsigned x, y, z, w; };
+__device__ __forceinline__ u32x4_t philox4x32_10(u32x4_t c, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+    c = u32x4_t{(unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0};
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mp_dropout_kernel(T* __restrict__ x, size_t n, float p, float scale, unsigned k0, unsigned k1, unsigned stream_id) {
+  const size_t n4 = (n + 3) / 4;
+  for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * 256) {
+    const u32x4_t r = philox4x32_10(u32x4_t{(unsigned)i4, (unsigned)(i4 >> 32), stream_id, 0u}, k0, k1);
+    const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t i = i4 * 4 + e;
+      if (i >= n) break;
+      const bool keep = (float)rr[e] * 2.3283064365386963e-10f >= p;      // uniform in [0, 1): P(keep) = 1 - p
+      x[i] = from_f32<T>(keep ? to_f32<T>(x[i]) * scale : 0.f);
+    }
+  }
+}
+// backward of D = mp_sum(x_ref[:, :-1], D0, t = x_ref[:, -1:]) (unet_edm2_b4.py:293-294), all NCHW fp32:
+//   n = sqrt((1 - t)^2 + t^2);  dD0 = dD t / n;  d xr = dD (1 - t) / n;  dt = sum_c dD [ (D0 - xr) / n - ((1 - t) xr + t D0) (2 t - 1) / n^3 ]
+__global__ __launch_bounds__(256) void xref_mix_bwd_kernel(const float* __restrict__ dD, const float* __restrict__ D0, const float* __restrict__ x_ref,
+                                                           float* __restrict__ dD0, float* __restrict__ dxref, int B, int C, size_t HW) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / HW, hw = i - b * HW;
+    const float t = x_ref[(b * (C + 1) + C) * HW + hw];
+    const float n2 = (1.f - t) * (1.f - t) + t * t, n = sqrtf(n2), inv = 1.f / n;
+    float dt = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const size_t o = (b * C + c) * HW + hw, oxr = (b * (C + 1) + c) * HW + hw;
+      const float g = dD[o], d0 = D0[o], xr = x_ref[oxr];
+      dD0[o] = g * t * inv;
+      if (dxref) dxref[oxr] = g * (1.f - t) * inv;
+      dt += g * ((d0 - xr) * inv - ((1.f - t) * xr + t * d0) * (2.f * t - 1.f) * inv / n2);
+    }
+    if (dxref) dxref[(b * (C + 1) + C) * HW + hw] = dt;
+  }
+}
+}  // namespace
+}  // namespace ddx
+
+extern "C" int ddx_mp_dropout(void* x, int64_t n, float p, uint64_t seed, uint32_t stream_id, int32_t dtype, ddx_stream stream) {
+  if (!x || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return set_error(DDX_ERR_ARG, "mp_dropout: bad args");
+  if (dtype != DDX_BF16 && dtype != DDX_F32) return set_error(DDX_ERR_ARG, "mp_dropout: dtype");
+  const float scale = 1.0f / std::sqrt(1.0f - p);     // 1 / (1 - p) of the dropout times (1 - p)^0.5 of the block
+  return dispatch([=](hipStream_t s) -> int {
+    const int blocks = grid_for((size_t)(n + 3) / 4);
+    if (dtype == DDX_BF16) hipLaunchKernelGGL(mp_dropout_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (bf16*)x, (size_t)n, p, scale, (unsigned)seed, (unsigned)(seed >> 32), stream_id);
+    else hipLaunchKernelGGL(mp_dropout_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)x, (size_t)n, p, scale, (unsigned)seed, (unsigned)(seed >> 32), stream_id);
+    return check_launch("mp_dropout");
+  }, stream, "mp_dropout", 0.0, 2.0 * (double)n * (double)dtype_size(dtype));
+}
+
+extern "C" int ddx_unet_xref_mix_bwd(const float* d_out_nchw, const float* d0_nchw, const float* x_ref_nchw, float* d_d0_nchw, float* d_x_ref_nchw,
+                                     int32_t B, int32_t C, int32_t H, int32_t W, ddx_stream stream) {
+  if (!d_out_nchw || !d0_nchw || !x_ref_nchw || !d_d0_nchw || B <= 0 || C <= 0) return set_error(DDX_ERR_ARG, "xref_mix_bwd: bad args");
+  return dispatch([=](hipStream_t s) -> int {
+    hipLaunchKernelGGL(xref_mix_bwd_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, s, d_out_nchw, d0_nchw, x_ref_nchw, d_d0_nchw, d_x_ref_nchw, B, C,
+                       (size_t)H * W);
+    return check_launch("xref_mix_bwd");
+  }, stream, "xref_mix_bwd");
 }
 
 // backward of D = c_skip * x_in + c_out * y w.r.t. y (unet_edm2_b4.py:291): dy[b][h][w][c] = c_out(sigma_b) * dD[b][c][h][w], written

@@ -99,9 +99,10 @@ class UNet(DualDiffusionUNet):
     def __init__(self, config: UNetConfig) -> None:
         super().__init__()
         self.config = config
-        if getattr(config, "dropout", 0):
-            # reference Block applies magnitude-preserving dropout in training (unet_edm2_b4.py:124-125); no kernel for it here
-            raise NotImplementedError(f"UNetConfig.dropout = {config.dropout}: dropout is not implemented on the HIP path (use 0)")
+        if not 0.0 <= float(getattr(config, "dropout", 0.0) or 0.0) < 1.0:
+            raise ValueError(f"UNetConfig.dropout = {config.dropout}: must be in [0, 1)")
+        # (config.dropout > 0: magnitude-preserving dropout of every block's hidden activation in TRAINING, unet_edm2_b4.py:124-125 -- applied by
+        # the differentiation engine, training.unet_grad / ddx_mp_dropout; eval forwards are unaffected, as in the reference)
         cblock = [config.model_channels * m for m in config.channel_mult]
         cnoise = config.model_channels * config.channel_mult_noise if config.channel_mult_noise is not None else max(cblock)
         cemb = config.model_channels * config.channel_mult_emb if config.channel_mult_emb is not None else max(cblock)
@@ -220,6 +221,9 @@ class UNet(DualDiffusionUNet):
     def _engine_for(self, B: int, H: int, W: int, with_xref: bool) -> "_UNetEngine":
         key = (B, H, W, self.dtype, self.training, with_xref)
         eng = self._engines.get(key)
+        if eng is None and self.training and float(getattr(self.config, "dropout", 0.0) or 0.0) > 0:
+            raise DDXError("UNetConfig.dropout > 0: the train-mode forward draws its dropout in the differentiation engine -- call the module "
+                           "with autograd enabled and trainable parameters (dualdiffusion_amd.autograd), or through training.UNetTrainStep")
         if eng is None:
             eng = _UNetEngine(self, B, H, W, self.training, with_xref)
             self._engines[key] = eng

@@ -425,8 +425,9 @@ def linear_small_bwd(dc: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, gr
 
 
 def edm2_loss(denoised: torch.Tensor, target: torch.Tensor, sigma: torch.Tensor, logvar: Optional[torch.Tensor], sigma_data: float,
-              want_grad: bool = True):
-    """Per-sample EDM2 loss [B] (+ d mean(loss)/d denoised, d mean(loss)/d logvar) -- unet_trainer.py:271-282."""
+              want_grad: bool = True, sigma_data_vec: Optional[torch.Tensor] = None):
+    """Per-sample EDM2 loss [B] (+ d mean(loss)/d denoised, d mean(loss)/d logvar) -- unet_trainer.py:271-282; `sigma_data_vec` [B]: the
+    per-sample sigma_data of use_dynamic_sigma_data (:263-269)."""
     B = denoised.shape[0]
     n = denoised.numel() // B
     dev = denoised.device
@@ -434,9 +435,26 @@ def edm2_loss(denoised: torch.Tensor, target: torch.Tensor, sigma: torch.Tensor,
     dd = torch.empty_like(denoised) if want_grad else None
     dlv = torch.empty(B, dtype=torch.float32, device=dev) if (want_grad and logvar is not None) else None
     ws = torch.empty(B, dtype=torch.float32, device=dev)
-    check(lib().ddx_edm2_loss(ptr(denoised), ptr(target), ptr(sigma), ptr(logvar), float(sigma_data), ptr(loss), ptr(dd), ptr(dlv), ptr(ws), B, n,
-                              current_stream()), "edm2_loss")
+    check(lib().ddx_edm2_loss_v(ptr(denoised), ptr(target), ptr(sigma), ptr(logvar), float(sigma_data), ptr(sigma_data_vec), ptr(loss), ptr(dd), ptr(dlv),
+                                ptr(ws), B, n, current_stream()), "edm2_loss")
     return loss, dd, dlv
+
+
+def mp_dropout_(x: torch.Tensor, p: float, seed: int, stream_id: int) -> torch.Tensor:
+    """In place: x <- keep ? x / sqrt(1 - p) : 0 with the keep mask Philox(seed, stream_id, element index) -- the block's magnitude-preserving
+    dropout (unet_edm2_b4.py:124-125) on the activation, and, called again with the same (seed, stream_id), its backward on the gradient."""
+    check(lib().ddx_mp_dropout(ptr(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, dtype_code(x.dtype), current_stream()),
+          "mp_dropout")
+    return x
+
+
+def unet_xref_mix_bwd(d_out: torch.Tensor, d0: torch.Tensor, x_ref: torch.Tensor, want_dxref: bool = True):
+    """Backward of D = mp_sum(x_ref[:, :-1], D0, t = x_ref[:, -1:]) (NCHW fp32): returns (dD0, d x_ref | None)."""
+    B, Cn, H, W = d0.shape
+    dd0 = torch.empty_like(d0)
+    dxr = torch.empty_like(x_ref) if want_dxref else None
+    check(lib().ddx_unet_xref_mix_bwd(ptr(d_out), ptr(d0), ptr(x_ref), ptr(dd0), ptr(dxr), B, Cn, H, W, current_stream()), "xref_mix_bwd")
+    return dd0, dxr
 
 
 def cat2_act(a: torch.Tensor, scale_a: float, b: torch.Tensor, scale_b: float):

@@ -82,6 +82,7 @@ class BlockTape:
     a1: Optional[torch.Tensor] = None
     out_twin: Optional[torch.Tensor] = None
     up_skip: bool = False             # the skip branch ran at the source size (up block)
+    dropout: Optional[tuple] = None   # (p, seed, stream id) of the magnitude-preserving dropout applied to a1 (unet_edm2_b4.py:124-125)
 
 
 def _prep(w: BlockWeightsT, key: str, weight: torch.Tensor, groups: int, dt, **kw):
@@ -137,7 +138,8 @@ def _resample_bwd(dx: torch.Tensor, mode: str) -> torch.Tensor:
 
 def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: float, s1: float, emb: torch.Tensor, w: BlockWeightsT, *,
                         flavor: str, resample: str = "keep", res_t: float = 0.3, clip: float = 256.0, attn_t: float = 0.3,
-                        act0: Optional[torch.Tensor] = None, act1: Optional[torch.Tensor] = None, twin_scale: Optional[float] = None):
+                        act0: Optional[torch.Tensor] = None, act1: Optional[torch.Tensor] = None, twin_scale: Optional[float] = None,
+                        dropout: Optional[tuple] = None):
     """in0 (| in1): NHWC bf16 block input(s) (mp_cat scales s0, s1); emb [B, Cemb] fp32.  Returns (out, tape).
 
     Producer-side activation, as in the inference plan: every conv operand that the reference activates on the fly is stored
@@ -145,7 +147,9 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     writes its output AND (twin_scale given) mp_silu(twin_scale * out) for the consumer -- so all convs stage their operands
     untouched (LDS-DMA kernels) and the backward finds the weight-gradient operands on the tape instead of recomputing them.
     act0 / act1: mp_silu(s0 * in0) / mp_silu(s1 * in1) from the producers (decoder blocks; computed here when absent).
-    tape.out_twin: mp_silu(twin_scale * out) or None."""
+    tape.out_twin: mp_silu(twin_scale * out) or None.
+    dropout = (p, seed, stream id): y = F.dropout(mp_silu(y0 * c), p) * (1 - p)^0.5 (unet_edm2_b4.py:124-125) as an in-place pass over the
+    activated twin, the keep mask a function of (seed, stream id, element) that the backward regenerates."""
     dt, G = in0.dtype, w.groups
     src0 = _resample(in0, resample)
     src1 = _resample(in1, resample) if in1 is not None else None
@@ -189,6 +193,8 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     y0 = torch.empty(src0.shape[:3] + (Cmid,), dtype=dt, device=in0.device)
     a1 = torch.empty_like(y0)
     ops.conv2d(a00, pw["res0"], src1=a01, out=y0, out_scale=c, out2=a1)      # y0 and mp_silu(y0 * c)
+    if dropout is not None and dropout[0] > 0:
+        ops.mp_dropout_(a1, *dropout)
     has_attn = w.attn_qk is not None
     out_twin = None
     tw = {}
@@ -198,6 +204,7 @@ def block_forward_train(in0: torch.Tensor, in1: Optional[torch.Tensor], s0: floa
     out = ops.conv2d(a1, pw["res1"], residual=sk, res_t=res_t, clip=0.0 if has_attn else clip, residual_up=up_skip, **({} if has_attn else tw))
     tape = BlockTape(w, flavor, resample, in0, in1, src0, src1, s0, s1, emb, c, xs, x1, y0, out, res_t, 0.0 if has_attn else clip, pw)
     tape.a00, tape.a01, tape.a1, tape.out_twin, tape.up_skip = a00, a01, a1, out_twin, up_skip
+    tape.dropout = dropout if (dropout is not None and dropout[0] > 0) else None
     if not has_attn:
         return out, tape
     # ---- self-attention: qk = attn_qk(x * c_qk), v = attn_v(x), y = attn_proj(mp_silu(attention * c_v)), x = mp_sum(x, y, t)
@@ -258,7 +265,14 @@ def block_backward(t: BlockTape, dout: torch.Tensor, demb: Optional[torch.Tensor
     g["dw_conv_res1"] = _wgrad(w, "conv_res1", t.pw["res1"], dy1, a1, G, 3)
     # data gradient of conv_res1 through a1 = mp_silu(y0 * c): one launch, the activation backward runs in the conv's epilogue
     dc = w.cvec["dc"] if w.cvec is not None else torch.zeros_like(t.c)
-    dy0, _ = ops.conv2d_dgrad_act(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt), t.y0, chan_scale=t.c, dchan_scale=dc)
+    if t.dropout is not None:
+        # a1 = dropout(mp_silu(y0 * c)): the gradient of the dropped operand gets the same keep / sqrt(1 - p) factor before the activation's
+        # backward (three launches instead of the fused one: the mask sits between the conv and the activation)
+        dA = ops.conv2d(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt))
+        ops.mp_dropout_(dA, *t.dropout)
+        dy0 = ops.silu_scale_bwd(dA, t.y0, t.c, 1.0, dc=dc)
+    else:
+        dy0, _ = ops.conv2d_dgrad_act(dy1, _prep_t(w, "conv_res1", w.conv_res1, G, dt), t.y0, chan_scale=t.c, dchan_scale=dc)
     # c = emb_linear(emb) * emb_gain + 1
     g["dw_emb_linear"], g["demb_gain"] = _linear_bwd(w, "emb_linear", dc, t.emb, w.emb_linear, G, w.emb_gain.reshape(1), demb)
     g["dc"] = dc

@@ -57,11 +57,22 @@ def allreduce_gradients(grads: dict, names: Optional[list] = None) -> dict:
     return out
 
 
+def trainer_options(cfg: dict) -> dict:
+    """UNetTrainStep keyword arguments for the reference `module_trainer_config` options (unet_trainer.py:38-72) that change the objective:
+    input_perturbation, conditioning_perturbation, conditioning_dropout, normalize_latents, use_dynamic_sigma_data (+ min / max / exp)."""
+    check_trainer_config(cfg)
+    kw = dict(input_perturbation=float(cfg.get("input_perturbation", 0.0) or 0.0), conditioning_dropout=float(cfg.get("conditioning_dropout", 0.1)),
+              conditioning_perturbation=float(cfg.get("conditioning_perturbation", 0.0) or 0.0), normalize_latents=bool(cfg.get("normalize_latents", False)))
+    if cfg.get("use_dynamic_sigma_data"):
+        kw["dynamic_sigma_data"] = (float(cfg.get("dynamic_sigma_data_min", 0.2)), float(cfg.get("dynamic_sigma_data_max", 5.0)),
+                                    float(cfg.get("dynamic_sigma_data_exp", 1.0)))
+    return kw
+
+
 def check_trainer_config(cfg: dict) -> None:
     """Reject reference `module_trainer_config` options (unet_trainer.py:38-72) that the HIP train batch does not implement, instead
     of silently training a different objective."""
-    bad = [k for k in ("conditioning_perturbation", "use_dynamic_sigma_data", "normalize_latents", "inpainting_probability")
-           if cfg.get(k) not in (None, 0, 0.0, False)]
+    bad = [k for k in ("inpainting_probability",) if cfg.get(k) not in (None, 0, 0.0, False)]
     if bad:
         raise NotImplementedError(f"UNetTrainStep: trainer options not implemented on the HIP path: {bad}")
 
@@ -183,7 +194,8 @@ class UNetTrainStep:
                  ema: Optional[dict] = None, ema_beta: float = 0.0, input_perturbation: float = 0.0, use_graph: bool = False,
                  gradient_accumulation_steps: int = 1, sigma_sampler=None, conditioning_dropout: float = 0.1,
                  emas: Optional[list] = None, fused_weight_norm: bool = False, trainer=None, optimizer_impl=None,
-                 grad_exchange: Optional[str] = None) -> None:
+                 grad_exchange: Optional[str] = None, conditioning_perturbation: float = 0.0, normalize_latents: bool = False,
+                 dynamic_sigma_data: Optional[tuple] = None) -> None:
         """use_graph: capture the whole train batch (forward, loss, backward: ~1900 launches) into one hipGraph on first use and
         replay it afterwards (static input buffers).  The eager loop needs ~20 ms of host time per step and every host hiccup of
         a shared machine lands in the step time; the replay needs the host for the input copies, one graph launch, the
@@ -191,7 +203,9 @@ class UNetTrainStep:
         emas: list of training.optimizer.EMASpec (power-function / classic / feedback EMAs, reference ema.py); with emas or
         fused_weight_norm the parameter pass after the backward is ONE launch (AdamW + EMAs + feedback + forced weight norm).
         trainer / optimizer_impl: differentiation engine and parameter pass (defaults: the module's own UNetTrainer and
-        FusedAdamW on the HIP kernels; the world_size-2 CPU test passes stubs to drive this class's control flow over gloo)."""
+        FusedAdamW on the HIP kernels; the world_size-2 CPU test passes stubs to drive this class's control flow over gloo).
+        conditioning_perturbation / normalize_latents / dynamic_sigma_data = (min, max, exp): the reference trainer options of the same
+        names (unet_trainer.py:65-72; `trainer_options()` maps a config dict); config.dropout > 0 of the module draws one seed per micro-step."""
         self.unet, self.format, self.lr_cfg = unet, format, lr_schedule
         self.use_graph = use_graph
         self._graph = None
@@ -231,6 +245,12 @@ class UNetTrainStep:
                                                                       FusedAdamW(self.params, optimizer, ema, ema_beta, emas=emas, wn_rows=wn_rows))
         self.emas = list(emas or [])
         self.input_perturbation = input_perturbation
+        self.conditioning_perturbation = float(conditioning_perturbation)
+        self.normalize_latents, self.dynamic_sigma_data = bool(normalize_latents), dynamic_sigma_data
+        self.dropout = float(getattr(getattr(unet, "config", None), "dropout", 0.0) or 0.0)
+        if use_graph and (self.dropout > 0):
+            raise NotImplementedError("UNetTrainStep(use_graph=True) with config.dropout > 0: the dropout seed is a launch argument, a captured "
+                                      "batch would replay one mask (run eagerly)")
         self.accum_steps = int(gradient_accumulation_steps)
         self.sigma_sampler, self.conditioning_dropout = sigma_sampler, conditioning_dropout
         self.global_step = 0
@@ -297,12 +317,23 @@ class UNetTrainStep:
         return self._graph_out
 
     # ------------------------------------------------------------------------------------------------ micro-steps
-    def _micro(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook, split=False):
+    def _extras(self) -> bool:
+        return self.conditioning_perturbation > 0 or self.normalize_latents or self.dynamic_sigma_data is not None or self.dropout > 0
+
+    def _micro(self, samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook, split=False, cond_perturbation=None,
+               dropout_seed=None):
         tr = self.trainer
         tr.bucket_hook = hook
         if self.use_graph:
+            if self._extras():
+                raise NotImplementedError("UNetTrainStep(use_graph=True): conditioning_perturbation / normalize_latents / dynamic_sigma_data / dropout "
+                                          "run on the eager path")
             return self._train_batch_graph(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook, split or hook is not None)
-        return tr.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation, self.input_perturbation)
+        if not self._extras():
+            return tr.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation, self.input_perturbation)
+        return tr.train_batch(samples, audio_embeddings, sigma, noise, conditioning_mask, self.format, perturbation, self.input_perturbation,
+                              conditioning_perturbation=cond_perturbation, conditioning_perturbation_scale=self.conditioning_perturbation,
+                              normalize_latents=self.normalize_latents, dynamic_sigma_data=self.dynamic_sigma_data, dropout_seed=dropout_seed)
 
     def _finish(self, loss, grads, world: int, n_micro: int, ex: Optional[GradientExchange], device_batch: int) -> dict:
         tr = self.trainer
@@ -361,13 +392,15 @@ class UNetTrainStep:
         return GradientExchange(tr.grad_flat, tr.early_numel, self._accum if n_micro > 1 else None, mode=self.grad_exchange) if exchange else None
 
     def step(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
-             conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None) -> dict:
+             conditioning_mask: torch.Tensor, perturbation: Optional[torch.Tensor] = None, cond_perturbation: Optional[torch.Tensor] = None,
+             dropout_seed: Optional[int] = None) -> dict:
         """One optimizer step on this rank's batch, ONE micro-step (the random draws are inputs: the caller owns the generators)."""
         world = _world_size()
         ex = self._exchange(world, 1)
         # the decoder's bucket travels while the encoder is back-propagated (graph mode: between the two captured halves)
         hook = ex.start_early if ex is not None else None
-        loss, grads = self._micro(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook)
+        loss, grads = self._micro(samples, audio_embeddings, sigma, noise, conditioning_mask, perturbation, hook, cond_perturbation=cond_perturbation,
+                                  dropout_seed=dropout_seed)
         return self._finish(loss, grads, world, 1, ex, int(samples.shape[0]))
 
     def run_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, generator: Optional[torch.Generator] = None,
@@ -397,11 +430,14 @@ class UNetTrainStep:
             x = samples[a * Bd:(a + 1) * Bd]
             e = audio_embeddings[a * Bd:(a + 1) * Bd]
             sig = D.strided_slice(gsig, rank, world, a, Bd).to(dev)
+            # the reference's draws in the reference's order (unet_trainer.py:234-257): mask, conditioning perturbation, noise, input perturbation
             mask = torch.rand(Bd, generator=generator, device=generator.device if generator is not None else dev) > self.conditioning_dropout
+            cpert = (torch.randn((Bd, self.unet.cemb), generator=generator, device=mask.device) if self.conditioning_perturbation > 0 else None)
             noise = torch.randn(x.shape, generator=generator, device=mask.device)
             pert = torch.randn(x.shape, generator=generator, device=mask.device) if self.input_perturbation > 0 else None
+            dseed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=mask.device).item()) if self.dropout > 0 else None
             hook = ex.start_early if (ex is not None and last) else None
-            loss, grads = self._micro(x, e, sig, noise, mask, pert, hook, split=ex is not None)
+            loss, grads = self._micro(x, e, sig, noise, mask, pert, hook, split=ex is not None, cond_perturbation=cpert, dropout_seed=dseed)
             if not last:                      # no_sync micro-step: gradients stay local
                 self._accum.add_(self.trainer.grad_flat)
             self.last_gathered.append(D.gather_scalars([loss, sig]))       # one small collective per micro-step

@@ -190,8 +190,15 @@ class UNetTrainer:
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor,
-                perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
+                perturbed_input: Optional[torch.Tensor] = None, x_ref: Optional[torch.Tensor] = None,
+                dropout_seed: Optional[int] = None) -> torch.Tensor:
+        """Training-mode forward with the tape (unet_edm2_b4.py:250-296).  x_ref [B, C + 1, H, W]: the reference blend of the output (:293-294);
+        config.dropout > 0 needs `dropout_seed` (one 64-bit seed per forward; block k draws Philox stream k)."""
         u, cfg, dev, dt = self.u, self.u.config, self.u.device, self.dt
+        p_drop = float(getattr(cfg, "dropout", 0.0) or 0.0)
+        if p_drop > 0 and dropout_seed is None:
+            raise DDXError("UNetTrainer.forward: config.dropout > 0 needs a dropout_seed (the draw of this forward)")
+        drop = (lambda k: (p_drop, int(dropout_seed), k)) if p_drop > 0 else (lambda k: None)
         B, _, H, W = x_in.shape
         G = cfg.mlp_groups
         x_in = x_in.to(dev, torch.float32).contiguous()
@@ -230,7 +237,7 @@ class UNetTrainer:
             if name == "conv_in":
                 continue
             x, t = block_forward_train(x, None, 1.0, 1.0, emb, _block_weights(blk, G, bank, "enc." + name, self.cvecs["enc." + name]), flavor="enc",
-                                       resample=blk.resample_mode, twin_scale=self.skip_twin_scale.get(len(skips)), **kw)
+                                       resample=blk.resample_mode, twin_scale=self.skip_twin_scale.get(len(skips)), dropout=drop(len(tapes)), **kw)
             tapes.append(("enc." + name, blk, t, None))
             skips.append(x)
             skip_tw.append(t.out_twin)
@@ -245,10 +252,11 @@ class UNetTrainer:
                 sk = skips[si]
                 s0, s1 = mp_cat_weights(x.shape[-1], sk.shape[-1], cfg.concat_balance)
                 x, t = block_forward_train(x, sk, s0, s1, emb, bw, flavor="dec", resample=blk.resample_mode, act0=x_tw, act1=skip_tw[si],
-                                           twin_scale=ts, **kw)
+                                           twin_scale=ts, dropout=drop(len(tapes)), **kw)
                 tapes.append(("dec." + name, blk, t, si))
             else:
-                x, t = block_forward_train(x, None, 1.0, 1.0, emb, bw, flavor="dec", resample=blk.resample_mode, act0=x_tw, twin_scale=ts, **kw)
+                x, t = block_forward_train(x, None, 1.0, 1.0, emb, bw, flavor="dec", resample=blk.resample_mode, act0=x_tw, twin_scale=ts,
+                                           dropout=drop(len(tapes)), **kw)
                 tapes.append(("dec." + name, blk, t, None))
             x_tw = t.out_twin
         # conv_out on an 8-row padded weight (4 output channels do not fill a 16-byte NHWC vector)
@@ -261,9 +269,15 @@ class UNetTrainer:
         y8 = ops.conv2d(x, pw_out)
         y = y8[..., :Co].contiguous()
         out = torch.empty(B, Co, H, W, dtype=torch.float32, device=dev)
-        ops.unet_output_combine(y, x_in, sig, None, out, cfg.sigma_data)
+        d0 = xr = None
+        if x_ref is not None:
+            # D = mp_sum(x_ref[:, :-1], D0, t = x_ref[:, -1:]): the unblended D0 stays on the tape for the blend's backward
+            xr = x_ref.to(dev, torch.float32).contiguous()
+            d0 = torch.empty_like(out)
+            ops.unet_output_combine(y, x_in, sig, None, d0, cfg.sigma_data)
+        ops.unet_output_combine(y, x_in, sig, xr, out, cfg.sigma_data)
         self.tape = dict(B=B, H=H, W=W, sig=sig, x0=x0, four=four, pre=pre, emb=emb, pw_in=pw_in, tapes=tapes, n_enc=n_enc, x_last=x,
-                         w_out8=w_out8, pw_out=pw_out, gain=gain, Co=Co)
+                         w_out8=w_out8, pw_out=pw_out, gain=gain, Co=Co, d0=d0, x_ref=xr)
         return out
 
     # ------------------------------------------------------------------------------------------------ backward
@@ -275,6 +289,9 @@ class UNetTrainer:
         grads: dict = {}
         self._scalar_tail.zero_()          # the gain gradients are accumulated with atomics (bank.backward, out_gain)
         self.dc_pool.zero_()               # so are the emb_linear* output gradients (silu_scale_bwd)
+        dD = dD.to(dev, torch.float32).contiguous()
+        if t.get("x_ref") is not None:     # the output was blended with x_ref: gradient of the blend first (d x_ref is returned as grads["x_ref"])
+            dD, grads["x_ref"] = ops.unet_xref_mix_bwd(dD, t["d0"], t["x_ref"])
         # D = c_skip * x_in + c_out * y  ->  dy = c_out[b] * dD, NHWC bf16 with the 4 channels padded to one 16-byte vector
         dy8 = torch.empty(B, H, W, 8, dtype=dt, device=dev)
         check(lib().ddx_unet_output_combine_bwd(ptr(dD.to(dev, torch.float32).contiguous()), ptr(t["sig"]), ptr(dy8), B, Co, H, W, 8, cfg.sigma_data,
@@ -389,25 +406,41 @@ class UNetTrainer:
     # ------------------------------------------------------------------------------------------------ one training batch
     def train_batch(self, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
                     conditioning_mask: torch.Tensor, format, input_perturbation: Optional[torch.Tensor] = None,
-                    input_perturbation_scale: float = 0.0):
-        """The device part of reference UNetTrainer.unet_train_batch (unet_trainer.py:222-296) with the random draws given:
+                    input_perturbation_scale: float = 0.0, *, conditioning_perturbation: Optional[torch.Tensor] = None,
+                    conditioning_perturbation_scale: float = 0.0, normalize_latents: bool = False, dynamic_sigma_data: Optional[tuple] = None,
+                    ref_samples: Optional[torch.Tensor] = None, dropout_seed: Optional[int] = None):
+        """The device part of reference UNetTrainer.train_batch / unet_train_batch (unet_trainer.py:203-296) with the random draws given:
         noise / input_perturbation ~ N(0, 1) like `samples`, conditioning_mask [B] bool, sigma [B].
+        Options of the reference trainer config (all off in config/models/default/training/unet_train.json):
+          normalize_latents (:205-206)         samples <- normalize(samples) per sample
+          conditioning_perturbation (:241-243) embeddings + draw * scale (draw ~ N(0, 1) like the embeddings [B, cemb])
+          dynamic_sigma_data = (min, max, exp) (:263-269) per-sample sigma_data of the loss weight from the RMS of the sample
+          ref_samples                          x_ref of the UNet forward; its gradient comes back as grads["x_ref"]
+          dropout_seed                         the draw of the blocks' dropout (config.dropout > 0)
         Returns (loss [B], grads) where grads holds d mean(loss) / d parameter for EVERY parameter of the module.
-        Not covered (the reference options behind them are off in config/models/default/training/unet_train.json):
-        conditioning_perturbation, use_dynamic_sigma_data, a custom loss_weight -- callers mapping a trainer config onto this path
-        must reject them (training.train_step.check_trainer_config)."""
+        Not covered: a custom loss_weight tensor (the ddec trainer's)."""
         u, cfg, dev = self.u, self.u.config, self.u.device
         B = samples.shape[0]
         samples = samples.to(dev, torch.float32).contiguous()
+        if normalize_latents:
+            samples = ops.pixelnorm(samples.reshape(B, 1, 1, -1)).reshape(samples.shape)
         sig = sigma.flatten().to(dev, torch.float32).contiguous()
         emb, ectx = self.embeddings_forward(audio_embeddings, conditioning_mask)
+        if conditioning_perturbation is not None and conditioning_perturbation_scale > 0:
+            emb = ops.lincomb3(torch.empty_like(emb), emb, 1.0, conditioning_perturbation.to(dev, torch.float32).contiguous(),
+                               float(conditioning_perturbation_scale))
         # model inputs (unet_trainer.py:249-259)
         s4 = sig.view(-1, 1, 1, 1)
         x_in = samples + noise.to(dev, torch.float32) * s4
         pert = x_in + input_perturbation.to(dev, torch.float32) * s4 * input_perturbation_scale if input_perturbation is not None else None
-        denoised = self.forward(x_in, sig, format, emb, pert)
+        denoised = self.forward(x_in, sig, format, emb, pert, x_ref=ref_samples, dropout_seed=dropout_seed)
         logvar, lctx = self.logvar_forward(sig)
-        loss, dD, dlv = ops.edm2_loss(denoised, samples, sig, logvar.view(-1), cfg.sigma_data)
+        sd_vec = None
+        if dynamic_sigma_data is not None:      # [B] glue: RMS of every sample, clipped and raised
+            lo, hi, ex = dynamic_sigma_data
+            n = samples[0].numel()
+            sd_vec = ((torch.linalg.vector_norm(samples, dim=(1, 2, 3)) / n ** 0.5).clip(min=lo, max=hi) ** ex).contiguous()
+        loss, dD, dlv = ops.edm2_loss(denoised, samples, sig, logvar.view(-1), cfg.sigma_data, sigma_data_vec=sd_vec)
         grads = self.backward(dD)
         grads.update(self.logvar_backward(dlv, lctx))
         grads.update(self.embeddings_backward(grads.pop("embeddings"), ectx))

@@ -307,6 +307,19 @@ int ddx_mpconv_wprep_bwd(const ddx_wprep_desc* d, const float* dwp, float* dw, f
  * workspace: B floats. */
 int ddx_edm2_loss(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data, float* loss,
                   float* d_denoised, float* d_logvar, float* workspace, int32_t B, int64_t n_per_sample, ddx_stream stream);
+/* The same with `use_dynamic_sigma_data` (unet_trainer.py:263-269): sigma_data_vec [B] (or NULL: sigma_data) is the per-sample sigma_data of
+ * the loss weight. */
+int ddx_edm2_loss_v(const float* denoised, const float* target, const float* sigma, const float* logvar, float sigma_data,
+                    const float* sigma_data_vec, float* loss, float* d_denoised, float* d_logvar, float* workspace, int32_t B,
+                    int64_t n_per_sample, ddx_stream stream);
+/* Magnitude-preserving dropout of a block's hidden activation in training (unet_edm2_b4.py:124-125: F.dropout(y, p) * (1 - p)^0.5), in place:
+ * x[i] <- keep_i ? x[i] / sqrt(1 - p) : 0.  The keep mask is a pure function of (seed, stream_id, i) (Philox4x32-10): the backward applies the
+ * same call to the gradient tensor of the same shape.  stream_id separates the draws of one step (one per block). */
+int ddx_mp_dropout(void* x, int64_t n, float p, uint64_t seed, uint32_t stream_id, int32_t dtype, ddx_stream stream);
+/* Backward of the x_ref blend of the UNet output, D = mp_sum(x_ref[:, :-1], D0, t = x_ref[:, -1:]) (unet_edm2_b4.py:293-294), NCHW fp32:
+ * d_d0 = d D / d D0 applied to d_out, d_x_ref [B][C + 1][H][W] = the gradient w.r.t. both the reference channels and t (NULL: skipped). */
+int ddx_unet_xref_mix_bwd(const float* d_out_nchw, const float* d0_nchw, const float* x_ref_nchw, float* d_d0_nchw, float* d_x_ref_nchw,
+                          int32_t B, int32_t C, int32_t H, int32_t W, ddx_stream stream);
 /* Backward of the preconditioning output D = c_skip x_in + c_out y (unet_edm2_b4.py:291) w.r.t. y: dy (NHWC, channels zero-padded to
  * Cpad) = c_out(sigma_b) * dD (NCHW fp32). */
 int ddx_unet_output_combine_bwd(const float* d_out_nchw, const float* sigma, void* dy_nhwc, int32_t B, int32_t C, int32_t H, int32_t W,

@@ -123,8 +123,10 @@ def attention_2d(qk: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
 
 def block_forward(sd: dict, prefix: str, x: torch.Tensor, emb: torch.Tensor, *, flavor: str, resample: str,
                   attention: bool, heads: int, groups: int, res_balance: float = 0.3, attn_balance: float = 0.3,
-                  clip: Optional[float] = 256.0, training: bool = False) -> torch.Tensor:
-    """modules/unets/unet_edm2_b4.py:110-158 (dropout = 0 on this path)."""
+                  clip: Optional[float] = 256.0, training: bool = False, dropout: float = 0.0,
+                  dropout_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """modules/unets/unet_edm2_b4.py:110-158.  Dropout (:124-125, training only): `dropout_mask` is the keep mask (1 = kept) of the
+    draw, shaped like the hidden tensor -- torch's dropout scales the kept values by 1 / (1 - p), the block then by (1 - p)^0.5."""
     def W(name):
         return sd[f"{prefix}.{name}.weight"]
 
@@ -135,6 +137,9 @@ def block_forward(sd: dict, prefix: str, x: torch.Tensor, emb: torch.Tensor, *, 
     y = conv_mp(silu_mp(x), W("conv_res0"), groups=groups, training=training)
     c = conv_mp(emb, W("emb_linear"), gain=sd[f"{prefix}.emb_gain"], groups=groups, training=training) + 1.0
     y = silu_mp(y * c)
+    if dropout != 0 and training:
+        assert dropout_mask is not None and dropout_mask.shape == y.shape, "training with dropout needs the keep mask of the draw"
+        y = y * dropout_mask.to(y.dtype) / (1.0 - dropout) * (1.0 - dropout) ** 0.5
     y = conv_mp(y, W("conv_res1"), groups=groups, training=training)
     if flavor == "dec":
         x = conv_mp(x, W("conv_skip"), training=training)
@@ -307,9 +312,10 @@ def unet_sigma_logvar(sd: dict, cfg: dict, sigma: torch.Tensor) -> torch.Tensor:
 def unet_forward(sd: dict, cfg: dict, x_in: torch.Tensor, sigma: torch.Tensor, embeddings: torch.Tensor,
                  freq_range: tuple[float, float] = (20.0, 16000.0), x_ref: Optional[torch.Tensor] = None,
                  perturbed_input: Optional[torch.Tensor] = None, training: bool = False,
-                 collect: Optional[dict] = None) -> torch.Tensor:
+                 collect: Optional[dict] = None, dropout_masks: Optional[dict] = None) -> torch.Tensor:
     """unet_edm2_b4.py:250-296.  `freq_range` = (freq_min, freq_max) of format.ms_freq_scale (mel scale).
-    `collect`, if given, receives every stage output by name (for layer-level parity tests)."""
+    `collect`, if given, receives every stage output by name (for layer-level parity tests).
+    `dropout_masks` (training with cfg["dropout"] > 0): {"enc.<block>" | "dec.<block>": keep mask of that block's draw}."""
     topo = unet_topology(cfg)
     sdata = cfg["sigma_data"]
     sig = sigma.float().view(-1, 1, 1, 1)
@@ -330,14 +336,15 @@ def unet_forward(sd: dict, cfg: dict, x_in: torch.Tensor, sigma: torch.Tensor, e
     x = torch.cat([x, torch.ones_like(x[:, :1]), ln_freq_channel(h, w, b, *freq_range)], dim=1)
     heads_of = lambda cout: cout // cfg["channels_per_head"]
     kw = dict(groups=cfg["mlp_groups"], res_balance=cfg["res_balance"], attn_balance=cfg["attn_balance"],
-              training=training)
+              training=training, dropout=cfg.get("dropout", 0.0))
+    dm = dropout_masks or {}
     skips = []
     for st in topo["enc"]:
         if st["kind"] == "conv_in":
             x = conv_mp(x, sd["enc.conv_in.weight"], training=training)
         else:
             x = block_forward(sd, f"enc.{st['name']}", x, emb, flavor="enc", resample=st["resample"],
-                              attention=st["attention"], heads=heads_of(st["cout"]), **kw)
+                              attention=st["attention"], heads=heads_of(st["cout"]), dropout_mask=dm.get(f"enc.{st['name']}"), **kw)
         skips.append(x)
         if collect is not None:
             collect[f"enc.{st['name']}"] = x
@@ -345,7 +352,7 @@ def unet_forward(sd: dict, cfg: dict, x_in: torch.Tensor, sigma: torch.Tensor, e
         if st["skip_in"]:
             x = cat_mp(x, skips.pop(), cfg["concat_balance"])
         x = block_forward(sd, f"dec.{st['name']}", x, emb, flavor="dec", resample=st["resample"],
-                          attention=st["attention"], heads=heads_of(st["cout"]), **kw)
+                          attention=st["attention"], heads=heads_of(st["cout"]), dropout_mask=dm.get(f"dec.{st['name']}"), **kw)
         if collect is not None:
             collect[f"dec.{st['name']}"] = x
     x = conv_mp(x, sd["conv_out.weight"], gain=sd["out_gain"], training=training)
@@ -357,16 +364,30 @@ def unet_forward(sd: dict, cfg: dict, x_in: torch.Tensor, sigma: torch.Tensor, e
 
 def unet_train_loss(sd: dict, cfg: dict, samples: torch.Tensor, audio_embeddings: torch.Tensor, sigma: torch.Tensor, noise: torch.Tensor,
                     cond_mask: torch.Tensor, input_perturbation: Optional[torch.Tensor] = None, input_perturbation_scale: float = 0.0,
-                    freq_range: tuple[float, float] = (20.0, 16000.0)) -> torch.Tensor:
-    """Device part of training/module_trainers/unet_trainer.py:222-296 (`unet_train_batch`, train branch) with the random draws
-    given: get_embeddings :236, noised / perturbed input :249-259, UNet forward in training mode :261, loss weight and MSE
-    :271-276, Gaussian NLL with the learned per-sigma log-variance :280-282.  Returns the per-sample loss [B]."""
+                    freq_range: tuple[float, float] = (20.0, 16000.0), *, conditioning_perturbation: Optional[torch.Tensor] = None,
+                    conditioning_perturbation_scale: float = 0.0, normalize_latents: bool = False, dynamic_sigma_data: Optional[tuple] = None,
+                    ref_samples: Optional[torch.Tensor] = None, dropout_masks: Optional[dict] = None) -> torch.Tensor:
+    """Device part of training/module_trainers/unet_trainer.py:203-296 (`train_batch` / `unet_train_batch`, train branch) with the random
+    draws given: normalize_latents :205-206, get_embeddings :236, conditioning_perturbation :241-243 (embeddings + draw * scale),
+    noised / perturbed input :249-259, UNet forward in training mode :261 (`ref_samples` = x_ref, `dropout_masks` the keep masks of the
+    blocks' dropout draws), loss weight and MSE :271-276 with use_dynamic_sigma_data :263-269 (`dynamic_sigma_data` = (min, max, exp)),
+    Gaussian NLL with the learned per-sigma log-variance :280-282.  Returns the per-sample loss [B]."""
+    if normalize_latents:
+        samples = rms_normalize(samples).float()
     emb = unet_embeddings(sd, cfg, audio_embeddings, cond_mask, training=True)
+    if conditioning_perturbation is not None and conditioning_perturbation_scale > 0:
+        emb = emb + conditioning_perturbation * conditioning_perturbation_scale
     s4 = sigma.float().view(-1, 1, 1, 1)
     x_in = samples + noise * s4
     pert = x_in + input_perturbation * s4 * input_perturbation_scale if input_perturbation is not None else None
-    denoised = unet_forward(sd, cfg, x_in, sigma, emb, freq_range, perturbed_input=pert, training=True)
-    sdata = cfg["sigma_data"]
+    denoised = unet_forward(sd, cfg, x_in, sigma, emb, freq_range, x_ref=ref_samples, perturbed_input=pert, training=True,
+                            dropout_masks=dropout_masks)
+    if dynamic_sigma_data is not None:
+        lo, hi, ex = dynamic_sigma_data
+        n = samples.shape[1] * samples.shape[2] * samples.shape[3]
+        sdata = (torch.linalg.vector_norm(samples, dim=(1, 2, 3), keepdim=True) / n ** 0.5).clip(min=lo, max=hi) ** ex
+    else:
+        sdata = cfg["sigma_data"]
     w = (s4 ** 2 + sdata ** 2) / (s4 * sdata) ** 2
     wl = (F.mse_loss(denoised, samples, reduction="none") * w).mean(dim=(1, 2, 3))
     logvar = unet_sigma_logvar(sd, cfg, sigma).flatten()

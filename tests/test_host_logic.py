@@ -165,3 +165,30 @@ def test_module_forwards_are_single_custom_ops_under_torch_compile():
         assert tuple(out.shape) == (2, 4, 16, 32) and out.dtype == torch.float32
         lat = CO.vae_encode(torch.empty(2, 2, 64, 128), torch.empty(2, vae.emb_dim), CO.handle_of(vae), CO.handle_of(fmt))
         assert tuple(lat.shape) == tuple(vae.get_latent_shape((2, 2, 64, 128)))
+
+
+def test_trainer_options_mapping():
+    """The reference `module_trainer_config` options that change the objective map onto UNetTrainStep keyword arguments (unet_trainer.py:38-72);
+    what is not built is refused, not ignored."""
+    import pytest
+    from dualdiffusion_amd.training.train_step import check_trainer_config, trainer_options
+    kw = trainer_options({"input_perturbation": 0.1, "conditioning_perturbation": 0.05, "conditioning_dropout": 0.2, "normalize_latents": True,
+                          "use_dynamic_sigma_data": True, "dynamic_sigma_data_min": 0.3, "dynamic_sigma_data_max": 4.0, "dynamic_sigma_data_exp": 0.5,
+                          "num_loss_buckets": 12})
+    assert kw == dict(input_perturbation=0.1, conditioning_dropout=0.2, conditioning_perturbation=0.05, normalize_latents=True,
+                      dynamic_sigma_data=(0.3, 4.0, 0.5))
+    assert "dynamic_sigma_data" not in trainer_options({"use_dynamic_sigma_data": False})
+    with pytest.raises(NotImplementedError):
+        check_trainer_config({"inpainting_probability": 0.5})
+
+
+def test_unet_config_accepts_dropout():
+    """UNetConfig.dropout is a training-time option of the blocks (unet_edm2_b4.py:124-125): the module builds with it (the differentiation engine
+    applies it), out-of-range values are rejected."""
+    import pytest
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    over = dict(model_channels=32, channel_mult=[1, 2], num_layers_per_block=1, attn_levels=[1], channels_per_head=32, in_channels_emb=16)
+    u = UNet(UNetConfig(dropout=0.1, **over))
+    assert u.config.dropout == 0.1
+    with pytest.raises(ValueError):
+        UNet(UNetConfig(dropout=1.0, **over))

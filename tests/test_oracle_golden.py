@@ -231,3 +231,32 @@ def test_dae_g1_golden():
     assert rel_l2(DO.dae_encode(sd, cfg, t["x"], emb, normalize_latents=False), t["latents_raw"]) < 1e-5
     assert rel_l2(DO.dae_decode(sd, cfg, t["latents"], emb), t["recon"]) < 1e-5
     assert rel_l2(DO.dae_tiled_encode(sd, cfg, t["x_tiled"], emb[:1], **m["tiled"]), t["latents_tiled"]) < 1e-5
+
+
+def test_train_options_golden():
+    """Oracle train batch with the trainer / model options that are off by default -- dropout (recorded keep masks of the reference's draws),
+    conditioning_perturbation, normalize_latents, use_dynamic_sigma_data, x_ref under autograd -- against the reference's loss, parameter
+    gradients and d loss / d x_ref (tests/golden/unet_train_options.safetensors; unet_trainer.py:203-296, unet_edm2_b4.py:124-125,293-294)."""
+    t, m = load_golden("unet_train_options")
+    cfg = O.unet_cfg(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in m["cfg"].items()})
+    sd = O.random_unet_state(cfg, seed=m["seed"], gain_value=m["gain_value"], normalized=False)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "fourier" not in k}
+    sd_o = dict(sd); sd_o.update(params)
+    xr = t["x_ref"].clone().requires_grad_(True)
+    masks = {k[len("dropout_mask."):]: v.bool() for k, v in t.items() if k.startswith("dropout_mask.")}
+    assert abs(torch.cat([v.flatten().float() for v in masks.values()]).mean().item() - (1 - cfg["dropout"])) < 0.02
+    loss = O.unet_train_loss(sd_o, cfg, t["latents"], t["clap"], t["sigma"], t["noise"], t["mask"].bool(), t["pert"], m["input_perturbation"],
+                             conditioning_perturbation=t["cpert"], conditioning_perturbation_scale=m["conditioning_perturbation"],
+                             normalize_latents=m["normalize_latents"], dynamic_sigma_data=tuple(m["dynamic_sigma_data"]), ref_samples=xr,
+                             dropout_masks=masks)
+    assert rel_l2(loss.detach(), t["loss"]) < 1e-5
+    names = m["grads"]
+    g = torch.autograd.grad(loss.mean(), [params[k] for k in names] + [xr])
+    for k, gk in zip(names, g[:-1]):
+        assert rel_l2(gk, t[f"grad.{k}"]) < 1e-3, k
+    assert rel_l2(g[-1], t["grad_x_ref"]) < 1e-4
+    # every option changes the objective: switching one off moves the loss
+    base = float(loss.detach().mean())
+    off = O.unet_train_loss(sd, cfg, t["latents"], t["clap"], t["sigma"], t["noise"], t["mask"].bool(), t["pert"], m["input_perturbation"],
+                            normalize_latents=True, dynamic_sigma_data=tuple(m["dynamic_sigma_data"]), ref_samples=t["x_ref"], dropout_masks=masks)
+    assert abs(float(off.mean()) - base) > 1e-6 * abs(base)

@@ -629,6 +629,95 @@ def gen_train() -> None:
                                grads=keep, freq_range=[20.0, 16000.0]))
 
 
+def gen_train_options() -> None:
+    """The trainer / model options of the UNet train batch that are off by default: `dropout` inside the blocks (unet_edm2_b4.py:124-125; the
+    keep masks of torch's draws are recorded and shipped), `conditioning_perturbation` (unet_trainer.py:241-243), `normalize_latents` (:205-206),
+    `use_dynamic_sigma_data` (:263-269) and a `ref_samples` / x_ref blend under autograd (unet_edm2_b4.py:293-294) -- the reference's own lines
+    on given draws -> per-sample loss, parameter gradients and the gradient with respect to x_ref."""
+    print("train options")
+    import torch.nn.functional as F
+    from modules.mp_tools import normalize
+    cfg = O.unet_cfg(model_channels=64, channel_mult=(1, 2), attn_levels=(1,), channels_per_head=32, num_layers_per_block=1,
+                     in_channels_emb=32, logvar_channels=16, dropout=0.2, mlp_groups=2)
+    unet = make_ref_unet(cfg)
+    sd = O.random_unet_state(cfg, seed=9, gain_value=0.5, normalized=False)
+    unet.load_state_dict(sd)
+    unet.requires_grad_(True)
+    unet.train(True)
+    fmt = FakeFormat()
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 2, 16, 32
+    latents = torch.randn(B, 4, H, W, generator=g) * 1.7
+    noise, pert = torch.randn(B, 4, H, W, generator=g), torch.randn(B, 4, H, W, generator=g)
+    sigma = torch.tensor([0.4, 9.0])
+    clap = torch.randn(B, 32, generator=g)
+    mask = torch.tensor([False, True])
+    cpert = torch.randn(B, unet.emb_label.weight.shape[0], generator=g)
+    x_ref = torch.cat((torch.randn(B, 4, H, W, generator=g), torch.rand(B, 1, H, W, generator=g) * 0.8 + 0.1), dim=1).requires_grad_(True)
+    cp_scale, ip_scale, dyn = 0.15, 0.3, (0.2, 5.0, 1.0)
+    # record the keep mask of every dropout draw, in call order (one per block: enc stages then dec stages)
+    masks, real_dropout = [], F.dropout
+
+    def recording_dropout(x, p=0.5, training=True, inplace=False):
+        y = real_dropout(x, p=p, training=training)
+        masks.append((y != 0) | (x == 0))
+        return y
+    F.dropout = torch.nn.functional.dropout = recording_dropout
+    try:
+        torch.manual_seed(77)
+        # the lines of train_batch / unet_train_batch, with the draws above in place of the device generator
+        samples = normalize(latents).float().detach()                                  # normalize_latents
+        emb = unet.get_embeddings(clap, mask)
+        emb = emb + cpert * cp_scale                                                     # conditioning_perturbation
+        s4 = sigma.view(-1, 1, 1, 1)
+        x_in = samples + noise * s4
+        perturbed = x_in + pert * s4 * ip_scale
+        denoised = unet(x_in, sigma, fmt, emb, x_ref, perturbed)
+    finally:
+        F.dropout = torch.nn.functional.dropout = real_dropout
+    n = samples.shape[1] * samples.shape[2] * samples.shape[3]
+    sdata = (torch.linalg.vector_norm(samples, dim=(1, 2, 3), keepdim=True) / n ** 0.5).clip(min=dyn[0], max=dyn[1]) ** dyn[2]   # use_dynamic_sigma_data
+    w = (s4 ** 2 + sdata ** 2) / (s4 * sdata) ** 2
+    wl = (F.mse_loss(denoised, samples, reduction="none") * w).mean(dim=(1, 2, 3))
+    logvar = unet.get_sigma_loss_logvar(sigma=sigma)
+    loss = wl / logvar.exp().flatten() + logvar.flatten()
+    loss.mean().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in unet.named_parameters()}
+    topo = O.unet_topology(cfg)
+    names = [f"enc.{st['name']}" for st in topo["enc"] if st["kind"] == "block"] + [f"dec.{st['name']}" for st in topo["dec"]]
+    assert len(masks) == len(names), (len(masks), len(names))
+    dmasks = dict(zip(names, masks))
+    keep_rate = float(torch.cat([m.flatten().float() for m in masks]).mean())
+    assert abs(keep_rate - 0.8) < 0.02, keep_rate
+    # oracle on the same draws and masks
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "fourier" not in k}
+    sd_o = dict(sd); sd_o.update(params)
+    xr_o = x_ref.detach().clone().requires_grad_(True)
+    loss_o = O.unet_train_loss(sd_o, cfg, latents, clap, sigma, noise, mask, pert, ip_scale, conditioning_perturbation=cpert,
+                               conditioning_perturbation_scale=cp_scale, normalize_latents=True, dynamic_sigma_data=dyn, ref_samples=xr_o,
+                               dropout_masks=dmasks)
+    go = torch.autograd.grad(loss_o.mean(), list(params.values()) + [xr_o])
+    grads_o = dict(zip(params, go[:-1]))
+    check("train-options loss", loss_o.detach(), loss.detach(), 1e-5)
+    worst = max(rel_l2(grads_o[k], ref_grads[k]) for k in ref_grads)
+    print(f"    oracle vs reference  train-option gradients ({len(ref_grads)} parameters)  worst rel-L2 {worst:.2e}")
+    assert worst < 1e-3, worst
+    check("train-options d/d x_ref", go[-1], x_ref.grad, 1e-4)
+    keep = ["enc.conv_in.weight", "enc.block0_layer0.conv_res1.weight", "enc.block1_layer0.attn_proj.weight", "dec.block1_in0.conv_res0.weight",
+            "dec.block0_layer0.conv_skip.weight", "dec.block0_up.emb_linear.weight", "dec.block0_layer0.emb_gain", "conv_out.weight", "out_gain",
+            "emb_label.weight", "logvar_linear.weight"]
+    t = {"latents": latents, "noise": noise, "pert": pert, "cpert": cpert, "sigma": sigma, "clap": clap, "mask": mask.to(torch.uint8),
+         "x_ref": x_ref.detach(), "loss": loss.detach(), "grad_x_ref": x_ref.grad.detach()}
+    for k, m in dmasks.items():
+        t[f"dropout_mask.{k}"] = m.to(torch.uint8)
+    for k in keep:
+        t[f"grad.{k}"] = ref_grads[k]
+    save("unet_train_options", t, dict(cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, seed=9, gain_value=0.5,
+                                       input_perturbation=ip_scale, conditioning_perturbation=cp_scale, dynamic_sigma_data=list(dyn), normalize_latents=True,
+                                       weights="oracle.random_unet_state(cfg, seed, gain_value, normalized=False)", grads=keep, freq_range=[20.0, 16000.0],
+                                       dropout_keep_rate=keep_rate))
+
+
 def gen_ema() -> None:
     """The parameter pass after the backward as the reference runs it (trainer.py:1027-1108): clip_grad_norm_ + torch.optim.AdamW,
     EMA_Manager.update (ema.py:284-321: classic EMA with warm-up, power-function EMA, feedback EMA, in this order), forced weight
@@ -1016,7 +1105,7 @@ def R_normalize(x):
     return normalize(x)
 
 
-GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default, "loader": gen_loader, "config5_b16": gen_config5_b16}
+GENS = {"ops": gen_ops, "blocks": gen_blocks, "unet": gen_unet, "unet_default": gen_unet_default, "schedule": gen_schedule, "sampler": gen_sampler, "vae": gen_vae, "mel": gen_mel, "msmel": gen_msmel, "sigma": gen_sigma, "mss": gen_mss, "train": gen_train, "train_options": gen_train_options, "ema": gen_ema, "dae": gen_dae, "ddec": gen_ddec, "vae_default": gen_vae_default, "ddec_default": gen_ddec_default, "dae_default": gen_dae_default, "loader": gen_loader, "config5_b16": gen_config5_b16}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
