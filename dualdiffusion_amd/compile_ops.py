@@ -22,30 +22,45 @@ import torch
 
 from ._lib import DDXError
 
-# handle -> weak reference (strong where the type has no weak references).  Dynamo traces `handle_of` itself (id() and a global dict
-# store are supported), but the store is a DEFERRED side effect: while the caller is being traced the fake implementations see the
-# handle before the registry does.  `_get` then looks the id up among the live, GC-tracked objects (the traced caller holds the
-# object, so it is there) -- never by casting the integer to a pointer: a stale or foreign handle raises instead of being dereferenced.
+# handle -> (weak reference, type).  Dynamo traces `handle_of` itself (id() and a global dict store are supported), but the store is a
+# DEFERRED side effect: while the caller is being traced the fake implementations see the handle before the registry does.  `_get` then
+# looks the id up among the live, GC-tracked objects (the traced caller holds the object, so it is there) -- never by casting the integer
+# to a pointer: a stale or foreign handle raises instead of being dereferenced.
+# Lifetime: an entry dies WITH its object (weak-reference callback), so an id() that CPython hands to a new object later cannot resolve to
+# the old slot, and nothing is kept alive by the registry.  Objects of types without weak references (none of the package's module /
+# format classes) are held strongly until `release()`.
 _OBJECTS: dict = {}
 
 
 def handle_of(obj) -> int:
     """Integer handle of a module / format object."""
     h = id(obj)
+    cur = _OBJECTS.get(h)
+    if cur is not None and cur[0]() is obj:
+        return h
     try:
-        _OBJECTS[h] = weakref.ref(obj)
+        _OBJECTS[h] = (weakref.ref(obj, lambda _r, h=h: _OBJECTS.pop(h, None)), type(obj))
     except TypeError:
-        _OBJECTS[h] = lambda o=obj: o
+        _OBJECTS[h] = ((lambda o=obj: o), type(obj))
     return h
 
 
+def release(obj) -> None:
+    """Drop the registry entry of `obj` (only needed for objects whose type has no weak references)."""
+    _OBJECTS.pop(id(obj), None)
+
+
 def _get(h: int):
-    ref = _OBJECTS.get(h, None)
-    obj = ref() if ref is not None else None
+    ent = _OBJECTS.get(h, None)
+    obj = ent[0]() if ent is not None else None
+    if obj is not None and type(obj) is not ent[1]:        # (cannot happen with the death callback; a foreign object under a recycled id)
+        obj = None
     if obj is None:
         _OBJECTS.pop(h, None)
+        # tracing: the handle precedes the registry store (see above).  One scan of the GC-tracked objects per unknown handle -- the hit is
+        # registered, so a trace pays it once per module, not once per fake call
         import gc
-        obj = next((o for o in gc.get_objects() if id(o) == h), None)
+        obj = next((o for o in gc.get_objects() if id(o) == h and (hasattr(o, "config") or hasattr(o, "ms_freq_scale") or hasattr(o, "_forward_plan"))), None)
         if obj is None:
             raise DDXError(f"dualdiffusion_amd custom op: unknown or expired module handle {h} (the module a compiled graph was traced "
                            "with must stay alive, and handles come from compile_ops.handle_of)")
