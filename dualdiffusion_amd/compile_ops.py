@@ -35,8 +35,13 @@ _OBJECTS: dict = {}
 def handle_of(obj) -> int:
     """Integer handle of a module / format object."""
     h = id(obj)
+    if torch.compiler.is_compiling():
+        # traced by Dynamo: a plain (deferred) store and nothing that reads the registry -- a read would become a guard on the dict's
+        # contents that the deferred store itself breaks.  `_get` upgrades the entry (death callback, type) the first time it resolves it.
+        _OBJECTS[h] = (weakref.ref(obj), None)
+        return h
     cur = _OBJECTS.get(h)
-    if cur is not None and cur[0]() is obj:
+    if cur is not None and cur[1] is not None and cur[0]() is obj:
         return h
     try:
         _OBJECTS[h] = (weakref.ref(obj, lambda _r, h=h: _OBJECTS.pop(h, None)), type(obj))
@@ -53,7 +58,9 @@ def release(obj) -> None:
 def _get(h: int):
     ent = _OBJECTS.get(h, None)
     obj = ent[0]() if ent is not None else None
-    if obj is not None and type(obj) is not ent[1]:        # (cannot happen with the death callback; a foreign object under a recycled id)
+    if obj is not None and ent[1] is None:                 # stored while tracing: give it the death callback and its type now
+        handle_of(obj)
+    elif obj is not None and type(obj) is not ent[1]:      # (cannot happen with the death callback; a foreign object under a recycled id)
         obj = None
     if obj is None:
         _OBJECTS.pop(h, None)
