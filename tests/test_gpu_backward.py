@@ -359,7 +359,10 @@ def test_sharded_adamw_hip_matches_fused():
             EMASpec(name="b", tensors={k: v.clone().cuda() for k, v in init.items()}, beta=0.9, feedback_beta=0.95)]
     calls = []
     sh = ShardedAdamW([(k, params[k]) for k in order], flat, views, [(0, early), (early, total - early)], cfg, emas=em_s, normalize=lambda: calls.append(1))
-    assert sh.use_hip and sh.tails[0][1] - sh.tails[0][0] == early % 64
+    # segment 0 ends off the 64-element grid (9708 = 151 x 64 + 44): its tail is replicated, and segment 1 -- which starts off the grid -- gets a
+    # replicated head up to the next multiple of 64 so that its shard, like every shard, starts 256-byte aligned in the bucket
+    assert sh.use_hip and sum(hi - lo for lo, hi in sh.tails[0]) == early % 64
+    assert sh.tails[1][0] == (early, (early + 63) // 64 * 64) and all(lo % 64 == 0 for (_s, S, lo, _hi) in sh.shards if S > 0)
     for step in range(4):
         grads = {k: torch.randn(s, generator=g) * (0.002 if step % 2 else 0.02) for k, s in shapes.items()}
         betas = [0.99, 0.9]

@@ -32,5 +32,8 @@ stats train python $root/tools/train_bench.py 8 3
 # BASELINE configs[4] as quoted: B = 16, 100 steps (CFG + Heun), VAE decode, 200 FGLA iterations (the tool's own timing line only)
 python $root/tools/pipeline_bench.py 16 100 200 > $out/${tag}_pipeline_b16.log 2>&1; tail -1 $out/${tag}_pipeline_b16.log
 python $root/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $out/${tag}_train_bench.json 2> $out/${tag}_train_bench.err; cat $out/${tag}_train_bench.json
+# BASELINE configs[2] and configs[4] as bench.py lines (per-stage device times inside)
+python $root/bench.py --mode config3 > $out/${tag}_config3.json 2> $out/${tag}_config3.err; cat $out/${tag}_config3.json
+python $root/bench.py --mode sample > $out/${tag}_config5.json 2> $out/${tag}_config5.err; cat $out/${tag}_config5.json
 # every tool's own timing line in one file
-( for n in fgla msmel mss vae pipeline pipeline_b16 ddec train; do echo "== $n"; grep -v -E 'amdgpu.ids|rocprofv3|output_stream|simple_timer|^[WEI]20[0-9]{6} ' $out/${tag}_${n}.log | tail -6; done; echo "== graph purity (tools/graph_purity.py on the pipeline kernel trace)"; python $root/tools/graph_purity.py $out/${tag}_pipeline_stats/x_kernel_trace.csv; echo "== bench.py --mode train"; cat $out/${tag}_train_bench.json ) > $out/${tag}_secondary_timings.txt
+( for n in fgla msmel mss vae pipeline pipeline_b16 ddec train; do echo "== $n"; grep -v -E 'amdgpu.ids|rocprofv3|output_stream|simple_timer|^[WEI]20[0-9]{6} ' $out/${tag}_${n}.log | tail -6; done; echo "== graph purity (tools/graph_purity.py on the pipeline kernel trace)"; python $root/tools/graph_purity.py $out/${tag}_pipeline_stats/x_kernel_trace.csv; echo "== bench.py --mode train"; cat $out/${tag}_train_bench.json; echo "== bench.py --mode config3"; cat $out/${tag}_config3.json; echo "== bench.py --mode sample"; cat $out/${tag}_config5.json ) > $out/${tag}_secondary_timings.txt
