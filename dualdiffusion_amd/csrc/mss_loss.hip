@@ -119,7 +119,18 @@ __global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p)
   cf* Bt = A + ASZ;
   __shared__ float red[kRegNT / 64];
   const int tid = threadIdx.x;
-  const int b = blockIdx.z, by = blockIdx.y, bx0 = blockIdx.x * NBLK;
+  // Workgroup -> block: neighbouring blocks share (W - step) / W of their pixels, and workgroups are dealt round-robin to the 8 XCDs, so a
+  // plain (x, y) grid makes every XCD's L2 fetch the whole image (r04: 2.3 GB fetched per width-64 launch for 45 MB of images).  Here XCD x
+  // (= linear id & 7) owns ONE contiguous range of the block list, ordered down the block columns first: the workgroups an XCD has in
+  // flight are vertical neighbours, the next ones the column beside.
+  const int gx = (p.nbw + NBLK - 1) / NBLK, nwg = gx * p.nbh;
+  int lin = blockIdx.x;
+  {
+    const int base = nwg >> 3, rem = nwg & 7, x = lin & 7;
+    lin = x * base + min(x, rem) + (lin >> 3);
+  }
+  const int bxg = lin / p.nbh;
+  const int b = blockIdx.z, by = lin - bxg * p.nbh, bx0 = bxg * NBLK;
   const size_t plane = (size_t)p.H * p.Wd;
   const float* sL = p.sample + (size_t)b * 2 * plane; const float* sR = sL + plane;
   const float* tL = p.target + (size_t)b * 2 * plane; const float* tR = tL + plane;
@@ -272,7 +283,7 @@ static int launch_mss_reg(const MssParams& p, hipStream_t s) {
       return set_error(DDX_ERR_LAUNCH, "hipFuncSetAttribute(mss_loss_reg)");
     attr_done = true;
   }
-  dim3 grid(ceil_div(p.nbw, NBLK), p.nbh, p.B);
+  dim3 grid(ceil_div(p.nbw, NBLK) * p.nbh, 1, p.B);     // (1-D over the blocks of an image: the kernel maps it XCD-contiguously)
   hipLaunchKernelGGL(kern, grid, dim3(kRegNT), smem, s, p);
   return check_launch("mss_loss_reg");
 }
