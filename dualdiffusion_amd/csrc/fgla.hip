@@ -54,6 +54,14 @@ constexpr int kFN = 6400;
 constexpr int kFNT = DDX_FGLA_NT;
 constexpr int kFMinWaves = DDX_FGLA_MINWAVES;   // (__launch_bounds__ second argument = min waves per SIMD: 4 -> <= 128 VGPRs)
 
+// Frame of a workgroup.  Consecutive frames share 24 / 25 of the audio they read (hop 256 of a 6400-sample window) and workgroups are dealt
+// round-robin to the 8 XCDs: with t = blockIdx.x every XCD's L2 fetches the whole waveform.  XCD x (= blockIdx.x & 7) takes one contiguous
+// eighth of the frames instead (round 5; the same remedy as the conv tiles and the MSS blocks).
+__device__ __forceinline__ int fgla_frame_of_block(int T) {
+  const int id = blockIdx.x, base = T >> 3, rem = T & 7, x = id & 7;
+  return x * base + min(x, rem) + (id >> 3);
+}
+
 struct FglaSynthParams {
   const float2* u;                          // [B][T][C][ustride] state, NB valid per row (nullptr: angles = 1)
   const float* mags;                        // [B][C][T][mstride]
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_synth_kernel(const Fgla
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int t = fgla_frame_of_block(p.T), b = blockIdx.y, tid = threadIdx.x;
   DDX_FT_BEGIN();
   const size_t sbase = ((size_t)b * p.T + t) * p.C * p.ustride;
   // two bins per lane: rows of the state (ustride even) and of the magnitudes (mstride even) start 16 / 8-byte aligned,
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_analysis_kernel(const F
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int t = fgla_frame_of_block(p.T), b = blockIdx.y, tid = threadIdx.x;
   DDX_FT_BEGIN();
   const float* aL = p.audio + (size_t)b * p.C * p.L;
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(kFNT, kFMinWaves) void fgla_iter_kernel(const FglaI
   constexpr int N = kFN, NB = N / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cf* bufA = reinterpret_cast<cf*>(smem);
-  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int t = fgla_frame_of_block(p.T), b = blockIdx.y, tid = threadIdx.x;
   const float* aL = p.audio + (size_t)b * p.C * p.L;
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
   const int base = t * p.hop - N / 2;

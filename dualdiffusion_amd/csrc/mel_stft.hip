@@ -42,7 +42,14 @@ __global__ __launch_bounds__(kNT, 4) void mel_stft_kernel(const MelStftParams p)
   cf* bufA = reinterpret_cast<cf*>(smem);
   float* sOut = reinterpret_cast<float*>(bufA + kFft6400RegEntries);   // [C * n_mel][kFPW]
   const int b = blockIdx.y;
-  const int f0 = blockIdx.x * kFPW;
+  // (XCD-contiguous frame groups: workgroup id & 7 is its XCD, which takes one contiguous eighth of the groups -- neighbouring frames share
+  // most of the audio they read, and a round-robin deal makes every XCD's L2 fetch all of it: 6.4 x the waveform in r04's counters)
+  int gi = blockIdx.x;
+  {
+    const int ng = gridDim.x, base = ng >> 3, rem = ng & 7, x = gi & 7;
+    gi = x * base + min(x, rem) + (gi >> 3);
+  }
+  const int f0 = gi * kFPW;
   const int tid = threadIdx.x;
   const float* aL = p.audio + (size_t)b * p.C * p.L;
   const float* aR = p.C > 1 ? aL + p.L : nullptr;
