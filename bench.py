@@ -507,7 +507,10 @@ def main() -> None:
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": int(by / n), "traffic_ratio": round(traffic / (by / n), 3) if traffic else None,
                     "kernel": dom[0], "launches_per_step": n, "avg_launch_us": round(ms / n * 1e3, 2),
-                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3), "share_of_step_time": round(ms / total_ms, 3),
+                    "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
+                    # share of the PER-OP profile (eager launches bracketed by hipEvents: their sum, `profile_sum_ms`, exceeds `ms_per_step` of the
+                    # hipGraph replay by the launch gaps of ~170 small kernels), not of the graph's step time
+                    "share_of_step_time": round(ms / total_ms, 3), "profile_sum_ms": round(total_ms, 3),
                     "step_tflops": round(B * FLOP_PER_SAMPLE / (elapsed / a.steps) / 1e12, 1),
                     # model FLOPs of the reference forward (489.3 GFLOP per sample), not executed MACs: the plan runs the up blocks' skip
                     # convs before the resample (~3 % fewer MACs), so this is throughput in the reference's units, not hardware utilisation
