@@ -83,9 +83,14 @@ template <int KS, int SK, int NF, int WN, int WM = 4, int MF = 2> struct DmaGeom
   static constexpr int NST = 2;  // (a 3-stage ring with counted vmcnt was measured on the 1x1 variant: no gain)
   static constexpr int AI = (APIECES + NW - 1) / NW, BI = (BPIECES + NW - 1) / NW;
   static constexpr int EPI_WAVE = 32 * 36 * 4;  // one 32 pixel x 32 channel fp32 patch, rows padded to 36 floats
+  // 96-channel tiles (NF = 3, round 5): two 38 KiB stages leave no room for the epilogue patches beside them at two workgroups per CU, so
+  // the patches live IN stage 1 -- free once every wave has multiplied the unit's last stage (one workgroup barrier before the epilogue; the
+  // next unit's first barrier keeps the DMA of its second stage behind the last patch read)
+  static constexpr bool EPI_ALIAS = KS == 3 && NF == 3 && WN == 1;
+  static constexpr int EPI_OFF = EPI_ALIAS ? STAGE : NST * STAGE;
   // output channel scales of the unit's BN channels, staged by DMA with the unit's first stage (two 1-KiB DMA targets, units
   // alternate): a global load inside the epilogue would wait behind the next unit's first stage, which is in flight there
-  static constexpr int CS_OFF = NST * STAGE + NW * EPI_WAVE;
+  static constexpr int CS_OFF = NST * STAGE + (EPI_ALIAS ? 0 : NW * EPI_WAVE);
   // per-wave partial sums of squares of the pixel-norm epilogue when WN waves share a pixel row (wide 1x1 units)
   static constexpr int PN_OFF = CS_OFF + 2048;
   static constexpr int SMEM = PN_OFF + (KS == 1 && WN > 1 ? NW * MF * 32 * 4 : 0);
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int NW = GEO::NW;
   constexpr int TAPS = GEO::TAPS, PAD = GEO::PAD, RB = GEO::RB, LPR = GEO::LPR, RPW = GEO::RPW, BN = GEO::BN;
-  constexpr int NST = GEO::NST, AI = GEO::AI, BI = GEO::BI;
+  [[maybe_unused]] constexpr int NST = GEO::NST;
+  constexpr int AI = GEO::AI, BI = GEO::BI;
   constexpr int KSTEPS = SK / 16;
   constexpr bool RES = NK > 0;
   constexpr bool PCS = RING > 0;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
   const rsrc_t rs0a = p.src0_alt ? make_rsrc(p.src0_alt, (size_t)p.B * p.sH * p.sW * p.C0 * 2) : rs0;
   const rsrc_t rsw = make_rsrc(p.wp, (size_t)p.G * p.nchunk * TAPS * p.NgP * p.CK * 2);
   const rsrc_t rscs = make_rsrc(p.out_cs ? (const void*)p.out_cs : p.wp, p.out_cs ? (size_t)p.B * p.Cout * 4 : 0);
-  constexpr bool CS_LDS = !EB && NF <= 2 && MF <= 2;   // (the 8-fragment variants have no registers to spare for it)
+  constexpr bool CS_LDS = !EB && NF <= 3 && MF <= 2;   // (the 8-fragment variants have no registers to spare for it)
   const bool cs_lds = CS_LDS && p.out_cs != nullptr;
   // LDS map of the WS variant: [A stage 0 | A stage 1 | nk weight stages | epilogue patches | channel scales]
   const int ws_boff = 2 * GEO::A_BYTES, ws_eoff = ws_boff + (p.Cg / SK) * GEO::B_BYTES;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     compute_at(smem + (int)stage * GEO::STAGE, smem + (int)stage * GEO::STAGE + GEO::A_BYTES);
   };
 
-  float* sE = reinterpret_cast<float*>(smem + (WS ? ws_eoff : NST * GEO::STAGE) + wave * GEO::EPI_WAVE);   // (epilogue patches of the 4-wave variants)
+  float* sE = reinterpret_cast<float*>(smem + (WS ? ws_eoff : GEO::EPI_OFF) + wave * GEO::EPI_WAVE);   // (epilogue patches of the 4-wave variants)
   bf16* out = reinterpret_cast<bf16*>(p.out);
   const bf16* res = reinterpret_cast<const bf16*>(p.res);
 
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     // Item idx = lane + 64 * tt is (pixel idx >> 2, run idx & 3): four lanes cover the 64-byte NHWC row of a pixel.  When the
     // main output is channel-blocked and nothing NHWC is read or written, (pixel (idx >> 1) & 31, run 2 * (idx >> 6) + (idx & 1)):
     // the 64 lanes of a store instruction write the 32-byte pieces of 32 consecutive pixels of ONE 16-channel plane = 1 KiB.
-    constexpr bool C16_OUT = !EB && WN == 1 && NF <= 2 && MF <= 2;
+    constexpr bool C16_OUT = !EB && WN == 1 && NF <= 3 && MF <= 2;
     const bool map16 = C16_OUT && (p.layout & 4) && p.epilogue != DDX_EPI_MPSUM && (!p.out2 || (p.layout & 8));
     auto item_px = [&](int tt) { return map16 ? (lane >> 1) : (lane >> 2) + 16 * tt; };
     auto item_c8 = [&](int tt) { return map16 ? (2 * tt + (lane & 1)) * 8 : (lane & 3) * 8; };
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PC), (WM * WN == 4 ? 2 : 1)) void c
     }
 
     // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
+    if constexpr (GEO::EPI_ALIAS && !WS) __builtin_amdgcn_s_barrier();
     if constexpr (LATE_RES) epilogue_offsets();  // (kept out of the matrix phase's register budget)
     if constexpr (!EB && KS == 1 && WN > 1) {
       if (p.epilogue == DDX_EPI_PIXELNORM) {
@@ -1029,7 +1036,7 @@ static void dma_trace_report(long total) {
 
 // dc[b][c] += scale * sum over the (pixel tile, wave) partial rows of image b written by the EB epilogue.
 // Row index = unit * NW + wave with unit = (g * ntile_n + nt) * ntile_px + b * tiles_per_image + tile.
-template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int WS = 0>
+template <int KS, int SK, int NF, int WN, int EB = 0, int WM = 4, int MF = 2, int WS = 0, int PD = 1>
 int launch_dma_t(const ConvParams& p, hipStream_t s) {
   using GEO = DmaGeom<KS, SK, NF, WN, WM, MF>;
   constexpr int WS_NK_MAX = (80 * 1024 - 2 * GEO::A_BYTES - GEO::NW * GEO::EPI_WAVE - 2048) / GEO::B_BYTES;   // weight stages that fit
@@ -1037,7 +1044,7 @@ int launch_dma_t(const ConvParams& p, hipStream_t s) {
   static_assert(GEO::SMEM <= (GEO::NW == 4 ? 80 : 160) * 1024, "LDS budget");
   if (WS && (p.Cg / SK > WS_NK_MAX)) return set_error(DDX_ERR_UNSUPPORTED, "conv_dma: weights do not fit LDS");
   static_assert(!EB || (NF <= 2 && WN == 1 && WM == 4 && MF == 2), "the fused backward epilogue keeps y in the residual registers");
-  auto kern = conv_dma_kernel<KS, SK, NF, WN, 1, EB, WM, MF, WS>;
+  auto kern = conv_dma_kernel<KS, SK, NF, WN, PD, EB, WM, MF, WS>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WS ? 80 * 1024 : SMEM_BYTES) != hipSuccess)
@@ -1121,6 +1128,17 @@ int dma_res_variant(const ConvParams& p, int TH, int TW) {
   const int cs_bytes = p.out_cs ? ((p.B * (bn / 4) + 63) / 64) * 1024 : 0;
   if (2 * nk * 340 * 32 + nk * 9 * bn * 32 + 64 + cs_bytes > 160 * 1024) return 0;
   return 1 + (nf - 1) + 2 * (nk == 4 ? 1 : 0);
+}
+
+// 3x3 layers with 96 output channels per group at full resolution (the level-0 layers of the VAE: 96 -> 96 dense, 2.8 M pixels per pair of
+// samples) take ONE 96-channel tile per unit (NF = 3) instead of a 64-channel tile and a half-empty one (25 % of their MFMAs multiplied padding).
+// Measured (tools/vae_profile.py 2, same box): the residual + twin layers 949 -> 796 us, the conv_res0 type 646 -> 605 us (away from the streaming
+// producer / consumer mode, which has no registers for a third fragment column), VAE decode 24.80 -> 24.22 ms, encode 14.01 -> 13.34 ms; layers with
+// fewer pixel tiles (levels 1-3: 192 / 288 / 480 channels) measured 10-15 % SLOWER on it and keep the 64-channel tiles.  DDX_DMA_BN96=0: off.
+bool dma_tile96(const ConvParams& p) {
+  static const bool on = []() { const char* e = std::getenv("DDX_DMA_BN96"); return !e || e[0] != '0'; }();
+  if (!on || p.epilogue == DDX_EPI_SILU_BWD || p.epilogue == DDX_EPI_PIXELNORM || p.Ng != 96) return false;
+  return (long)p.B * p.tiles_h * p.tiles_w >= 8192;
 }
 
 // 1x1 layers with >= 192 output channels per group run as 256 x 256 GEMM tiles (8 waves) when that still leaves
@@ -1252,7 +1270,7 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
   // streaming producer / consumer mode (512-pixel units) for the conv_res0-type layers with more than 64 channels per group and
   // >= 640 units: measured -5 ... -11 % on those (same command); +6 ... +18 % with the LDS-patch epilogue of the residual + twin
   // layers and slower at level 2 (384 units for 256 workgroups): not built for them.
-  if (ksize == 3 && p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0 && p.Cg % 16 == 0) {
+  if (ksize == 3 && !dma_tile96(p) && p.epilogue == DDX_EPI_STORE && !p.out2 && (p.layout & 4) && p.Ng % 32 == 0 && p.Cout % 16 == 0 && p.Cg % 16 == 0) {
     using GEO = DmaGeom<3, 16, 2, 1, 8, 2>;
     int th = 0, tw = 0; double ut = 0;
     if (dma_tile(p, 3, &th, &tw, &ut, GEO::BM, GEO::AROWS) && ut >= 0.6) {
@@ -1278,6 +1296,9 @@ int launch_conv_dma(const ConvParams& p_in, int ksize, hipStream_t s) {
     if (combos <= 64 && 512 % (8 * combos) == 0 && tiles * combos >= 1024 && nk <= (bn == 32 ? 4 : 2))
       return bn == 32 ? launch_dma_t<3, 16, 1, 1, 0, 4, 2, 1>(p, s) : launch_dma_t<3, 16, 2, 1, 0, 4, 2, 1>(p, s);
   }
+  // (fragments read just in time, PD = 0: the one-slot-ahead ring of the other variants costs 20 more registers than the 256 there are --
+  // 31 spills and 949 -> 821 us against 19 spills and 796 us)
+  if (ksize == 3 && dma_tile96(p)) return launch_dma_t<3, 16, 3, 1, 0, 4, 2, 0, 0>(p, s);
   if (ksize == 3) return p.Ng <= 32 ? launch_dma_t<3, 16, 1, 1>(p, s) : launch_dma_t<3, 16, 2, 1>(p, s);
   if (p.Ng <= 32) return launch_dma_t<1, 32, 1, 1>(p, s);
   // wide 1x1 layers on flat pixel lists: 256 | 192 pixels x 256 channels per unit, whichever leaves the 256 CUs less idle
