@@ -219,8 +219,12 @@ bool conv_gemm_supported(const ConvParams& p, int ksize, int dtype, bool auto_pi
   if (!knob) return false;
   // units: from ~2/3 of the CUs to ~1.5 per CU (measured, tools/conv_bench.py --path gemm+auto with DDX_CONV_GEMM=0: level-3 qkv 22.1 ->
   // 18.6 us, level-2 skip convs 17.2 -> 12.3, 22.2 -> 15.4, 31.8 -> 28.8 us; from 688 units (level 1) the 256-wide LDS-DMA units win)
+  // Round 5: and again from ~2 500 units (the sampler's batches: level 0 from B = 8, level 1 from B = 16) -- with operands that stream from HBM
+  // (tools/conv_bench.py --batch 32 --cold-act 3) the one-unit-per-workgroup kernel at two workgroups per CU beats the persistent 192 x 256
+  // units: level-1 skip over mp_cat 362 -> 320 us, 243 -> 219, level-0 341 -> 328 at B = 32; 127 -> 118, 93 -> 85 at B = 8 (deeper rings and
+  // 32-channel stages lose here too: 354 ... 393 us).  DDX_CONV_GEMM=2: the round-4 window only.
   const long units = (long)ceil_div((int)M, GM) * ceil_div(p.Ng, GN);
-  return p.Cin >= 256 && units >= 160 && units <= 400;
+  return p.Cin >= 256 && units >= 160 && (units <= 400 || (knob != 2 && units >= 2500));
 }
 
 int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
@@ -235,6 +239,11 @@ int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
   // 64-channel stages (whole 128-byte lines) in a two-slot ring, two workgroups per CU; 32-channel stages where the layer's channel
   // counts need them.  Measured (tools/conv_bench.py --path gemm, level-3 qkv): 32-channel stages with 2 / 3 / 4 slots 18.9 / 19.8 /
   // 19.3 us, 64-channel with 2 slots 18.6, with 3 slots (one workgroup per CU) 26.7, rings of 6 / 8 slots 31.6 / 30.1 us.
+  static const int force = []() { const char* e = std::getenv("DDX_GEMM_CFG"); return e ? atoi(e) : 0; }();   // (experiments: 322, 323, 324, 642, 643)
+  if (force == 323) return launch_cfg<32, 3>(p, a, grid, s);
+  if (force == 324) return launch_cfg<32, 4>(p, a, grid, s);
+  if (force == 322) return launch_cfg<32, 2>(p, a, grid, s);
+  if (force == 643 && !(p.C0 % 64 || (p.src1 && p.C1 % 64) || p.CK % 64)) return launch_cfg<64, 3>(p, a, grid, s);
   if (p.C0 % 64 || (p.src1 && p.C1 % 64) || p.CK % 64) return launch_cfg<32, 2>(p, a, grid, s);
   return launch_cfg<64, 2>(p, a, grid, s);
 }

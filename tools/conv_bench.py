@@ -123,12 +123,15 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--path", default="auto", help="auto | mfma | dma | sm | gemm | dma16 (LDS-DMA kernel on channel-blocked tensors) | both; a+b runs several")
     ap.add_argument("--cold", type=int, default=0, help="N > 0: cycle through N distinct prepared-weight buffers inside the timed graph (weights stream from HBM as in the network, instead of staying cache-resident)")
+    ap.add_argument("--cold-act", type=int, default=0, help="N > 0: cycle through N distinct input / output tensor sets inside the timed graph (operands stream from HBM as in the network)")
+    ap.add_argument("--batch", type=int, default=0, help="override the case's batch size")
     ap.add_argument("--epi", default="plain", help="plain | real (conv_res0: activated output with channel scales; conv_res1: residual + activated twin)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
     for name in ({"small": SMALL_M, "dma3": DMA3, "one": ONE}.get(a.cases) or a.cases.split(",")):
         B, H, W, C0, C1, Cout, G, ks, rs, pro, has_res = CASES[name]
+        B = a.batch or B
         sh, sw = (H // 2, W // 2) if rs == 1 else ((H * 2, W * 2) if rs == 2 else (H, W))
         a0 = torch.randn(B, sh, sw, C0, device=dev).to(dt)
         a1 = torch.randn(B, sh, sw, C1, device=dev).to(dt) if C1 else None
@@ -167,10 +170,22 @@ def main():
             pws = [pw]
             if a.cold > 0:
                 pws = [ops.wprep(torch.randn_like(w), G, dt, CK=pw.CK) for _ in range(a.cold)]
+            sets = [(a0, kw)]
+            for _ in range(max(a.cold_act - 1, 0)):
+                kwc = dict(kw)
+                kwc["out"] = torch.empty_like(out)
+                if kw.get("src1") is not None:
+                    kwc["src1"] = torch.randn_like(kw["src1"].float()).to(dt)
+                if kw.get("residual") is not None:
+                    kwc["residual"] = torch.randn_like(kw["residual"].float()).to(dt)
+                if kw.get("out2") is not None:
+                    kwc["out2"] = torch.empty_like(kw["out2"])
+                sets.append((torch.randn_like(a0.float()).to(dt), kwc))
             plan = L.Plan()
             with plan.record():
                 for it in range(a.iters):
-                    ops.conv2d(a0, pws[it % len(pws)], **kw)
+                    ai, kwi = sets[it % len(sets)]
+                    ops.conv2d(ai, pws[it % len(pws)], **kwi)
             cap = torch.cuda.Stream()
             plan.graph_build(cap.cuda_stream)
             cap.synchronize()
