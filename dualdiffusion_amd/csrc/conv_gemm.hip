@@ -219,12 +219,15 @@ bool conv_gemm_supported(const ConvParams& p, int ksize, int dtype, bool auto_pi
   if (!knob) return false;
   // units: from ~2/3 of the CUs to ~1.5 per CU (measured, tools/conv_bench.py --path gemm+auto with DDX_CONV_GEMM=0: level-3 qkv 22.1 ->
   // 18.6 us, level-2 skip convs 17.2 -> 12.3, 22.2 -> 15.4, 31.8 -> 28.8 us; from 688 units (level 1) the 256-wide LDS-DMA units win)
-  // Round 5: and again from ~2 500 units (the sampler's batches: level 0 from B = 8, level 1 from B = 16) -- with operands that stream from HBM
+  // Round 5: and again from 600 units (levels 0 / 1 at every batch) -- with operands that stream from HBM
   // (tools/conv_bench.py --batch 32 --cold-act 3) the one-unit-per-workgroup kernel at two workgroups per CU beats the persistent 192 x 256
   // units: level-1 skip over mp_cat 362 -> 320 us, 243 -> 219, level-0 341 -> 328 at B = 32; 127 -> 118, 93 -> 85 at B = 8 (deeper rings and
-  // 32-channel stages lose here too: 354 ... 393 us).  DDX_CONV_GEMM=2: the round-4 window only.
+  // 32-channel stages lose here too: 354 ... 393 us); at B = 4 the step reads 4.413 / 4.412 / 4.395 ms with the window opening at 2500 / 1300 / 600 units
+  // (two runs each on one box; between 400 and 600 units -- level 2 at B = 8 -- the persistent units measured 44.4 against 48.0 us).
+  // DDX_CONV_GEMM=2: the round-4 window only; DDX_GEMM_MIN_UNITS=n moves the upper window.
   const long units = (long)ceil_div((int)M, GM) * ceil_div(p.Ng, GN);
-  return p.Cin >= 256 && units >= 160 && (units <= 400 || (knob != 2 && units >= 2500));
+  static const long big = std::getenv("DDX_GEMM_MIN_UNITS") ? atol(std::getenv("DDX_GEMM_MIN_UNITS")) : 600;
+  return p.Cin >= 256 && units >= 160 && (units <= 400 || (knob != 2 && units >= big));
 }
 
 int launch_conv_gemm(const ConvParams& p, hipStream_t s) {
