@@ -87,6 +87,36 @@ class _Logvar(torch.autograd.Function):
         return None, None, g["logvar_linear.weight"].reshape(ctx.unet.logvar_linear.weight.shape)
 
 
+# ---- the same node for a torch.compile'd caller (compile_ops.unet_forward_train / unet_backward): plain functions over the trainer's tape
+_COMPILED = "compiled"      # tape-owner token of the custom-op path (the eager path's owner is its autograd ctx)
+
+
+def train_forward(unet, x_in, sigma, format, embeddings, perturbed_input, x_ref):
+    """Taped training forward of `unet` (what _UNetForward.forward runs); the tape is claimed for compile_ops.unet_backward."""
+    tr = unet._get_trainer()
+    seed = None
+    if float(getattr(unet.config, "dropout", 0.0) or 0.0) > 0:
+        seed = int(torch.randint(0, 2 ** 62, (1,), device=unet.device).item())
+    with torch.no_grad():
+        out = tr.forward(x_in, sigma, format, embeddings, perturbed_input, x_ref=x_ref, dropout_seed=seed)
+    tr._tape_owner = _COMPILED
+    return out
+
+
+def train_backward(unet, d_out, emb_dtype, xref_dtype):
+    """[d_embeddings, d_x_ref (zero-size when there was none), *parameter gradients in named_parameters() order] of the taped forward."""
+    tr = unet._get_trainer()
+    if getattr(tr, "_tape_owner", None) != _COMPILED or tr.tape is None:
+        raise DDXError("UNet backward: the activation tape of this forward is gone (one forward per backward, no double backward)")
+    grads = tr.backward(d_out.contiguous().float())
+    tr._tape_owner, tr.tape = None, None
+    d_emb = grads.pop("embeddings").to(emb_dtype)
+    d_xref = grads.pop("x_ref", None)
+    d_xref = d_xref.to(xref_dtype) if (d_xref is not None and xref_dtype is not None) else d_out.new_zeros(0)
+    g = tr.store_grads(grads)
+    return [d_emb, d_xref] + [g[k].clone().reshape(p.shape) if k in g else torch.zeros_like(p) for k, p in _named(unet)]
+
+
 def wants_grad(unet) -> bool:
     return torch.is_grad_enabled() and unet.training and any(p.requires_grad for p in unet.parameters())
 

@@ -10,22 +10,31 @@ ctypes call.  Each module forward is therefore ONE custom op with a fake (meta) 
 
 `module` / `format` are integer handles into a registry (custom ops take tensors and scalars only).  `UNet.forward`,
 `AutoencoderKL_EDM2.encode / decode` route through these ops while `torch.compiler.is_compiling()`, so a compiled caller holds the
-whole module call as one opaque node: no graph break, shapes and dtypes known to the tracer.  Inference only (the autograd bridge
-of dualdiffusion_amd.autograd is a torch.autograd.Function, which Dynamo already traces as a unit).
+whole module call as one opaque node: no graph break, shapes and dtypes known to the tracer.
+
+Training under torch.compile (the reference compiles the forward it trains with, module.py:145-149): a module in train() mode with
+trainable parameters routes through
+
+    dualdiffusion_amd::unet_forward_train(x_in, sigma, embeddings, x_ref?, perturbed_input?, params[], module, format) -> float32 [B, C_out, H, W]
+    dualdiffusion_amd::unet_backward(d_out, embeddings, x_ref?, params[], module) -> [d_embeddings, d_x_ref, *d_params]
+
+The parameters are inputs of the forward op so that AOT autograd routes their gradients; `register_autograd` connects the two ops, and
+the backward is itself an op with a fake implementation, so the joint graph traces without running a kernel.  The arithmetic is the
+eager autograd bridge's (dualdiffusion_amd.autograd: UNetTrainer.forward / backward over the trainer's tape): same gradients, bit for bit.
 """
 from __future__ import annotations
 
 import weakref
-from typing import Optional
+from typing import List, Optional
 
 import torch
 
 from ._lib import DDXError
 
-# handle -> (weak reference, type).  Dynamo traces `handle_of` itself (id() and a global dict store are supported), but the store is a
-# DEFERRED side effect: while the caller is being traced the fake implementations see the handle before the registry does.  `_get` then
-# looks the id up among the live, GC-tracked objects (the traced caller holds the object, so it is there) -- never by casting the integer
-# to a pointer: a stale or foreign handle raises instead of being dereferenced.
+# handle -> (weak reference, type).  While a caller is being traced by Dynamo `handle_of` only returns id(obj) -- no registry access at
+# all: a store would be a deferred side effect (replayed after the frame, possibly over a better entry) and any read a guard on the
+# dict's contents.  `_get` resolves an unknown handle among the live, GC-tracked objects (the traced caller holds the object, so it is
+# there) and registers it -- never by casting the integer to a pointer: a stale or foreign handle raises instead of being dereferenced.
 # Lifetime: an entry dies WITH its object (weak-reference callback), so an id() that CPython hands to a new object later cannot resolve to
 # the old slot, and nothing is kept alive by the registry.  Objects of types without weak references (none of the package's module /
 # format classes) are held strongly until `release()`.
@@ -36,12 +45,9 @@ def handle_of(obj) -> int:
     """Integer handle of a module / format object."""
     h = id(obj)
     if torch.compiler.is_compiling():
-        # traced by Dynamo: a plain (deferred) store and nothing that reads the registry -- a read would become a guard on the dict's
-        # contents that the deferred store itself breaks.  `_get` upgrades the entry (death callback, type) the first time it resolves it.
-        _OBJECTS[h] = (weakref.ref(obj), None)
         return h
     cur = _OBJECTS.get(h)
-    if cur is not None and cur[1] is not None and cur[0]() is obj:
+    if cur is not None and cur[0]() is obj:
         return h
     try:
         _OBJECTS[h] = (weakref.ref(obj, lambda _r, h=h: _OBJECTS.pop(h, None)), type(obj))
@@ -58,14 +64,12 @@ def release(obj) -> None:
 def _get(h: int):
     ent = _OBJECTS.get(h, None)
     obj = ent[0]() if ent is not None else None
-    if obj is not None and ent[1] is None:                 # stored while tracing: give it the death callback and its type now
-        handle_of(obj)
-    elif obj is not None and type(obj) is not ent[1]:      # (cannot happen with the death callback; a foreign object under a recycled id)
+    if obj is not None and type(obj) is not ent[1]:        # (cannot happen with the death callback; a foreign object under a recycled id)
         obj = None
     if obj is None:
         _OBJECTS.pop(h, None)
-        # tracing: the handle precedes the registry store (see above).  One scan of the GC-tracked objects per unknown handle -- the hit is
-        # registered, so a trace pays it once per module, not once per fake call
+        # a handle taken while tracing (see above).  One scan of the GC-tracked objects per unknown handle -- the hit is registered, so a
+        # trace pays it once per module, not once per fake call
         import gc
         obj = next((o for o in gc.get_objects() if id(o) == h and (hasattr(o, "config") or hasattr(o, "ms_freq_scale") or hasattr(o, "_forward_plan"))), None)
         if obj is None:
@@ -107,3 +111,49 @@ def vae_decode(z: torch.Tensor, class_embeddings: torch.Tensor, module: int, for
 def _(z, class_embeddings, module, format):
     vae = _get(module)
     return z.new_empty(tuple(vae.get_sample_shape(z.shape)), dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ training under torch.compile
+@torch.library.custom_op("dualdiffusion_amd::unet_forward_train", mutates_args=())
+def unet_forward_train(x_in: torch.Tensor, sigma: torch.Tensor, embeddings: torch.Tensor, x_ref: Optional[torch.Tensor],
+                       perturbed_input: Optional[torch.Tensor], params: List[torch.Tensor], module: int, format: int) -> torch.Tensor:
+    from . import autograd as A
+    unet = _get(module)
+    if len(params) != sum(1 for _ in unet.parameters()):
+        raise DDXError("unet_forward_train: `params` must be list(module.parameters())")
+    return A.train_forward(unet, x_in, sigma, _get(format), embeddings, perturbed_input, x_ref)
+
+
+@unet_forward_train.register_fake
+def _(x_in, sigma, embeddings, x_ref, perturbed_input, params, module, format):
+    cfg = _get(module).config
+    return x_in.new_empty((x_in.shape[0], cfg.out_channels, x_in.shape[2], x_in.shape[3]), dtype=torch.float32)
+
+
+@torch.library.custom_op("dualdiffusion_amd::unet_backward", mutates_args=())
+def unet_backward(d_out: torch.Tensor, embeddings: torch.Tensor, x_ref: Optional[torch.Tensor], params: List[torch.Tensor],
+                  module: int) -> List[torch.Tensor]:
+    from . import autograd as A
+    return A.train_backward(_get(module), d_out, embeddings.dtype, x_ref.dtype if x_ref is not None else None)
+
+
+@unet_backward.register_fake
+def _(d_out, embeddings, x_ref, params, module):
+    return [torch.empty_like(embeddings), torch.empty_like(x_ref) if x_ref is not None else d_out.new_empty(0)] + [torch.empty_like(p) for p in params]
+
+
+def _train_setup(ctx, inputs, output):
+    _x, _s, embeddings, x_ref, _p, params, module, _f = inputs
+    ctx.module, ctx.has_xref, ctx.n = module, x_ref is not None, len(params)
+    ctx.save_for_backward(embeddings, *([x_ref] if x_ref is not None else []), *params)    # (references: shapes / dtypes of the gradients)
+
+
+def _train_backward(ctx, d_out):
+    saved = ctx.saved_tensors
+    embeddings, x_ref = saved[0], (saved[1] if ctx.has_xref else None)
+    params = list(saved[(2 if ctx.has_xref else 1):])
+    g = unet_backward(d_out, embeddings, x_ref, params, ctx.module)
+    return None, None, g[0], (g[1] if ctx.has_xref else None), None, list(g[2:]), None, None
+
+
+unet_forward_train.register_autograd(_train_backward, setup_context=_train_setup)

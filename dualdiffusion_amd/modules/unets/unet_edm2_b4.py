@@ -201,12 +201,18 @@ class UNet(DualDiffusionUNet):
     def forward(self, x_in: torch.Tensor, sigma: torch.Tensor, format, embeddings: torch.Tensor,
                 x_ref: Optional[torch.Tensor] = None, perturbed_input: Optional[torch.Tensor] = None) -> torch.Tensor:
         """reference unet_edm2_b4.py:250-296.  Returns float32 NCHW like the reference."""
-        if torch.compiler.is_compiling() and not self.training:
+        if torch.compiler.is_compiling() and _autograd.wants_grad(self):
+            # training under torch.compile (reference module.py:145-149 compiles the forward it trains with): one custom op with an autograd
+            # registration; the parameters are inputs of the op so that their gradients are routed (compile_ops.unet_forward_train)
+            from ... import compile_ops
+            return compile_ops.unet_forward_train(x_in, sigma, embeddings, x_ref, perturbed_input, list(self.parameters()),
+                                                  compile_ops.handle_of(self), compile_ops.handle_of(format))
+        if torch.compiler.is_compiling():
             # under torch.compile the whole forward is one custom op with a fake implementation (no graph break in a compiled caller);
-            # inference only: the op has no autograd registration, so a caller that wants gradients must not get detached outputs silently
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise DDXError("the compiled HIP UNet forward is inference-only: call under torch.no_grad() or requires_grad_(False) "
-                               "(training runs the uncompiled module in train() mode through dualdiffusion_amd.autograd)")
+            # this op has no autograd registration, so a caller that wants gradients must not get detached outputs silently
+            if not self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise DDXError("autograd through the compiled HIP UNet needs the module in training mode (module.train()); "
+                               "for inference call under torch.no_grad() or requires_grad_(False)")
             from ... import compile_ops
             return compile_ops.unet_forward(x_in, sigma, embeddings, x_ref, perturbed_input, compile_ops.handle_of(self), compile_ops.handle_of(format))
         self._require_device()

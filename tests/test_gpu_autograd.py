@@ -89,6 +89,40 @@ def test_autograd_matches_reference_gradients_and_accumulates():
     assert torch.isfinite(y).all() and not y.requires_grad
 
 
+def test_compiled_forward_trains_with_the_same_gradients():
+    """Reference module.py:145-149: the trainer's module forward is torch.compile'd.  Here the compiled forward of a train()-mode module is the
+    custom op compile_ops.unet_forward_train with an autograd registration: no graph break (fullgraph), loss.backward() fills every .grad, and the
+    gradients equal the eager autograd bridge's (same kernels, same tape)."""
+    import torch._dynamo as dynamo
+    unet, t, m, cfg = _make()
+    fmt = _Fmt()
+    args = [t[k].cuda() for k in ("samples", "clap", "sigma", "noise")] + [t["mask"].bool().cuda(), t["pert"].cuda()]
+    _loss(unet, fmt, *args).mean().backward()
+    eager = {k: p.grad.clone() for k, p in unet.named_parameters()}
+    unet.zero_grad(set_to_none=True)
+
+    dynamo.reset()
+    fwd = torch.compile(lambda x, s, e, p: unet(x, s, fmt, e, None, p), backend="aot_eager", fullgraph=True)
+
+    class _Compiled:                       # the module with its forward replaced by the compiled one, as Module.compile does in the reference
+        config = unet.config
+        get_embeddings, get_sigma_loss_logvar = unet.get_embeddings, unet.get_sigma_loss_logvar
+
+        def __call__(self, x_in, sigma, format, emb, x_ref, pert):
+            return fwd(x_in, sigma, emb, pert)
+    loss = _loss(_Compiled(), fmt, *args)
+    assert loss.requires_grad and rel_l2(loss, t["loss"]) < 1e-2
+    loss.mean().backward()
+    for k, p in unet.named_parameters():
+        assert p.grad is not None, k
+        assert _same(p.grad, eager[k]), k
+    # a second compiled step reuses the graph (no retrace) and accumulates
+    _loss(_Compiled(), fmt, *args).mean().backward()
+    for k, p in unet.named_parameters():
+        assert _same(p.grad, 2 * eager[k]), k
+    dynamo.reset()
+
+
 def test_reference_shaped_loop_matches_train_step():
     """Two optimizer steps: (a) torch autograd + clip_grad_norm_ + torch.optim.AdamW + normalize_weights on the HIP module,
     (b) UNetTrainStep (fused kernels) -- same data, same draws: same weights."""

@@ -167,6 +167,49 @@ def test_module_forwards_are_single_custom_ops_under_torch_compile():
         assert tuple(lat.shape) == tuple(vae.get_latent_shape((2, 2, 64, 128)))
 
 
+def test_training_forward_is_a_differentiable_custom_op_under_torch_compile():
+    """Reference module.py:145-149 compiles the forward it trains with: in train() mode with trainable parameters the compiled UNet forward is
+    ONE op with an autograd registration (compile_ops.unet_forward_train -> unet_backward), the parameters among its inputs.  Traced here on CPU
+    through AOT autograd (forward + backward graphs from the fake implementations); running it needs the device and raises like every product path."""
+    import torch._dynamo as dynamo
+    from dualdiffusion_amd import compile_ops as CO
+    from dualdiffusion_amd.modules.unets.unet_edm2_b4 import UNet, UNetConfig
+    unet = UNet(UNetConfig(model_channels=32, channel_mult=[1, 2], num_layers_per_block=1, attn_levels=[1], channels_per_head=32,
+                           channel_mult_noise=1, channel_mult_emb=2)).train(True)
+    nparams = sum(1 for _ in unet.parameters())
+
+    class Fmt:
+        ms_freq_scale = None      # (what compile_ops recognises a format object by)
+    fmt = Fmt()
+
+    def step(x, sigma, emb, target):
+        d = unet(x, sigma, fmt, emb)
+        return ((d - target) ** 2).mean()
+
+    x, sigma, emb = torch.randn(2, 4, 16, 32), torch.ones(2), torch.randn(2, unet.cemb, requires_grad=True)
+    graphs = []
+
+    def backend(gm, example_inputs):
+        graphs.append(gm)
+        from torch._dynamo.backends.debugging import aot_eager
+        return aot_eager(gm, example_inputs)
+
+    dynamo.reset()
+    from dualdiffusion_amd._lib import DDXError
+    with pytest.raises(DDXError, match="ROCm device"):   # the joint graph traces (fake forward AND fake backward); the real forward then needs the GPU
+        torch.compile(step, backend=backend, fullgraph=True)(x, sigma, emb, torch.randn(2, 4, 16, 32))
+    assert len(graphs) == 1
+    names = [str(n.target) for n in graphs[0].graph.nodes if n.op == "call_function"]
+    assert sum("unet_forward_train" in n for n in names) == 1 and not any("unet_forward.default" in n for n in names)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        ps = [torch.empty(tuple(p.shape)) for p in unet.parameters()]
+        g = CO.unet_backward(torch.empty(2, 4, 16, 32), torch.empty(2, unet.cemb), None, ps, CO.handle_of(unet))
+        assert len(g) == 2 + nparams and g[0].shape == (2, unet.cemb) and g[1].numel() == 0
+        assert all(a.shape == b.shape for a, b in zip(g[2:], ps))
+    dynamo.reset()
+
+
 def test_trainer_options_mapping():
     """The reference `module_trainer_config` options that change the objective map onto UNetTrainStep keyword arguments (unet_trainer.py:38-72);
     what is not built is refused, not ignored."""
