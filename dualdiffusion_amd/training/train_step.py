@@ -70,8 +70,11 @@ def trainer_options(cfg: dict) -> dict:
 
 
 def check_trainer_config(cfg: dict) -> None:
-    """Reject reference `module_trainer_config` options (unet_trainer.py:38-72) that the HIP train batch does not implement, instead
-    of silently training a different objective."""
+    """Reject reference `module_trainer_config` options that the HIP train batch does not implement, instead of silently training a
+    different objective.  Every option of the live trainer (unet_trainer.py:38-72) is implemented (trainer_options); what is left is
+    `inpainting_probability`, an option of the retired `module_trainers/old/unet_trainer_b4.py:73-80` (that module no longer imports in
+    the reference: its `.module_trainer` sibling is gone) -- the live trainer takes the reference samples from its caller
+    (`ref_samples`, unet_trainer.py:223,260), and so does UNetTrainStep.step / run_batch."""
     bad = [k for k in ("inpainting_probability",) if cfg.get(k) not in (None, 0, 0.0, False)]
     if bad:
         raise NotImplementedError(f"UNetTrainStep: trainer options not implemented on the HIP path: {bad}")
