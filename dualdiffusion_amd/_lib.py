@@ -137,7 +137,8 @@ class MssDesc(C.Structure):
     _fields_ = [("sample", C.c_void_p), ("target", C.c_void_p), ("window", C.c_void_p), ("weight", C.c_void_p),
                 ("twiddle", C.c_void_p), ("loss", C.c_void_p), ("grad", C.c_void_p),
                 ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("block_width", C.c_int32),
-                ("step", C.c_int32), ("midside", C.c_int32), ("use_mse", C.c_int32), ("loss_scale", C.c_float)]
+                ("step", C.c_int32), ("midside", C.c_int32), ("use_mse", C.c_int32), ("loss_scale", C.c_float),
+                ("phase_scale", C.c_float), ("weight_ld", C.c_int32), ("reserved", C.c_int32), ("stats", C.c_void_p)]
 
 
 class LinearJob(C.Structure):

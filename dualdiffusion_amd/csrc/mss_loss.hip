@@ -20,8 +20,11 @@ namespace ddx {
 struct MssParams {
   const float* sample; const float* target; const float* window; const float* weight; const float2* tw;
   float* loss; float* grad;
+  float* stats;   // statistics launch (mss_loss_reg_kernel<W, true>): stats[c][kh][kw] += sum over (b, blocks) |T_c|
   int B, H, Wd, step, nbh, nbw, midside, use_mse;
-  float scale;  // abs_loss_scale / (channels * nbh * nbw * w * (w/2+1))
+  int weight_ld;  // floats between the weight tables of the two channels (0: one table)
+  float norm;     // 1 / (channels * nbh * nbw * w * (w/2+1)): the mean over everything but the batch
+  float abs_scale, phase_scale;
 };
 
 constexpr int kMssPts = 4096;   // block pixels per workgroup (1 block of 64 x 64 ... 64 blocks of 8 x 8)
@@ -106,7 +109,7 @@ __device__ __forceinline__ void mss_reg_lines(cf* __restrict__ x0, cf* __restric
   __syncthreads();
 }
 
-template <int W>
+template <int W, bool STATS = false>
 __global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p) {
   constexpr int NBLK = kMssPts / (W * W);
   constexpr int P = W + 1, BSZ = W * P, ASZ = NBLK * BSZ;
@@ -147,14 +150,42 @@ __global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p)
       const int gx = reflect_pad_index(bx * p.step - W / 2 + c, p.Wd);
       const float w = p.window[r * W + c];
       const size_t o = (size_t)gy * p.Wd + gx;
-      zs = cf{sL[o] * w, sR[o] * w};
+      if constexpr (!STATS) zs = cf{sL[o] * w, sR[o] * w};
       zt = cf{tL[o] * w, tR[o] * w};
     }
-    A[blk * BSZ + r * P + c] = zs;
+    if constexpr (!STATS) A[blk * BSZ + r * P + c] = zs;
     Bt[blk * BSZ + r * P + c] = zt;
   }
   __syncthreads();
   constexpr int SPLIT = W == 64 ? 2 : 1;
+  if constexpr (STATS) {
+    // ---- statistics launch (frequency_weighting = "dynamic", multiscale_spectral.py:252-253): sum of |T_c[kh][kw]| over the blocks, first
+    // over the workgroup's blocks in LDS (the sample half of the buffer is free), then one global atomic per table entry
+    mss_reg_lines<W, false, true, SPLIT>(Bt, nullptr, 1);
+    mss_reg_lines<W, false, false, SPLIT>(Bt, nullptr, 1);
+    float* tab = reinterpret_cast<float*>(A);
+    for (int i = tid; i < 2 * W * HB; i += kRegNT) tab[i] = 0.f;
+    __syncthreads();
+    const float inv_w = 1.0f / (float)W;
+#pragma unroll
+    for (int it = 0; it < NITEM; ++it) {
+      const int idx = tid + it * kRegNT;
+      if (idx >= NHALF) continue;
+      const int blk = idx / (W * HB), rem = idx - blk * (W * HB);
+      const int kh = rem / HB, kw = rem - kh * HB;
+      if (bx0 + blk >= p.nbw) continue;
+      const cf z = Bt[blk * BSZ + kh * P + kw], zc = cconj(Bt[blk * BSZ + ((W - kh) % W) * P + ((W - kw) % W)]);
+      const cf sum = cadd(z, zc), dif = csub(z, zc);
+      const cf xl{0.5f * inv_w * sum.x, 0.5f * inv_w * sum.y};
+      const cf xr{0.5f * inv_w * dif.y, -0.5f * inv_w * dif.x};
+      const cf c0 = p.midside ? cadd(xl, xr) : xl, c1 = p.midside ? csub(xl, xr) : xr;
+      atomicAdd(tab + rem, sqrtf(c0.x * c0.x + c0.y * c0.y));
+      atomicAdd(tab + W * HB + rem, sqrtf(c1.x * c1.x + c1.y * c1.y));
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * W * HB; i += kRegNT) unsafeAtomicAdd(p.stats + i, tab[i]);
+    return;
+  }
   mss_reg_lines<W, false, true, SPLIT>(A, Bt, 2);
   mss_reg_lines<W, false, false, SPLIT>(A, Bt, 2);
 
@@ -182,18 +213,27 @@ __global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p)
     cf s0, s1, t0, t1;
     unmix(A, s0, s1);
     unmix(Bt, t0, t1);
-    const float wgt = p.weight[kh * HB + kw];
-    auto term = [&](cf s, cf t, cf& g) {
+    const float wgt0 = p.weight[kh * HB + kw], wgt1 = p.weight[p.weight_ld + kh * HB + kw];
+    auto dist = [&](float d, float& gd) {       // L1 or squared distance and its derivative
+      gd = p.use_mse ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      return p.use_mse ? d * d : fabsf(d);
+    };
+    auto term = [&](cf s, cf t, float wgt, cf& g) {
       const float as = sqrtf(s.x * s.x + s.y * s.y), at = sqrtf(t.x * t.x + t.y * t.y);
-      const float d = as - at;
-      lsum += wgt * (p.use_mse ? d * d : fabsf(d));
-      const float gd = p.use_mse ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-      const float f = as > 0.f ? p.scale * wgt * gd / as : 0.f;
+      float gd;
+      lsum += wgt * p.abs_scale * dist(as - at, gd);
+      const float f = as > 0.f ? p.norm * p.abs_scale * wgt * gd / as : 0.f;
       g = cf{f * s.x, f * s.y};
+      if (p.phase_scale != 0.f) {               // the same distance on the real and imaginary parts (multiscale_spectral.py:275-277, :286-288)
+        float gr_, gi_;
+        lsum += wgt * p.phase_scale * (dist(s.x - t.x, gr_) + dist(s.y - t.y, gi_));
+        const float fp = p.norm * p.phase_scale * wgt;
+        g.x += fp * gr_; g.y += fp * gi_;
+      }
     };
     cf g0, g1;
-    term(s0, t0, g0);
-    term(s1, t1, g1);
+    term(s0, t0, wgt0, g0);
+    term(s1, t1, wgt1, g1);
     if (p.midside) { gl[it] = cadd(g0, g1); gr[it] = csub(g0, g1); } else { gl[it] = g0; gr[it] = g1; }
   }
   lsum = wave_sum(lsum);
@@ -203,7 +243,7 @@ __global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p)
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < kRegNT / 64; ++w) tot += red[w];
-    atomicAdd(p.loss + b, tot * p.scale);
+    atomicAdd(p.loss + b, tot * p.norm);
   }
   if (!p.grad) return;
 
@@ -272,11 +312,11 @@ __global__ __launch_bounds__(kRegNT) void mss_loss_reg_kernel(const MssParams p)
   }
 }
 
-template <int W>
+template <int W, bool STATS = false>
 static int launch_mss_reg(const MssParams& p, hipStream_t s) {
   constexpr int NBLK = kMssPts / (W * W);
   const size_t smem = 2 * (size_t)NBLK * W * (W + 1) * sizeof(cf);
-  auto kern = mss_loss_reg_kernel<W>;
+  auto kern = mss_loss_reg_kernel<W, STATS>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -295,7 +335,10 @@ using namespace ddx;
 extern "C" int ddx_mss_loss_scale(const ddx_mss_desc* dp, ddx_stream stream) {
   if (!dp) return set_error(DDX_ERR_ARG, "mss_loss: null descriptor");
   const ddx_mss_desc d = *dp;
-  if (!d.sample || !d.target || !d.window || !d.weight || !d.twiddle || !d.loss) return set_error(DDX_ERR_ARG, "mss_loss: null buffer");
+  const bool stats = d.stats != nullptr;
+  if (!d.target || !d.window || !d.twiddle) return set_error(DDX_ERR_ARG, "mss_loss: null buffer");
+  if (!stats && (!d.sample || !d.weight || !d.loss)) return set_error(DDX_ERR_ARG, "mss_loss: null buffer");
+  if (d.loss_scale < 0.f || d.phase_scale < 0.f || d.weight_ld < 0) return set_error(DDX_ERR_ARG, "mss_loss: negative scale / stride");
   if (d.C != 2) return set_error(DDX_ERR_UNSUPPORTED, "mss_loss: stereo (C = 2) only");
   const int w = d.block_width;
   if (w != 8 && w != 16 && w != 32 && w != 64) return set_error(DDX_ERR_UNSUPPORTED, "mss_loss: block width must be 8, 16, 32 or 64");
@@ -303,15 +346,24 @@ extern "C" int ddx_mss_loss_scale(const ddx_mss_desc* dp, ddx_stream stream) {
   MssParams p{};
   p.sample = d.sample; p.target = d.target; p.window = d.window; p.weight = d.weight;
   p.tw = reinterpret_cast<const float2*>(d.twiddle);
-  p.loss = d.loss; p.grad = d.grad;
+  p.loss = d.loss; p.grad = d.grad; p.stats = d.stats;
+  p.weight_ld = d.weight_ld; p.abs_scale = d.loss_scale; p.phase_scale = d.phase_scale;
   p.B = d.B; p.H = d.H; p.Wd = d.W; p.step = d.step;
   p.nbh = d.H / d.step + 1; p.nbw = d.W / d.step + 1;  // unfold count of the (H + w)-padded axis
   p.midside = d.midside; p.use_mse = d.use_mse;
-  p.scale = d.loss_scale / ((float)2 * p.nbh * p.nbw * w * (w / 2 + 1));
+  p.norm = 1.0f / ((float)2 * p.nbh * p.nbw * w * (w / 2 + 1));
   const double blocks = (double)p.B * p.nbh * p.nbw;
   const double flops = blocks * 3.0 * 2.0 * w * (5.0 * w * log2((double)w));  // three complex 2-D FFTs per block
   const double bytes = (double)p.B * 2 * d.H * d.W * 4 * (d.grad ? 3 : 2);
-  return dispatch([p, w](hipStream_t s) -> int {
+  return dispatch([p, w, stats](hipStream_t s) -> int {
+    if (stats) {
+      switch (w) {
+        case 8: return launch_mss_reg<8, true>(p, s);
+        case 16: return launch_mss_reg<16, true>(p, s);
+        case 32: return launch_mss_reg<32, true>(p, s);
+        default: return launch_mss_reg<64, true>(p, s);
+      }
+    }
     switch (w) {
       case 8: return launch_mss_reg<8>(p, s);
       case 16: return launch_mss_reg<16>(p, s);

@@ -96,7 +96,7 @@ extern "C" int64_t ddx_abi_offsetof_tail(int32_t which) {
     case 7: return offsetof(ddx_melstft_desc, scale);
     case 8: return offsetof(ddx_msmel_desc, offset);
     case 9: return offsetof(ddx_bgemm_desc, alpha);
-    case 10: return offsetof(ddx_mss_desc, loss_scale);
+    case 10: return offsetof(ddx_mss_desc, stats);
     case 11: return offsetof(ddx_optim_job, n);
     case 12: return offsetof(ddx_optim_job_ex, reserved);
     case 13: return offsetof(ddx_conv_pair_desc, out2_scale);

@@ -4,8 +4,11 @@ Mirrors reference src/training/loss/multiscale_spectral.py:121-296: `MSSLoss2DCo
 `mss_loss(sample, target) -> Tensor[B]`, `compile()`.  The unfold / rfft2 / abs / weighted mean chain AND its backward
 run as one HIP kernel per block width (`ddx_mss_loss_scale`), so `mss_loss` returns a tensor whose `backward()` hands
 the pre-computed gradient to `sample`.  Host side only builds the window / weight / twiddle tables (:147-174).
-Unsupported reference options raise (no fallback): `frequency_weighting="dynamic"`, `use_midside_transform="cat"`,
-`phase_loss_scale > 0`, `block_window_fn="flat_top_circular"`, block widths other than 8/16/32/64, non-stereo inputs.
+Every option of `MSSLoss2DConfig` is served: the five window functions (2-D tables), static or `"dynamic"` frequency weighting (a
+statistics launch per width sums |T| over batch and blocks, :252-253; the weights become per-channel tables), mid/side `"stack"`,
+`"none"` and `"cat"` (two launches per width: (L, R) and (L+R, L-R), the latter scaled by sqrt(1/2) [L1] or 1/2 [MSE] -- the mean over
+the four channels of :229-231), L1 / MSE, `abs_loss_scale` (0 allowed) and `phase_loss_scale`.  Block widths other than 8/16/32/64 and
+non-stereo inputs raise (no fallback).
 """
 from __future__ import annotations
 
@@ -64,14 +67,12 @@ class MSSLoss2D:
     def __init__(self, config: MSSLoss2DConfig, device: torch.device) -> None:
         self.config = config
         self.device = torch.device(device)
-        if config.frequency_weighting == "dynamic":
-            raise NotImplementedError("MSSLoss2D: frequency_weighting='dynamic' is not built")
-        if config.use_midside_transform == "cat":
-            raise NotImplementedError("MSSLoss2D: use_midside_transform='cat' is not built")
-        if config.phase_loss_scale > 0:
-            raise NotImplementedError("MSSLoss2D: phase loss is not built")
-        if config.abs_loss_scale <= 0:
-            raise ValueError("MSSLoss2D: abs_loss_scale must be positive")
+        if config.frequency_weighting not in ("product", "f^2", "dynamic"):
+            raise ValueError(f"Invalid frequency weighting: {config.frequency_weighting}")
+        if config.use_midside_transform not in ("stack", "cat", "none", None):
+            raise ValueError(f"Invalid midside transform type: {config.use_midside_transform}")
+        if config.abs_loss_scale < 0 or config.phase_loss_scale < 0:
+            raise ValueError("MSSLoss2D: abs_loss_scale / phase_loss_scale must not be negative")
         self.steps, self.windows, self.loss_weights, self.twiddles = [], [], [], []
         for w in config.block_widths:
             if w not in (8, 16, 32, 64):
@@ -88,22 +89,29 @@ class MSSLoss2D:
                 window = torch.outer(w1, w1)
             elif config.block_window_fn == "none":
                 window = torch.ones((w, w))
+            elif config.block_window_fn == "flat_top_circular":     # multiscale_spectral.py:200-211: radial, zero outside the inscribed circle
+                xc, yc = (torch.arange(w) + 0.5).view(1, -1), (torch.arange(w) + 0.5).view(-1, 1)
+                dist = torch.sqrt((xc - w / 2) ** 2 + (yc - w / 2) ** 2) / (w // 2)
+                window = _flat_top(dist * torch.pi + torch.pi) * (dist <= 1)
             else:
-                raise NotImplementedError(f"MSSLoss2D: block_window_fn={config.block_window_fn!r} is not built")
+                raise ValueError(f"Invalid block window function: {config.block_window_fn}")
             window = window / window.square().mean().sqrt()
             self.windows.append(window.float().contiguous().to(self.device))
             fh = torch.fft.fftfreq(w, d=1 / w)
             fw = torch.fft.rfftfreq(w, d=1 / w)
-            if config.frequency_weighting == "product":
-                lw = (fh.view(-1, 1).abs() + 1) * (fw.view(1, -1).abs() + 1)
+            if config.frequency_weighting == "dynamic":
+                self.loss_weights.append(None)      # derived from the target in every call (_dynamic_weights)
             else:
-                lw = fh.view(-1, 1) ** 2 + fw.view(1, -1) ** 2 + 1
-            lw = lw.float()
-            if config.frequency_weight_exponent != 1:
-                lw = lw.pow(config.frequency_weight_exponent)
-            if config.block_width_weight_exponent != 0:
-                lw = lw * (w ** config.block_width_weight_exponent)
-            self.loss_weights.append(lw.contiguous().to(self.device))
+                if config.frequency_weighting == "product":
+                    lw = (fh.view(-1, 1).abs() + 1) * (fw.view(1, -1).abs() + 1)
+                else:
+                    lw = fh.view(-1, 1) ** 2 + fw.view(1, -1) ** 2 + 1
+                lw = lw.float()
+                if config.frequency_weight_exponent != 1:
+                    lw = lw.pow(config.frequency_weight_exponent)
+                if config.block_width_weight_exponent != 0:
+                    lw = lw * (w ** config.block_width_weight_exponent)
+                self.loss_weights.append(lw.contiguous().to(self.device))
             ang = torch.arange(w, dtype=torch.float64) * (2 * math.pi / w)
             self.twiddles.append(torch.stack((ang.cos(), -ang.sin()), dim=1).float().contiguous().to(self.device))
 
@@ -118,15 +126,48 @@ class MSSLoss2D:
         loss = torch.zeros(B, device=s.device, dtype=torch.float32)
         grad = torch.zeros_like(s) if need_grad else None
         cfg = self.config
+        use_mse = bool(cfg.use_mse_loss)
+        # mid/side modes as (kernel midside flag, factor on the loss of that launch): "cat" is the mean over the four channels
+        # (L, R, (L+R)/sqrt 2, (L-R)/sqrt 2) = half the (L, R) launch + half the (L+R, L-R) launch scaled by sqrt(1/2) (L1) or 1/2 (MSE)
+        if cfg.use_midside_transform == "stack":
+            modes = [(1, 1.0, 1.0)]
+        elif cfg.use_midside_transform == "cat":
+            modes = [(0, 0.5, 1.0), (1, 0.5 * (0.5 if use_mse else 0.5 ** 0.5), 0.5 ** 0.5)]
+        else:
+            modes = [(0, 1.0, 1.0)]
         for i, w in enumerate(cfg.block_widths):
             if w > W:                      # multiscale_spectral.py:243-244
                 continue
-            d = L.MssDesc(sample=ptr(s), target=ptr(t), window=ptr(self.windows[i]), weight=ptr(self.loss_weights[i]),
-                          twiddle=ptr(self.twiddles[i]), loss=ptr(loss), grad=ptr(grad), B=B, C=Cn, H=H, W=W, block_width=w,
-                          step=self.steps[i], midside=1 if cfg.use_midside_transform == "stack" else 0,
-                          use_mse=int(bool(cfg.use_mse_loss)), loss_scale=float(cfg.abs_loss_scale))
-            check(lib().ddx_mss_loss_scale(C.byref(d), current_stream()), "mss_loss_scale")
+            for midside, factor, amp in modes:
+                if cfg.frequency_weighting == "dynamic":
+                    weight, weight_ld = self._dynamic_weights(t, i, midside, amp), w * (w // 2 + 1)
+                else:
+                    weight, weight_ld = self.loss_weights[i], 0
+                d = L.MssDesc(sample=ptr(s), target=ptr(t), window=ptr(self.windows[i]), weight=ptr(weight),
+                              twiddle=ptr(self.twiddles[i]), loss=ptr(loss), grad=ptr(grad), B=B, C=Cn, H=H, W=W, block_width=w,
+                              step=self.steps[i], midside=midside, use_mse=int(use_mse), loss_scale=float(cfg.abs_loss_scale) * factor,
+                              phase_scale=float(cfg.phase_loss_scale) * factor, weight_ld=weight_ld, reserved=0, stats=None)
+                check(lib().ddx_mss_loss_scale(C.byref(d), current_stream()), "mss_loss_scale")
         return loss, grad
+
+    def _dynamic_weights(self, t: torch.Tensor, i: int, midside: int, amp: float) -> torch.Tensor:
+        """frequency_weighting = "dynamic" (multiscale_spectral.py:252-259): 1 / clip(mean over batch and blocks of |T_c[kh][kw]|, 1e-2) per
+        channel and frequency, then the two exponents.  The sums come from the statistics launch of the loss kernel; `amp` is the
+        amplitude factor of the launch's channels (sqrt(1/2) for the mid/side half of "cat")."""
+        cfg, w = self.config, self.config.block_widths[i]
+        B, Cn, H, W = t.shape
+        stats = torch.zeros(2, w, w // 2 + 1, device=t.device, dtype=torch.float32)
+        d = L.MssDesc(sample=None, target=ptr(t), window=ptr(self.windows[i]), weight=None, twiddle=ptr(self.twiddles[i]), loss=None, grad=None,
+                      B=B, C=Cn, H=H, W=W, block_width=w, step=self.steps[i], midside=midside, use_mse=0, loss_scale=0.0, phase_scale=0.0,
+                      weight_ld=0, reserved=0, stats=ptr(stats))
+        check(lib().ddx_mss_loss_scale(C.byref(d), current_stream()), "mss_loss_scale(stats)")
+        nblk = B * (H // self.steps[i] + 1) * (W // self.steps[i] + 1)
+        lw = 1.0 / (stats * (amp / nblk)).clip(min=1e-2)
+        if cfg.frequency_weight_exponent != 1:
+            lw = lw.pow(cfg.frequency_weight_exponent)
+        if cfg.block_width_weight_exponent != 0:
+            lw = lw * (w ** cfg.block_width_weight_exponent)
+        return lw.contiguous()
 
     def mss_loss(self, sample: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         return _MSSFunction.apply(sample, target, self)

@@ -618,13 +618,19 @@ int ddx_softmax_bwd_rows_f32(const void* p, const void* dp, void* ds, int64_t ro
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-scale 2-D spectral loss, one block width per call  (training/loss/multiscale_spectral.py:213-294 `MSSLoss2D.stft2d`
- * + `mss_loss`, static frequency weighting, phase_loss_scale = 0) -- value AND gradient in one pass:
- *   loss[b] += loss_scale * mean_{c,blocks,kh,kw} weight[kh][kw] * | |S| - |T| |   (use_mse: squared)
+ * + `mss_loss`) -- value AND gradient in one pass:
+ *   loss[b] += mean_{c,blocks,kh,kw} weight[c][kh][kw] * ( loss_scale * | |S| - |T| | + phase_scale * (|Re S - Re T| + |Im S - Im T|) )
+ *              (use_mse: squared distances; loss_scale = abs_loss_scale, phase_scale = phase_loss_scale, either may be 0)
  *   grad    += d(sum_b loss[b]) / d(sample)            (grad NULL: value only)
  *   S, T = rfft2(window * block, ortho) of the reflect-padded (w/2) sample / target, blocks every `step` pixels,
  *   midside 1: channels (L+R, L-R) (`use_midside_transform="stack"`), 0: (L, R).
  * sample, target, grad: [B][2][H][W] fp32; window [w][w]; weight [w][w/2+1]; twiddle [w] = (cos, -sin)(2 pi k / w) (must be a valid buffer; the line transforms carry their factors as literals since round 4);
  * loss [B] fp32.  loss and grad are ACCUMULATED: zero them before the first block width.  w in {8, 16, 32, 64}.
+ * weight_ld: floats between the weight tables of the call's two channels (0: one table for both -- the static weightings).
+ * stats non-NULL: STATISTICS call for frequency_weighting = "dynamic" (:252-253): no loss; stats[c][kh][kw] (2 x w x (w/2+1) floats,
+ *   zeroed by the caller) += sum over (b, blocks) of |T_c[kh][kw]|; sample / weight / loss / grad are not read.  The caller divides by
+ *   B * (H / step + 1) * (W / step + 1), clips and inverts it into the per-channel weight tables of the loss call.
+ * use_midside_transform = "cat" is two calls per width (midside 0 and 1) with scaled loss_scale / phase_scale (host side).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   const float* sample;
@@ -637,6 +643,9 @@ typedef struct {
   int32_t B, C, H, W;
   int32_t block_width, step, midside, use_mse;
   float loss_scale;
+  float phase_scale;
+  int32_t weight_ld, reserved;
+  float* stats;
 } ddx_mss_desc;
 
 int ddx_mss_loss_scale(const ddx_mss_desc* d, ddx_stream stream);

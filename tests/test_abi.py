@@ -39,7 +39,7 @@ def test_descriptor_struct_layout_matches_header():
     from dualdiffusion_amd import _lib
     assert ctypes.sizeof(_lib.WPrepDesc) == 96  # 3 pointers, float, 10 int32, 2 floats, int32 transpose, pointer row_scale, 2 int32
     assert ctypes.sizeof(_lib.WgradDesc) == 88  # 5 pointers, 11 int32 (+4 tail padding)
-    assert ctypes.sizeof(_lib.MssDesc) == 96    # 7 pointers, 8 int32, float (+4 tail padding)
+    assert ctypes.sizeof(_lib.MssDesc) == 112   # 7 pointers, 8 int32, 2 floats, 2 int32, pointer
     assert ctypes.sizeof(_lib.WPathJob) == 120  # 8 pointers, float, 9 int32, 2 floats, 2 int32
     assert ctypes.sizeof(_lib.LinearBwdJob) == 40  # 4 pointers, 2 int32
     assert ctypes.sizeof(_lib.DgradActDesc) == 192 + 7 * 8 + 4 * 4

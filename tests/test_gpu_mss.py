@@ -17,11 +17,13 @@ def _loss(meta):
     cfg = MSSLoss2DConfig(block_widths=tuple(meta["block_widths"]), block_overlap=meta["block_overlap"], block_window_fn=meta["window_fn"],
                           frequency_weighting=meta["weighting"], frequency_weight_exponent=meta["weight_exponent"],
                           block_width_weight_exponent=meta["width_weight_exponent"], use_midside_transform=meta["midside"],
-                          use_mse_loss=meta["use_mse"])
+                          use_mse_loss=meta["use_mse"], abs_loss_scale=meta.get("abs_loss_scale", 1.0), phase_loss_scale=meta.get("phase_loss_scale", 0.0))
     return MSSLoss2D(cfg, torch.device("cuda"))
 
 
-@pytest.mark.parametrize("name", ["default", "hann_f2_mse", "ragged"])
+# (the last five: every MSSLoss2DConfig option beyond the defaults -- circular window, mid/side "cat", phase terms with L1 and MSE, dynamic
+# frequency weights from the statistics launch, and their combination)
+@pytest.mark.parametrize("name", ["default", "hann_f2_mse", "ragged", "circular_cat", "phase_l1", "phase_mse_cat", "dynamic", "dynamic_cat_phase"])
 def test_mss_matches_reference(name):
     t, m = load_golden("mss_loss")
     mss = _loss(m[name])

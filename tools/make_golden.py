@@ -555,6 +555,13 @@ def gen_mss() -> None:
         "hann_f2_mse": (dict(block_window_fn="hann", frequency_weighting="f^2", use_mse_loss=True, use_midside_transform="none",
                              block_widths=(8, 32), frequency_weight_exponent=0.5, block_width_weight_exponent=0.25), (1, 2, 48, 40)),
         "ragged": (dict(block_widths=(16, 64), block_overlap=4, block_window_fn="none"), (1, 2, 70, 50)),   # 64 > W: skipped
+        # the options of MSSLoss2DConfig beyond the defaults (round 5): circular window, mid/side "cat", phase terms, dynamic weights
+        "circular_cat": (dict(block_window_fn="flat_top_circular", use_midside_transform="cat", block_widths=(8, 16, 32)), (2, 2, 40, 72)),
+        "phase_l1": (dict(phase_loss_scale=0.5, block_widths=(8, 64)), (1, 2, 72, 80)),
+        "phase_mse_cat": (dict(phase_loss_scale=0.25, abs_loss_scale=2.0, use_mse_loss=True, use_midside_transform="cat", block_widths=(16, 32)), (2, 2, 48, 48)),
+        "dynamic": (dict(frequency_weighting="dynamic", block_widths=(8, 16, 32, 64), frequency_weight_exponent=0.5), (3, 2, 64, 80)),
+        "dynamic_cat_phase": (dict(frequency_weighting="dynamic", use_midside_transform="cat", phase_loss_scale=0.3, block_widths=(16, 32),
+                                   block_width_weight_exponent=0.5), (2, 2, 40, 56)),
     }
     for name, (kw, shape) in cases.items():
         g = torch.Generator().manual_seed(sum(map(ord, name)))
@@ -567,7 +574,8 @@ def gen_mss() -> None:
         okw = dict(block_widths=kw.get("block_widths", (8, 16, 32, 64)), block_overlap=kw.get("block_overlap", 8),
                    window_fn=kw.get("block_window_fn", "flat_top"), weighting=kw.get("frequency_weighting", "product"),
                    weight_exponent=kw.get("frequency_weight_exponent", 1.0), width_weight_exponent=kw.get("block_width_weight_exponent", 0.0),
-                   midside=kw.get("use_midside_transform", "stack"), use_mse=kw.get("use_mse_loss", False))
+                   midside=kw.get("use_midside_transform", "stack"), use_mse=kw.get("use_mse_loss", False),
+                   abs_loss_scale=kw.get("abs_loss_scale", 1.0), phase_loss_scale=kw.get("phase_loss_scale", 0.0))
         ol, og = M.mss_loss_and_grad(sample, target, **okw)
         check(f"mss {name} loss", ol, loss.detach(), 1e-6)
         check(f"mss {name} grad", og, s.grad, 1e-5)
